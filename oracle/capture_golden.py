@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Capture golden vectors from the imported reference  --  TEST INFRASTRUCTURE.
+
+Runs ONLY in the build container, where the reference is mounted read-only at
+/root/reference; it writes nothing but inputs and the reference's outputs
+(``tests/golden/*.npz`` / ``*.json``).  The GPU box has no reference: tests
+there read these fixtures.
+
+    python oracle/capture_golden.py            # regenerate every fixture
+
+Fixtures:
+  kat_n10.json            the reference's own known-answer vector and table
+                          (features.py:240-255, 286-305) restated as data
+  frames_n{N}.npz         N in {1024, 2048, 4096}: 6 mods x 3 SNR x 2 frames
+                          complex64 inputs; golden64 (reference on complex128
+                          input, float32-stored as feature_extraction.py:35,56
+                          does) + its unrounded float64; golden32 (reference on
+                          the complex64 input as is); the 11 moments
+  edges_n{N}.npz          degenerate frames and what the reference returns
+  extract_roundtrip.npz   a tiny `run_extraction(cfg)` run by the reference:
+                          input container + the six output files' contents
+"""
+
+from __future__ import annotations
+
+import json
+import os
+import sys
+import tempfile
+import warnings
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parents[1]
+REF_SRC = Path("/root/reference/src")
+OUT = REPO / "tests" / "golden"
+
+sys.dont_write_bytecode = True
+sys.path.insert(0, str(REPO))
+
+
+def _import_reference():
+    if not REF_SRC.exists():
+        raise SystemExit("reference not mounted at /root/reference: nothing to capture")
+    sys.path.insert(0, str(REF_SRC))
+    import amcpy.config as rcfg                       # noqa: E402
+    import amcpy.feature_extraction as rfe            # noqa: E402
+    import amcpy.features as rfeat                    # noqa: E402
+    return rfeat, rfe, rcfg
+
+
+def _ref18(rfeat, frame, dtype):
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with np.errstate(all="ignore"):
+            return np.array(rfeat.calculate_features(list(range(1, 19)), frame.astype(dtype)),
+                            dtype=np.float64)
+
+
+def _ref_moments(rfeat, frame):
+    m = rfeat.MomentValues(frame.astype(np.complex128))
+    return np.array([complex(getattr(m, k)) for k in
+                     ("m20", "m21", "m22", "m40", "m41", "m42", "m43", "m60", "m61", "m62", "m63")])
+
+
+def capture_kat(rfeat):
+    sig = rfeat._test_signal()
+    # the table the reference asserts at rtol=1e-5 (features.py:286-305)
+    expected = [405.0, 0.940293603578649, 1.5903100728408748, 0.3312693299999689,
+                0.5153882032022075, 6.363961030678928, 0.7977443845417482,
+                1.7757575757575754, 1.0627162629757787, 57.0, 57.0, 3613.8, 3613.8,
+                3613.8, 3905583.0, 1094628.0, 311904.0, 1094628.0]
+    got = _ref18(rfeat, sig, np.complex128)
+    assert np.allclose(got, expected, rtol=1e-5), "reference disagrees with its own table?"
+    iv = rfeat.InstantaneousValues(sig)
+    mv = rfeat.MomentValues(sig)
+    doc = {
+        "source": "reference features.py:240-255 (_test_signal), :286-305 (expected), "
+                  ":258-271 / :274-280 (spot values)",
+        "signal_re": [float(v.real) for v in sig],
+        "signal_im": [float(v.imag) for v in sig],
+        "expected": expected,
+        "rtol": 1e-5,
+        "reference_output_float64": [float(v) for v in got],
+        "spot": {"abs1": float(iv.abs[1]), "cna0": float(iv.cn_amplitude[0]),
+                 "cna_last": float(iv.cn_amplitude[-1]), "len_frequency": int(len(iv.frequency)),
+                 "m21": float(mv.m21), "m42": float(mv.m42), "m63": float(np.real(mv.m63))},
+    }
+    (OUT / "kat_n10.json").write_text(json.dumps(doc, indent=1))
+
+
+def capture_frames(rfeat, N):
+    from amcpy_amd import synth
+    snrs = (-10.0, 4.0, 20.0)
+    frames, tags = [], []
+    for mi, mod in enumerate(synth.MODS6):
+        for si, snr in enumerate(snrs):
+            blk = synth.host_block(mod, snr, 2, N, seed=1000 + 10 * mi + si)
+            frames.append(blk)
+            tags += [f"{mod}@{snr:g}dB#{k}" for k in range(2)]
+    x = np.concatenate(frames, axis=0).astype(np.complex64)
+    g64 = np.stack([_ref18(rfeat, f, np.complex128) for f in x])
+    g32 = np.stack([_ref18(rfeat, f, np.complex64) for f in x])
+    mom = np.stack([_ref_moments(rfeat, f) for f in x])
+    np.savez(OUT / f"frames_n{N}.npz", iq=x, golden64_f64=g64,
+             golden64=g64.astype(np.float32), golden32=g32.astype(np.float32),
+             moments=mom, tags=np.array(tags))
+
+
+def edge_frames(N):
+    n = np.arange(N)
+    z = {
+        "zeros": np.zeros(N, np.complex64),
+        "const_pos": np.ones(N, np.complex64),
+        "const_neg": -np.ones(N, np.complex64),
+        "const_neg_negzero": (-np.ones(N) - 0j * np.ones(N)).astype(np.complex64),
+        "alternating": ((-1.0) ** n).astype(np.complex64),
+        "tone_k5": np.exp(2j * np.pi * 5 * n / N).astype(np.complex64),
+        "ramp_phase_pi": np.exp(1j * np.pi * n).astype(np.complex64),   # d = +-pi ties
+        "real_only": (np.cos(0.37 * n) + 0.5).astype(np.complex64),
+        "imag_only": (1j * (np.sin(0.11 * n) + 0.25)).astype(np.complex64),
+        "impulse": np.where(n == 3, 1.0, 0.0).astype(np.complex64),
+        "huge": (np.exp(0.9j * n) * 3e5).astype(np.complex64),
+        "tiny": (np.exp(0.9j * n) * 1e-4 + 1e-5).astype(np.complex64),
+    }
+    nan = np.exp(0.3j * n).astype(np.complex64)
+    nan[7] = np.nan
+    z["one_nan"] = nan
+    # explicit -0.0 imaginary part on the negative real axis: angle = -pi
+    negz = np.empty(N, np.complex64)
+    negz.real = -1.0
+    negz.imag = -0.0
+    z["const_neg_negzero"] = negz
+    return z
+
+
+def capture_edges(rfeat, N):
+    z = edge_frames(N)
+    names = sorted(z)
+    x = np.stack([z[k] for k in names])
+    g64 = np.stack([_ref18(rfeat, f, np.complex128) for f in x])
+    g32 = np.stack([_ref18(rfeat, f, np.complex64) for f in x])
+    np.savez(OUT / f"edges_n{N}.npz", iq=x, names=np.array(names), golden64_f64=g64,
+             golden64=g64.astype(np.float32), golden32=g32.astype(np.float32))
+
+
+def capture_roundtrip(rfe, rcfg):
+    """The reference's own batch driver on a tiny container whose rows are
+    LONGER than frame_size (exercises the [0:frame_size] slice,
+    feature_extraction.py:68) and complex128 (MATLAB doubles)."""
+    import scipy.io
+    from amcpy_amd import synth
+    frame_size, row_len, n_frames = 256, 300, 3
+    mods = synth.MODS6
+    blocks = synth.host_frames(mods, 2, n_frames, row_len)
+    with tempfile.TemporaryDirectory() as td:
+        paths = rcfg.Paths(root=Path(td))
+        sig = rcfg.SignalConfig(snr_values={0: "0", 1: "10"}, num_frames=n_frames,
+                                frame_size=frame_size, num_threads=2)
+        cfg = rcfg.Config(paths=paths, signals=sig)
+        paths.ensure_dirs()
+        container = {sig.mat_info[m]: blocks[m].astype(np.complex128) for m in mods}
+        scipy.io.savemat(str(paths.mat_data / paths.mat_filename), container)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            rfe.run_extraction(cfg)
+        rec = {}
+        for m in mods:
+            d = scipy.io.loadmat(str(paths.calculated_features / f"{m}_features.mat"))
+            keys = sorted(k for k in d if not k.startswith("__"))
+            assert keys == sorted(["Modulation", sig.mat_info[m]]), keys
+            arr = d[sig.mat_info[m]]
+            assert arr.dtype == np.float32 and arr.shape == (2, n_frames, 18)
+            rec[f"out_{m}"] = arr
+            rec[f"label_{m}"] = np.array(str(np.ravel(d["Modulation"])[0]))
+            rec[f"in_{m}"] = blocks[m]
+    np.savez(OUT / "extract_roundtrip.npz", frame_size=frame_size, row_len=row_len,
+             n_frames=n_frames, mods=np.array(mods), **rec)
+
+
+def main():
+    os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+    OUT.mkdir(parents=True, exist_ok=True)
+    rfeat, rfe, rcfg = _import_reference()
+    capture_kat(rfeat)
+    for N in (1024, 2048, 4096):
+        capture_frames(rfeat, N)
+    for N in (1000, 2048):
+        capture_edges(rfeat, N)
+    capture_roundtrip(rfe, rcfg)
+    for p in sorted(OUT.iterdir()):
+        print(f"{p.name:28s} {p.stat().st_size:9d} B")
+
+
+if __name__ == "__main__":
+    main()

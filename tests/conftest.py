@@ -1,0 +1,37 @@
+"""Shared pytest wiring: the `gpu` marker and fixture loading."""
+import json
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+REPO = Path(__file__).resolve().parents[1]
+GOLDEN = REPO / "tests" / "golden"
+if str(REPO) not in sys.path:
+    sys.path.insert(0, str(REPO))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def kat():
+    return json.loads((GOLDEN / "kat_n10.json").read_text())
+
+
+def load_npz(name):
+    return np.load(GOLDEN / name, allow_pickle=False)
+
+
+@pytest.fixture(scope="session", params=[1024, 2048, 4096])
+def golden_frames(request):
+    return request.param, load_npz(f"frames_n{request.param}.npz")
+
+
+@pytest.fixture(scope="session", params=[1000, 2048])
+def golden_edges(request):
+    return request.param, load_npz(f"edges_n{request.param}.npz")
