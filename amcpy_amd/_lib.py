@@ -1,0 +1,84 @@
+"""ctypes binding of libamcx.so (C ABI: include/amcx.h).
+
+The HIP library is the product: if it cannot be loaded this module raises --
+there is no CPU fallback anywhere in the package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("AMCX_LIB", _HERE / "lib" / "libamcx.so"))
+
+ABI_VERSION = 1
+NUM_FEATURES = 18
+VARIANT_AUTO, VARIANT_BLOCK, VARIANT_WAVE = 0, 1, 2
+VARIANTS = {"auto": VARIANT_AUTO, "block": VARIANT_BLOCK, "wave": VARIANT_WAVE}
+OK, EINVAL, ENOTSUP, EHIP, ENODEV, ENOMEM = 0, -1, -2, -3, -4, -5
+
+# every symbol include/amcx.h declares: (restype, argtypes)
+_i64, _i32, _vp, _fp = C.c_int64, C.c_int32, C.c_void_p, C.POINTER(C.c_float)
+SIGNATURES = {
+    "amcx_abi_version": (C.c_int, []),
+    "amcx_strerror": (C.c_char_p, [C.c_int]),
+    "amcx_last_hip_error": (C.c_char_p, []),
+    "amcx_device_count": (C.c_int, []),
+    "amcx_features18_c64": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i64, _vp]),
+    "amcx_features18_c64_ex": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i64, _vp, _i32]),
+    "amcx_features18_c64_host": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i64, _i32, _i32]),
+    "amcx_kernel_name": (C.c_int, [_i32, _i32, C.c_char_p, _i32]),
+    "amcx_probe_read_bw": (C.c_int, [_vp, _i64, _vp, _vp]),
+}
+
+_lib = None
+
+
+class AmcxError(RuntimeError):
+    def __init__(self, code: int, detail: str = ""):
+        self.code = code
+        super().__init__(f"amcx error {code}: {detail}")
+
+
+def load() -> C.CDLL:
+    """Load libamcx.so once.  torch (if installed) is imported first so that the
+    library binds to the HIP runtime torch ships and device pointers are shared."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python amcpy_amd/csrc/build.py` "
+            "(hipcc, gfx950). amcpy_amd has no CPU fallback.")
+    try:
+        import torch  # noqa: F401  (side effect: loads torch's libamdhip64.so.7)
+    except Exception:
+        pass
+    lib = C.CDLL(str(LIB_PATH), mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype, fn.argtypes = res, args
+    got = lib.amcx_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError(f"libamcx ABI {got}, binding expects {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(code: int) -> None:
+    if code == OK:
+        return
+    lib = load()
+    msg = lib.amcx_strerror(code).decode()
+    if code == EHIP:
+        msg += ": " + lib.amcx_last_hip_error().decode()
+    if code == EINVAL:
+        raise ValueError(f"amcx: {msg}")
+    raise AmcxError(code, msg)
+
+
+def kernel_name(frame_size: int, variant: int = VARIANT_AUTO) -> str:
+    buf = C.create_string_buffer(128)
+    check(load().amcx_kernel_name(frame_size, variant, buf, len(buf)))
+    return buf.value.decode()

@@ -1,0 +1,222 @@
+// libamcx.so -- C ABI (include/amcx.h) over the gfx950 feature kernels.
+// Build: hipcc --offload-arch=gfx950 -O3 -fPIC -shared (see build.py).
+#include "../../include/amcx.h"
+
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "amcx_block_kernel.h"
+#include "amcx_wave_kernel.h"
+
+namespace {
+
+thread_local char g_hip_err[256] = "";
+
+int hip_fail(hipError_t e, const char* what) {
+  snprintf(g_hip_err, sizeof g_hip_err, "%s: %s", what, hipGetErrorString(e));
+  return AMCX_EHIP;
+}
+
+#define AMCX_HIP(call)                                     \
+  do {                                                     \
+    hipError_t e_ = (call);                                \
+    if (e_ != hipSuccess) return hip_fail(e_, #call);      \
+  } while (0)
+
+bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+
+int resolve_variant(int32_t frame_size, int32_t variant) {
+  if (frame_size < AMCX_MIN_FRAME_SIZE || frame_size > AMCX_MAX_FRAME_SIZE) return AMCX_EINVAL;
+  switch (variant) {
+    case AMCX_VARIANT_AUTO:
+      return amcx::wave_supports(frame_size) ? AMCX_VARIANT_WAVE : AMCX_VARIANT_BLOCK;
+    case AMCX_VARIANT_BLOCK:
+      return AMCX_VARIANT_BLOCK;
+    case AMCX_VARIANT_WAVE:
+      return amcx::wave_supports(frame_size) ? AMCX_VARIANT_WAVE : AMCX_ENOTSUP;
+    default:
+      return AMCX_EINVAL;
+  }
+}
+
+int cu_count() {
+  static int cus = 0;   // benign race: every writer stores the same value
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+      cus = n;
+    else
+      return 256;
+  }
+  return cus;
+}
+
+int launch_block(const float2* iq, int64_t n_frames, int32_t N, int64_t row_stride, float* out,
+                 int64_t out_stride, hipStream_t stream) {
+  const size_t lds = (size_t)16 * N + sizeof(double) * amcx::kBlockWaves * amcx::kMaxReduce;
+  auto kern = is_pow2(N) ? amcx::amcx_features18_block_kernel<true>
+                         : amcx::amcx_features18_block_kernel<false>;
+  if (lds > 64 * 1024)
+    AMCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  // enough workgroups to fill every CU at the occupancy LDS allows, grid-stride beyond
+  const int per_cu = (int)((160 * 1024) / lds) < 1 ? 1 : (int)((160 * 1024) / lds);
+  int64_t grid = (int64_t)cu_count() * (per_cu > 8 ? 8 : per_cu) * 4;
+  if (grid > n_frames) grid = n_frames;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(amcx::kBlockThreads), lds, stream, iq,
+                     (long long)n_frames, (int)N, (long long)row_stride, out, (long long)out_stride);
+  AMCX_HIP(hipGetLastError());
+  return AMCX_OK;
+}
+
+__global__ __launch_bounds__(256) void amcx_probe_read_kernel(const float4* __restrict__ src,
+                                                             long long n_vec, float* partial) {
+  float acc = 0.f;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride) {
+    const float4 v = src[i];
+    acc += (v.x + v.y) + (v.z + v.w);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  __shared__ float s[4];
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+
+}  // namespace
+
+extern "C" {
+
+int amcx_abi_version(void) { return AMCX_ABI_VERSION; }
+
+const char* amcx_strerror(int code) {
+  switch (code) {
+    case AMCX_OK: return "ok";
+    case AMCX_EINVAL: return "invalid argument (null pointer, negative count, stride or frame_size out of range)";
+    case AMCX_ENOTSUP: return "kernel variant does not support this frame_size";
+    case AMCX_EHIP: return "HIP runtime error (see amcx_last_hip_error)";
+    case AMCX_ENODEV: return "no usable gfx950 device";
+    case AMCX_ENOMEM: return "device memory allocation failed";
+    default: return "unknown amcx error code";
+  }
+}
+
+const char* amcx_last_hip_error(void) { return g_hip_err; }
+
+int amcx_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e == hipErrorNoDevice) return 0;
+  if (e != hipSuccess) return hip_fail(e, "hipGetDeviceCount");
+  int ok = 0;
+  for (int d = 0; d < n; ++d) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, d) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ++ok;
+  }
+  return ok;
+}
+
+int amcx_features18_c64_ex(const void* iq_dev, int64_t n_frames, int32_t frame_size,
+                           int64_t row_stride_elems, float* out_dev, int64_t out_row_stride,
+                           void* hip_stream, int32_t variant) {
+  if (n_frames < 0 || row_stride_elems < frame_size || out_row_stride < AMCX_NUM_FEATURES)
+    return AMCX_EINVAL;
+  const int v = resolve_variant(frame_size, variant);
+  if (v < 0) return v;
+  if (n_frames == 0) return AMCX_OK;
+  if (iq_dev == nullptr || out_dev == nullptr) return AMCX_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(iq_dev) & 7u) || (reinterpret_cast<uintptr_t>(out_dev) & 3u))
+    return AMCX_EINVAL;
+  hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+  const float2* iq = static_cast<const float2*>(iq_dev);
+  if (v == AMCX_VARIANT_WAVE) {
+    hipError_t e = amcx::launch_wave(iq, n_frames, frame_size, row_stride_elems, out_dev,
+                                     out_row_stride, stream, cu_count());
+    if (e != hipSuccess) return hip_fail(e, "wave kernel launch");
+    return AMCX_OK;
+  }
+  return launch_block(iq, n_frames, frame_size, row_stride_elems, out_dev, out_row_stride, stream);
+}
+
+int amcx_features18_c64(const void* iq_dev, int64_t n_frames, int32_t frame_size,
+                        int64_t row_stride_elems, float* out_dev, int64_t out_row_stride,
+                        void* hip_stream) {
+  return amcx_features18_c64_ex(iq_dev, n_frames, frame_size, row_stride_elems, out_dev,
+                                out_row_stride, hip_stream, AMCX_VARIANT_AUTO);
+}
+
+int amcx_features18_c64_host(const void* iq_host, int64_t n_frames, int32_t frame_size,
+                             int64_t row_stride_elems, float* out_host, int64_t out_row_stride,
+                             int32_t device, int32_t variant) {
+  if (n_frames < 0 || row_stride_elems < frame_size || out_row_stride < AMCX_NUM_FEATURES)
+    return AMCX_EINVAL;
+  const int v = resolve_variant(frame_size, variant);
+  if (v < 0) return v;
+  if (n_frames == 0) return AMCX_OK;
+  if (iq_host == nullptr || out_host == nullptr) return AMCX_EINVAL;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
+    return AMCX_ENODEV;
+  int prev = 0;
+  AMCX_HIP(hipGetDevice(&prev));
+  AMCX_HIP(hipSetDevice(device));
+  void* d_iq = nullptr;
+  float* d_out = nullptr;
+  hipStream_t stream = nullptr;
+  int rc = AMCX_OK;
+  const size_t row_bytes = (size_t)frame_size * 8;
+  // frames are packed on the device (row stride == frame_size), so rows longer
+  // than frame_size (feature_extraction.py:68) cost no HBM or PCIe bytes
+  if (hipMalloc(&d_iq, row_bytes * (size_t)n_frames) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&d_out), sizeof(float) * AMCX_NUM_FEATURES * (size_t)n_frames) != hipSuccess) {
+    (void)hipGetLastError();
+    rc = AMCX_ENOMEM;
+  }
+  hipError_t e = hipSuccess;
+  if (rc == AMCX_OK) e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+  if (rc == AMCX_OK && e == hipSuccess)
+    e = hipMemcpy2DAsync(d_iq, row_bytes, iq_host, (size_t)row_stride_elems * 8, row_bytes,
+                         (size_t)n_frames, hipMemcpyHostToDevice, stream);
+  if (rc == AMCX_OK && e == hipSuccess) {
+    rc = amcx_features18_c64_ex(d_iq, n_frames, frame_size, frame_size, d_out, AMCX_NUM_FEATURES,
+                                stream, v);
+    if (rc == AMCX_OK)
+      e = hipMemcpy2DAsync(out_host, sizeof(float) * (size_t)out_row_stride, d_out,
+                           sizeof(float) * AMCX_NUM_FEATURES, sizeof(float) * AMCX_NUM_FEATURES,
+                           (size_t)n_frames, hipMemcpyDeviceToHost, stream);
+    if (rc == AMCX_OK && e == hipSuccess) e = hipStreamSynchronize(stream);
+  }
+  if (rc == AMCX_OK && e != hipSuccess) rc = hip_fail(e, "amcx_features18_c64_host");
+  if (stream) (void)hipStreamDestroy(stream);
+  if (d_iq) (void)hipFree(d_iq);
+  if (d_out) (void)hipFree(d_out);
+  (void)hipSetDevice(prev);
+  return rc;
+}
+
+int amcx_kernel_name(int32_t frame_size, int32_t variant, char* buf, int32_t buf_len) {
+  if (buf == nullptr || buf_len <= 0) return AMCX_EINVAL;
+  const int v = resolve_variant(frame_size, variant);
+  if (v < 0) return v;
+  const char* name = (v == AMCX_VARIANT_WAVE) ? amcx::wave_kernel_name(frame_size)
+                     : is_pow2(frame_size)    ? "amcx_features18_block_kernel<true>"
+                                              : "amcx_features18_block_kernel<false>";
+  snprintf(buf, (size_t)buf_len, "%s", name);
+  return AMCX_OK;
+}
+
+int amcx_probe_read_bw(const void* src_dev, int64_t n_bytes, float* partial_dev, void* hip_stream) {
+  if (src_dev == nullptr || partial_dev == nullptr || n_bytes < 0 || (n_bytes & 15)) return AMCX_EINVAL;
+  if (n_bytes == 0) return AMCX_OK;
+  hipLaunchKernelGGL(amcx_probe_read_kernel, dim3(4096), dim3(256), 0,
+                     static_cast<hipStream_t>(hip_stream), static_cast<const float4*>(src_dev),
+                     (long long)(n_bytes / 16), partial_dev);
+  AMCX_HIP(hipGetLastError());
+  return AMCX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,191 @@
+// AMCX_VARIANT_BLOCK: one 256-thread workgroup per frame.
+//
+// The literal shape BASELINE.json's north_star describes: the complex frame
+// is staged into LDS once with coalesced loads, every moment is a
+// wavefront-level (shuffle) reduction followed by a 4-wave LDS combine, and
+// the spectral term is a shared-memory radix-2 FFT.  It is the accuracy-first,
+// any-frame-size kernel: sums accumulate in fp64, centred statistics are true
+// two-pass, and a frame size that is not a power of two takes a direct DFT
+// (the reference's np.fft.fft accepts any N; its own known-answer test uses
+// N = 10, features.py:240-255).  The throughput kernel is amcx_wave_kernel.h.
+//
+// LDS per workgroup: 16*N bytes (frame + (|x|, angle) stash / DFT twiddles)
+// + 1 KiB of reduction scratch.  Algorithmic HBM bytes per frame: 8*N + 72.
+#pragma once
+
+#include "amcx_math.h"
+
+namespace amcx {
+
+constexpr int kBlockThreads = 256;
+constexpr int kBlockWaves = kBlockThreads / 64;
+constexpr int kMaxReduce = 16;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// Sum K per-thread doubles over the workgroup; every thread gets the totals.
+template <int K>
+__device__ __forceinline__ void block_sum(double (&v)[K], double* scratch) {
+  static_assert(K <= kMaxReduce, "scratch too small");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const double w = wave_sum(v[k]);
+    if (lane == 0) scratch[wave * kMaxReduce + k] = w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    double t = 0;
+#pragma unroll
+    for (int w = 0; w < kBlockWaves; ++w) t += scratch[w * kMaxReduce + k];
+    v[k] = t;
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ float block_max(float v, double* scratch) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // NaN must survive the reduction: fmaxf drops it, so carry a flag
+  float bad = (v == v) ? 0.f : 1.f;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    v = __builtin_fmaxf(v, __shfl_xor(v, off, 64));
+    bad = __builtin_fmaxf(bad, __shfl_xor(bad, off, 64));
+  }
+  float* s = reinterpret_cast<float*>(scratch);
+  if (lane == 0) { s[wave * 2] = v; s[wave * 2 + 1] = bad; }
+  __syncthreads();
+  float m = s[0], b = s[1];
+#pragma unroll
+  for (int w = 1; w < kBlockWaves; ++w) { m = __builtin_fmaxf(m, s[w * 2]); b = __builtin_fmaxf(b, s[w * 2 + 1]); }
+  __syncthreads();
+  return b > 0.f ? __builtin_nanf("") : m;
+}
+
+template <bool POW2>
+__global__ __launch_bounds__(kBlockThreads) void amcx_features18_block_kernel(
+    const float2* __restrict__ iq, long long n_frames, int N, long long row_stride,
+    float* __restrict__ out, long long out_stride) {
+  extern __shared__ float4 amcx_block_smem[];
+  float2* xs = reinterpret_cast<float2*>(amcx_block_smem);        // frame, later FFT workspace
+  float2* at = xs + N;                                            // (|x|, angle), later DFT twiddles
+  double* scratch = reinterpret_cast<double*>(at + N);            // kBlockWaves * kMaxReduce doubles
+  const int tid = threadIdx.x;
+
+  for (long long f = blockIdx.x; f < n_frames; f += gridDim.x) {
+    const float2* src = iq + f * row_stride;
+    for (int n = tid; n < N; n += kBlockThreads) xs[n] = src[n];
+    __syncthreads();
+
+    FrameSums S;
+    // ---- pass A: mixed moments, envelope and phase first sums ------------
+    {
+      double m[15];
+#pragma unroll
+      for (int k = 0; k < 15; ++k) m[k] = 0;
+      double e[3] = {0, 0, 0};  // sum a, sum theta, sum |theta|
+      for (int n = tid; n < N; n += kBlockThreads) {
+        const float2 x = xs[n];
+        const double re = x.x, im = x.y;
+        const double A = re * re - im * im, Bh = re * im, P = re * re + im * im;
+        const double AA = A * A, BB = Bh * Bh, AP = A * P;
+        m[0] += A; m[1] += Bh; m[2] += P;
+        m[3] += AA; m[4] += BB; m[5] += A * Bh;
+        m[6] += AP; m[7] += Bh * P;
+        m[8] += AA * A; m[9] += A * BB; m[10] += AA * Bh; m[11] += BB * Bh;
+        m[12] += AA * P; m[13] += BB * P; m[14] += AP * Bh;
+        const float a = __builtin_sqrtf(__builtin_fmaf(x.x, x.x, x.y * x.y));
+        const float th = fast_angle(x.x, x.y);
+        at[n] = make_float2(a, th);
+        e[0] += a; e[1] += th; e[2] += __builtin_fabsf(th);
+      }
+      block_sum(m, scratch);
+      block_sum(e, scratch);   // the barrier inside also publishes `at`
+      S.sA = m[0]; S.sBh = m[1]; S.sP = m[2]; S.sAA = m[3]; S.sBB = m[4]; S.sAB = m[5];
+      S.sAP = m[6]; S.sBP = m[7]; S.sAAA = m[8]; S.sABB = m[9]; S.sAAB = m[10]; S.sBBB = m[11];
+      S.sAAP = m[12]; S.sBBP = m[13]; S.sABP = m[14];
+      S.sa = e[0]; S.Kt = e[1] / N; S.sabst = e[2];
+    }
+    // ---- pass B: centred envelope / phase sums, first sum of the steps ---
+    {
+      const double mu = S.sa / N;
+      double c[6] = {0, 0, 0, 0, 0, 0};
+      for (int n = tid; n < N; n += kBlockThreads) {
+        const float2 v = at[n];
+        const double d = (double)v.x - mu, d2 = d * d;
+        c[0] += __builtin_fabs(d); c[1] += d2; c[2] += d2 * d2;
+        const double dt = (double)v.y - S.Kt;
+        c[3] += dt; c[4] += dt * dt;
+        if (n + 1 < N) c[5] += wrapped_step(at[n + 1].y, v.y);
+      }
+      block_sum(c, scratch);
+      S.sad1 = c[0]; S.sad2 = c[1]; S.sad4 = c[2]; S.std1 = c[3]; S.std2 = c[4];
+      S.Kw = c[5] / (N - 1);
+    }
+    // ---- pass C: centred sums of the wrapped phase step ------------------
+    {
+      double c[4] = {0, 0, 0, 0};
+      for (int n = tid; n + 1 < N; n += kBlockThreads) {
+        const double d = (double)wrapped_step(at[n + 1].y, at[n].y) - S.Kw, d2 = d * d;
+        c[0] += d; c[1] += d2; c[2] += d2 * d; c[3] += d2 * d2;
+      }
+      block_sum(c, scratch);   // trailing barrier: `at` may now be overwritten
+      S.swd1 = c[0]; S.swd2 = c[1]; S.swd3 = c[2]; S.swd4 = c[3];
+    }
+    // ---- spectral peak ---------------------------------------------------
+    // (a non-finite sample is caught by the finaliser through the power sum,
+    //  so the maximum itself need not carry NaNs)
+    float peak = 0.f;
+    if constexpr (POW2) {
+      // in-place radix-2 decimation-in-frequency; output order is bit-reversed,
+      // which a maximum does not care about
+      for (int half = N >> 1; half >= 1; half >>= 1) {
+        for (int b = tid; b < (N >> 1); b += kBlockThreads) {
+          const int j = b & (half - 1);
+          const int i0 = ((b - j) << 1) + j, i1 = i0 + half;
+          const float2 u = xs[i0], v = xs[i1];
+          float sn, cs;
+          sincospif((float)j / (float)half, &sn, &cs);       // W = cs - i*sn
+          const float dr = u.x - v.x, di = u.y - v.y;
+          xs[i0] = make_float2(u.x + v.x, u.y + v.y);
+          xs[i1] = make_float2(__builtin_fmaf(dr, cs, di * sn), __builtin_fmaf(di, cs, -dr * sn));
+        }
+        __syncthreads();
+      }
+      for (int n = tid; n < N; n += kBlockThreads) {
+        const float2 X = xs[n];
+        peak = __builtin_fmaxf(peak, __builtin_fmaf(X.x, X.x, X.y * X.y));
+      }
+    } else {
+      // direct DFT with an exact-index twiddle table: tw[m] = exp(-2*pi*i*m/N)
+      for (int mI = tid; mI < N; mI += kBlockThreads) {
+        double sn, cs;
+        sincospi(2.0 * (double)mI / (double)N, &sn, &cs);
+        at[mI] = make_float2((float)cs, (float)(-sn));
+      }
+      __syncthreads();
+      for (int k = tid; k < N; k += kBlockThreads) {
+        double ar = 0, ai = 0;
+        int idx = 0;
+        for (int n = 0; n < N; ++n) {
+          const float2 x = xs[n], w = at[idx];
+          ar += (double)x.x * w.x - (double)x.y * w.y;
+          ai += (double)x.x * w.y + (double)x.y * w.x;
+          idx += k;
+          if (idx >= N) idx -= N;
+        }
+        peak = __builtin_fmaxf(peak, (float)(ar * ar + ai * ai));
+      }
+    }
+    peak = block_max(peak, scratch);   // barriers inside: LDS free for the next frame
+    S.gmax_raw = peak;
+    if (tid == 0) finalize_features(S, N, out + f * out_stride);
+  }
+}
+
+}  // namespace amcx

@@ -1,0 +1,186 @@
+// Per-sample fp32 device math shared by every amcx kernel, plus the fp64
+// per-frame finaliser that turns reduced sums into the 18 features.
+// gfx950 (CDNA4) only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace amcx {
+
+constexpr float kPi = 3.14159265358979323846f;
+constexpr float kHalfPi = 1.57079632679489661923f;
+constexpr float kTwoPi = 6.28318530717958647692f;
+constexpr float kInvTwoPi = 0.15915494309189533577f;
+constexpr double kTwoPiD = 6.283185307179586476925286766559;
+
+// ---------------------------------------------------------------------------
+// angle(x) = atan2(im, re) in (-pi, pi], numpy semantics on the axes:
+// angle(0) = 0, angle(-1+0j) = +pi, angle(-1-0j) = -pi  (reference
+// features.py:28 -> np.angle).  ~23 VALU issue slots, max abs error 1.5e-7
+// (8-term minimax of atan(r)/r on [0,1], tools/fit_atan.py; fp32 Horner).
+// NaN inputs do not propagate through min/max here: a frame with a
+// non-finite sample is turned into 18 NaNs by the finaliser instead, from the
+// NaN its power sum carries.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float fast_angle(float re, float im) {
+  const float ax = __builtin_fabsf(re);
+  const float ay = __builtin_fabsf(im);
+  const float mx = __builtin_fmaxf(ax, ay);
+  const float mn = __builtin_fminf(ax, ay);
+  // mx == 0 -> r = 0 * rcp(FLT_MIN) = 0 -> angle 0
+  const float r = mn * __builtin_amdgcn_rcpf(__builtin_fmaxf(mx, 1.17549435e-38f));
+  const float s = r * r;
+  float q = -4.054567212e-03f;
+  q = __builtin_fmaf(q, s, 2.186295787e-02f);
+  q = __builtin_fmaf(q, s, -5.591232676e-02f);
+  q = __builtin_fmaf(q, s, 9.642197328e-02f);
+  q = __builtin_fmaf(q, s, -1.390862955e-01f);
+  q = __builtin_fmaf(q, s, 1.994656565e-01f);
+  q = __builtin_fmaf(q, s, -3.332986078e-01f);
+  q = __builtin_fmaf(q, s, 9.999993356e-01f);
+  float t = q * r;                                    // atan(mn/mx) in [0, pi/4]
+  t = (ay > ax) ? (kHalfPi - t) : t;                  // first quadrant angle
+  t = (__builtin_signbitf(re)) ? (kPi - t) : t;       // re < 0 or re == -0
+  // re == -0 with im == 0 must give +-pi like atan2; the sign-bit test does that.
+  return __builtin_copysignf(t, im);
+}
+
+// diff(unwrap(theta))[i] from two neighbouring angles: d - 2*pi*rint(d/2pi),
+// half-to-even (v_rndne_f32) reproduces numpy's tie rule since |d| <= 2*pi
+// (reference features.py:29-30 -> np.unwrap/np.diff).
+__device__ __forceinline__ float wrapped_step(float th_next, float th) {
+  const float d = th_next - th;
+  const float k = __builtin_rintf(d * kInvTwoPi);
+  return __builtin_fmaf(-kTwoPi, k, d);
+}
+
+// ---------------------------------------------------------------------------
+// Reduced per-frame sums, everything the 18 features need.
+// A = re^2 - im^2, Bh = re*im (so x^2 = A + 2i*Bh), P = re^2 + im^2.
+// ---------------------------------------------------------------------------
+struct FrameSums {
+  // mixed-moment sums over the N samples
+  double sA, sBh, sP;            // -> m20, m21
+  double sAA, sBB, sAB;          // A^2, Bh^2, A*Bh          -> m40, m42
+  double sAP, sBP;               // A*P, Bh*P                -> m41
+  double sAAA, sABB, sAAB, sBBB; // A^3, A*Bh^2, A^2*Bh, Bh^3 -> m60, m62
+  double sAAP, sBBP, sABP;       // A^2*P, Bh^2*P, A*Bh*P    -> m61, m63
+  // envelope a = |x| : exact mean, then centred sums about it
+  double sa;                     // sum a
+  double sad1, sad2, sad4;       // sum |a-mu|, (a-mu)^2, (a-mu)^4
+  // phase theta, shifted by Kt: d = theta - Kt
+  double Kt, std1, std2;         // shift, sum d, sum d^2
+  double sabst;                  // sum |theta|
+  // wrapped phase step w (N-1 values), shifted by Kw: d = w - Kw
+  double Kw, swd1, swd2, swd3, swd4;
+  double gmax_raw;               // max_k |X_k|^2 (unnormalised FFT)
+};
+
+// All 18 features from the sums, fp64 (the reference evaluates in fp64 and
+// stores float32: feature_extraction.py:35,56).  Formulas: features.py:66-185;
+// C60 uses +3*m20^3 and m62 is real-only, as the reference has them
+// (features.py:147,57).
+__device__ inline void finalize_features(const FrameSums& s, int N, float* __restrict__ out) {
+  const double n = (double)N;
+  const double inv = 1.0 / n;
+  // non-finite input anywhere -> the reference's numpy arithmetic yields NaN
+  // in every feature (SURVEY.md Appendix C "one NaN sample")
+  if (!(__builtin_fabs(s.sP) <= 1.79e308) || !(s.gmax_raw == s.gmax_raw)) {
+#pragma unroll
+    for (int j = 0; j < 18; ++j) out[j] = __builtin_nanf("");
+    return;
+  }
+  // ---- f1: gamma_max
+  out[0] = (float)(s.gmax_raw * inv);
+
+  // ---- phase: f2 = std1(|theta|), f3 = std1(theta)
+  const double md = s.std1 * inv;                       // mean of shifted theta
+  double ct2 = s.std2 - n * md * md;                    // sum (theta-mean)^2
+  if (ct2 < 0) ct2 = 0;
+  const double tbar = s.Kt + md;
+  const double sum_t2 = ct2 + n * tbar * tbar;          // sum theta^2
+  const double mabs = s.sabst * inv;
+  double cabs2 = sum_t2 - n * mabs * mabs;              // sum (|theta|-mean)^2
+  if (cabs2 < 0) cabs2 = 0;
+  out[1] = (float)__builtin_sqrt(cabs2 / (n - 1.0));
+  out[2] = (float)__builtin_sqrt(ct2 / (n - 1.0));
+
+  // ---- envelope: f4, f6, f7, f8
+  const double mu = s.sa * inv;
+  {
+    const double mad = s.sad1 * inv;                    // mean |a-mu|
+    double v = s.sad2 - n * mad * mad;                  // sum (|a-mu| - mad)^2
+    if (v < 0) v = 0;
+    out[3] = (float)(__builtin_sqrt(v / (n - 1.0)) / mu);   // 0/0 -> NaN for a zero frame
+    out[5] = (float)mu;
+    out[6] = (float)(__builtin_sqrt(s.sa) * inv);
+    const double m2 = s.sad2 * inv, m4 = s.sad4 * inv;
+    out[7] = (float)(m4 / (m2 * m2));                   // m2 == 0 -> NaN (scipy rule)
+  }
+
+  // ---- frequency phi = w / 2pi over N-1 values: f5, f9
+  {
+    const double n1 = n - 1.0, inv1 = 1.0 / n1;
+    const double d1 = s.swd1 * inv1;                    // mean of shifted w
+    const double r2 = s.swd2 * inv1, r3 = s.swd3 * inv1, r4 = s.swd4 * inv1;
+    double c2 = r2 - d1 * d1;                           // central moments of w
+    if (c2 < 0) c2 = 0;
+    const double c4 = r4 - 4.0 * d1 * r3 + 6.0 * d1 * d1 * r2 - 3.0 * d1 * d1 * d1 * d1;
+    out[4] = (float)(__builtin_sqrt(c2 * n1 / (n1 - 1.0)) / kTwoPiD);
+    const double wbar = (s.Kw + d1) / kTwoPiD;          // mean phi, for scipy's rule
+    const double m2phi = c2 / (kTwoPiD * kTwoPiD);
+    const double eps_mean = 2.220446049250313e-16 * wbar;
+    out[8] = (m2phi <= eps_mean * eps_mean) ? __builtin_nanf("") : (float)(c4 / (c2 * c2));
+  }
+
+  // ---- mixed moments (complex as (re, im) pairs)
+  const double m20r = s.sA * inv, m20i = 2.0 * s.sBh * inv;
+  const double m21 = s.sP * inv;
+  const double m40r = (s.sAA - 4.0 * s.sBB) * inv, m40i = 4.0 * s.sAB * inv;
+  const double m41r = s.sAP * inv, m41i = 2.0 * s.sBP * inv;
+  const double m42 = (s.sAA + 4.0 * s.sBB) * inv;                     // mean P^2
+  const double m60r = (s.sAAA - 12.0 * s.sABB) * inv;                 // Re (A+iB)^3, B = 2Bh
+  const double m60i = (6.0 * s.sAAB - 8.0 * s.sBBB) * inv;
+  const double m61r = (s.sAAP - 4.0 * s.sBBP) * inv, m61i = 4.0 * s.sABP * inv;
+  const double m62 = (s.sAAA + 4.0 * s.sABB) * inv;                   // mean A*P^2 (real only)
+  const double m63 = (s.sAAP + 4.0 * s.sBBP) * inv;                   // mean P^3
+  // m22 = conj(m20), m43 = conj(m41)
+
+  auto cabs = [](double r, double i) { return __builtin_sqrt(r * r + i * i); };
+  const double q20r = m20r * m20r - m20i * m20i, q20i = 2.0 * m20r * m20i;   // m20^2
+  const double n20 = m20r * m20r + m20i * m20i;                              // |m20|^2
+
+  out[9] = (float)cabs(m20r, m20i);                                          // C20
+  out[10] = (float)__builtin_fabs(m21);                                      // C21
+  out[11] = (float)cabs(m40r - 3.0 * q20r, m40i - 3.0 * q20i);               // C40
+  out[12] = (float)cabs(m41r - 3.0 * m20r * m21, m41i - 3.0 * m20i * m21);   // C41
+  out[13] = (float)__builtin_fabs(m42 - n20 - 2.0 * m21 * m21);              // C42
+  {  // C60 = m60 - 15 m20 m40 + 3 m20^3
+    const double pr = m20r * m40r - m20i * m40i, pi = m20r * m40i + m20i * m40r;
+    const double cr = q20r * m20r - q20i * m20i, ci = q20r * m20i + q20i * m20r;
+    out[14] = (float)cabs(m60r - 15.0 * pr + 3.0 * cr, m60i - 15.0 * pi + 3.0 * ci);
+  }
+  {  // C61 = m61 - 5 m21 m40 - 10 m20 m41 + 30 m20^2 m21
+    const double pr = m20r * m41r - m20i * m41i, pi = m20r * m41i + m20i * m41r;
+    out[15] = (float)cabs(m61r - 5.0 * m21 * m40r - 10.0 * pr + 30.0 * q20r * m21,
+                          m61i - 5.0 * m21 * m40i - 10.0 * pi + 30.0 * q20i * m21);
+  }
+  {  // C62 = m62 - 6 m20 m42 - 8 m21 m41 - m22 m40 + 6 m20^2 m22 + 24 m21^2 m20
+    // m22 m40 = conj(m20) m40 ; m20^2 m22 = m20 |m20|^2
+    const double ar = m20r * m40r + m20i * m40i, ai = m20r * m40i - m20i * m40r;
+    const double re = m62 - 6.0 * m20r * m42 - 8.0 * m21 * m41r - ar + 6.0 * m20r * n20 +
+                      24.0 * m21 * m21 * m20r;
+    const double im = -6.0 * m20i * m42 - 8.0 * m21 * m41i - ai + 6.0 * m20i * n20 +
+                      24.0 * m21 * m21 * m20i;
+    out[16] = (float)cabs(re, im);
+  }
+  {  // C63 = m63 - 9 m21 m42 + 12 m21^3 - 3 m20 m43 - 3 m22 m41 + 18 m20 m21 m22
+    // m20 conj(m41) + conj(m20) m41 = 2 Re(m20 conj(m41)), real
+    const double cross = 2.0 * (m20r * m41r + m20i * m41i);
+    out[17] = (float)__builtin_fabs(m63 - 9.0 * m21 * m42 + 12.0 * m21 * m21 * m21 -
+                                    3.0 * cross + 18.0 * m21 * n20);
+  }
+}
+
+}  // namespace amcx

@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""Headline benchmark: IQ frames/sec, all 18 features, 2048-sample complex64
+frames (BASELINE.json metric), on N MI355X of one node.
+
+    python bench.py                       # N=1, defaults finish in ~2-3 min
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+
+A *step* is one pass of the hot path over one rank's resident shard: the
+BASELINE configs[1] shape -- 6 modulations x 26 SNR x 4096 frames x 2048
+samples of synthetic IQ (10.47 GB), generated in HBM before the timed region
+(SURVEY.md section 8d).  With N > 1 every rank holds its own shard of that
+shape (frames shard embarrassingly: no collective on the data path, weak
+scaling); the only cross-rank traffic is the timing barrier/MAX.
+
+One JSON line on stdout (rank 0).  Extra objects:
+  roofline     achieved = algorithmic bytes per launch ((8*N+72) B x frames)
+               / mean launch duration from HIP events on the launch stream,
+               against the 8 TB/s HBM peak (MI355X_MICROARCH.md); `traffic`
+               carries the PMC-derived HBM bytes per launch when a committed
+               profile summary provides it (profiles/*.json), else null.
+  cpu_baseline the oracle's reference-shaped per-frame evaluator on the host
+               cores (kind "port"), on the configs[0] shape, rank 0 at N=1
+               only; run BEFORE the GPU is initialised (worker processes).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+N_MODS, N_SNR, N_FRAMES, FRAME_SIZE = 6, 26, 4096, 2048
+CPU_SAMPLE = (6, 2, 500, 2048)  # BASELINE configs[0]
+
+
+# ----------------------------------------------------------------------------
+# CPU baseline (oracle, reference-shaped) -- runs before any GPU initialisation
+# ----------------------------------------------------------------------------
+def _cpu_worker(job):
+    import numpy as np
+    from amcpy_amd import synth
+    from oracle import iq_features_oracle as orc
+    mod, mi, si, snr, n_frames, N = job
+    blk = synth.host_block(mod, snr, n_frames, N, seed=1000 + 10 * mi + si).astype(np.complex128)
+    t0 = time.perf_counter()
+    acc = 0.0
+    for f in range(n_frames):
+        row = orc.calculate_features(range(1, 19), blk[f])
+        acc += row[5]
+    return n_frames, time.perf_counter() - t0, acc
+
+
+def cpu_baseline(max_procs: int | None = None):
+    """Frames/s of the oracle's per-frame, per-feature evaluator (same
+    redundancy class as the reference: 9x moments, 4x instantaneous values per
+    frame) over worker processes on the host cores."""
+    import multiprocessing as mp
+    from amcpy_amd import synth
+    n_mods, n_snr, n_frames, N = CPU_SAMPLE
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    procs = max(1, min(cores, max_procs or cores))
+    grid = synth.snr_grid(n_snr)
+    # split every (mod, snr) block into chunks so all workers stay busy
+    per = max(1, n_frames // max(1, procs // (n_mods * n_snr) + 1))
+    jobs = []
+    for mi, mod in enumerate(synth.MODS6[:n_mods]):
+        for si in range(n_snr):
+            left = n_frames
+            while left > 0:
+                c = min(per, left)
+                jobs.append((mod, mi, si, float(grid[si]), c, N))
+                left -= c
+    ctx = mp.get_context("fork")
+    t0 = time.perf_counter()
+    with ctx.Pool(procs) as pool:
+        res = pool.map(_cpu_worker, jobs, chunksize=1)
+    wall = time.perf_counter() - t0
+    frames = sum(r[0] for r in res)
+    return {
+        "value": frames / wall, "unit": "frames/s", "cores": procs, "kind": "port",
+        "sample": f"{n_mods} mods x {n_snr} SNR x {n_frames} frames x {N} samples (BASELINE configs[0]), "
+                  f"complex128 input, oracle.calculate_features per frame, {procs} worker processes, "
+                  f"{wall:.1f} s wall",
+    }
+
+
+# ----------------------------------------------------------------------------
+def _pmc_traffic(frames_per_launch: int):
+    """HBM bytes per launch from a committed PMC summary, if one matches."""
+    best = None
+    for p in sorted((REPO / "profiles").glob("*pmc*.json")):
+        try:
+            d = json.loads(p.read_text())
+            if d.get("frame_size") == FRAME_SIZE and d.get("hbm_bytes_per_frame"):
+                best = d["hbm_bytes_per_frame"] * frames_per_launch
+        except Exception:
+            continue
+    return best
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=N_FRAMES, help="frames per (mod, SNR) block")
+    ap.add_argument("--variant", default="auto", choices=["auto", "block", "wave"])
+    ap.add_argument("--no-cpu-baseline", action="store_true",
+                    help="skip the host baseline (use under rocprofv3: no worker processes)")
+    ap.add_argument("--cpu-procs", type=int, default=None)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs {args.gpus} ranks: launch with "
+                             "python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N")
+        world, rank, local_rank = 1, 0, 0
+
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.cpu_procs)            # before the GPU is touched
+
+    import torch
+    import torch.distributed as dist
+    from amcpy_amd import _lib, synth
+    from amcpy_amd.features import features18
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # ---- resident shard: (mods, snr, frames, N) complex64 arena in HBM --------
+    arena = torch.empty((N_MODS, N_SNR, args.frames, FRAME_SIZE), dtype=torch.complex64, device=dev)
+    for mi, mod in enumerate(synth.MODS6):
+        synth.device_frames(mod, N_SNR, args.frames, FRAME_SIZE, device=dev, rank=rank,
+                            mod_idx=mi, out=arena[mi])
+    frames_per_launch = N_MODS * N_SNR * args.frames
+    out = torch.empty((N_MODS, N_SNR, args.frames, 18), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        features18(arena, out=out, variant=args.variant)   # one launch over the whole shard
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:                       # events sit on the stream the kernel is launched on
+        a.record()
+        step()
+        b.record()
+    fence()
+    wall = time.perf_counter() - t0
+    launch_ms = [a.elapsed_time(b) for a, b in ev]
+    if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+
+    # sanity: the timed output is finite
+    assert torch.isfinite(out[0, N_SNR // 2, :64]).all(), "non-finite features in the timed output"
+
+    # measured streaming-read ceiling next to the nominal peak (rank 0)
+    read_peak = None
+    if rank == 0:
+        lib = _lib.load()
+        part = torch.empty(4096, dtype=torch.float32, device=dev)
+        nbytes = arena.numel() * 8
+        stream = torch.cuda.current_stream().cuda_stream
+        for _ in range(2):
+            _lib.check(lib.amcx_probe_read_bw(arena.data_ptr(), nbytes, part.data_ptr(), stream))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            _lib.check(lib.amcx_probe_read_bw(arena.data_ptr(), nbytes, part.data_ptr(), stream))
+        e1.record()
+        torch.cuda.synchronize()
+        read_peak = nbytes * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        return
+
+    total_frames = frames_per_launch * world * args.steps
+    value = total_frames / wall
+    mean_launch_s = sum(launch_ms) / len(launch_ms) * 1e-3
+    alg_bytes = (8 * FRAME_SIZE + 72) * frames_per_launch
+    achieved = alg_bytes / mean_launch_s / 1e9
+    rec = {
+        "metric": "IQ frames/sec (18 features, 2048-sample complex64)",
+        "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"{N_MODS} mods x {N_SNR} SNR x {args.frames} frames x {FRAME_SIZE} samples "
+                        f"complex64 per GPU (BASELINE configs[1]), resident in HBM; one launch per step",
+            "frames_per_gpu_per_step": frames_per_launch, "frame_size": FRAME_SIZE,
+            "kernel": _lib.kernel_name(FRAME_SIZE, _lib.VARIANTS[args.variant]),
+            "sharding": f"frames x{world}, no collective on the data path",
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": _pmc_traffic(frames_per_launch),
+            "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_ms": mean_launch_s * 1e3,
+            "measured_read_peak_GBps": read_peak,
+        },
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(rec))
+
+
+if __name__ == "__main__":
+    main()

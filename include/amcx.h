@@ -1,0 +1,120 @@
+/*
+ * amcx.h -- C ABI of the MI355X IQ feature-extraction engine (libamcx.so).
+ *
+ * The reference (ronnymilleo/amcpy) is pure Python and has no FFI layer; the
+ * seams this ABI replaces are plain Python call sites:
+ *
+ *   per frame : amcpy.features.calculate_features(feature_ids, signal)
+ *               src/amcpy/features.py:214-232   (18 feature fns :66-185)
+ *   per batch : the `_Worker` loop body
+ *               feature_matrix[snr, frame, :] = calculate_features(1..18, signal)
+ *               src/amcpy/feature_extraction.py:30-39, fed by :64-72
+ *
+ * A binding is a ctypes stub of ~15 lines; see INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types cross this boundary.
+ *   - IQ layout: row-major frames of interleaved (re, im) float32 == numpy
+ *     complex64 == the reference's (n_snr, n_frames, >=frame_size) container
+ *     flattened to [n_frames][row_stride_elems] (README.md:60-73;
+ *     feature_extraction.py:68 takes the first frame_size samples of a row).
+ *   - output: out[f * out_row_stride + j], j = 0..17 is feature id j+1 of
+ *     frame f, float32 (feature_extraction.py:35,56).  Caller allocates both
+ *     buffers and keeps them alive until the stream has drained; the library
+ *     holds no persistent state and never frees caller memory.
+ *   - every function returns 0 or a negative AMCX_E* code and never throws.
+ *     NaN/Inf in the data are not errors: a frame holding a non-finite sample
+ *     yields 18 NaNs, as numpy's arithmetic does for the reference.
+ *   - re-entrant and thread-safe; launches are asynchronous on `hip_stream`
+ *     (a hipStream_t, NULL = default stream); completion = caller's stream sync.
+ */
+#ifndef AMCX_H_
+#define AMCX_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMCX_ABI_VERSION 1
+#define AMCX_NUM_FEATURES 18
+
+/* error codes */
+#define AMCX_OK 0
+#define AMCX_EINVAL (-1)   /* null pointer, negative count, bad stride, frame_size out of range */
+#define AMCX_ENOTSUP (-2)  /* requested kernel variant cannot handle this frame_size */
+#define AMCX_EHIP (-3)     /* HIP runtime / launch failure (see amcx_last_hip_error) */
+#define AMCX_ENODEV (-4)   /* no usable gfx950 device */
+#define AMCX_ENOMEM (-5)   /* device allocation failed (host-buffer entry point only) */
+
+/* kernel variants (amcx_features18_c64_ex) */
+#define AMCX_VARIANT_AUTO 0     /* fastest kernel that supports frame_size */
+#define AMCX_VARIANT_BLOCK 1    /* one 256-thread workgroup per frame, frame staged in LDS,
+                                   radix-2 LDS FFT (power of two) or direct DFT (any N);
+                                   fp64 accumulation; 2 <= frame_size <= AMCX_MAX_FRAME_SIZE */
+#define AMCX_VARIANT_WAVE 2     /* one wavefront per frame, frame held in registers,
+                                   register radix-16/8 FFT with LDS exchanges;
+                                   frame_size in {1024, 2048, 4096} */
+
+#define AMCX_MIN_FRAME_SIZE 2
+#define AMCX_MAX_FRAME_SIZE 8192
+
+int amcx_abi_version(void);
+const char* amcx_strerror(int code);
+/* text of the last HIP error seen by the calling thread ("" if none) */
+const char* amcx_last_hip_error(void);
+/* number of visible devices whose architecture is gfx950; <0 on error */
+int amcx_device_count(void);
+
+/*
+ * All 18 features of n_frames frames, device buffers.
+ * Replaces the `_Worker.run` loop body, feature_extraction.py:30-39, for a
+ * whole (n_snr * n_frames) block at once.
+ *   iq_dev            device pointer, complex64 [n_frames][row_stride_elems]
+ *   row_stride_elems  distance between frame starts in complex elements, >= frame_size
+ *   out_dev           device pointer, float32 [n_frames][out_row_stride]
+ *   out_row_stride    in floats, >= 18
+ *   hip_stream        hipStream_t or NULL
+ * n_frames == 0 is a valid no-op.
+ */
+int amcx_features18_c64(const void* iq_dev, int64_t n_frames, int32_t frame_size,
+                        int64_t row_stride_elems, float* out_dev, int64_t out_row_stride,
+                        void* hip_stream);
+
+/* Same, with an explicit kernel variant (tests and benchmarks). */
+int amcx_features18_c64_ex(const void* iq_dev, int64_t n_frames, int32_t frame_size,
+                           int64_t row_stride_elems, float* out_dev, int64_t out_row_stride,
+                           void* hip_stream, int32_t variant);
+
+/*
+ * Same computation for HOST buffers (numpy arrays): allocates device scratch,
+ * copies in, runs the kernel on `device`, copies the (n_frames x 18) result
+ * back and returns when it is in `out_host`.  Replaces a direct
+ * calculate_features(...) call, features.py:214-232, without torch.
+ * This is NOT a CPU implementation: it fails with AMCX_ENODEV without a GPU.
+ */
+int amcx_features18_c64_host(const void* iq_host, int64_t n_frames, int32_t frame_size,
+                             int64_t row_stride_elems, float* out_host, int64_t out_row_stride,
+                             int32_t device, int32_t variant);
+
+/*
+ * Name of the kernel `variant` resolves to for this frame_size (as it shows in
+ * rocprofv3 kernel traces), written NUL-terminated into buf.  Returns 0, or
+ * AMCX_ENOTSUP / AMCX_EINVAL.
+ */
+int amcx_kernel_name(int32_t frame_size, int32_t variant, char* buf, int32_t buf_len);
+
+/*
+ * Streaming-read ceiling probe: sums n_bytes of device memory with 16-byte
+ * loads (one float per workgroup written to partial_dev, >= 4096 floats).
+ * Used by bench.py to report the measured HBM read ceiling next to the
+ * nominal 8 TB/s.  n_bytes must be a multiple of 16.
+ */
+int amcx_probe_read_bw(const void* src_dev, int64_t n_bytes, float* partial_dev,
+                       void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMCX_H_ */
