@@ -93,6 +93,7 @@ def test_golden_edges(golden_edges):
     N, g = golden_edges
     names = [str(s) for s in g["names"]]
     ref = g["golden64_f64"]
+    S = orc.conditioning_scales(np.nan_to_num(g["iq"]))
     for variant in _variants_for(N):
         got = _run(g["iq"], variant).astype(np.float64)
         for i, name in enumerate(names):
@@ -109,13 +110,19 @@ def test_golden_edges(golden_edges):
                 skip[[7, 8]] = True
             if name in ("real_only", "imag_only"):
                 skip[8] = True
+            if name == "ramp_phase_pi":
+                # every phase step is pi - O(1e-16): an exact +-pi tie in fp32, just
+                # off the tie in fp64, so the sign of each wrapped step (hence f5)
+                # is decided by rounding residue in the reference itself; the
+                # deterministic tie case is the 'alternating' frame
+                skip[4] = True
             sel = ~np.isnan(r) & ~skip
             assert not np.isnan(o[sel]).any(), (variant, name, o, r)
             # absolute floor: constant phase/envelope series give exact zeros in
-            # fp64 but fp32 rounding dust here
-            scale = np.maximum(np.abs(r[sel]), 2e-6 * max(1.0, np.abs(r[sel][:9]).max()))
-            big = np.abs(r[sel]) > 1e3            # cumulants of the 3e5-amplitude frame
-            err = np.abs(o[sel] - r[sel]) / np.where(big, np.abs(r[sel]), scale)
+            # fp64 but fp32 rounding dust here; cumulants (ids 10, 12-18) are
+            # judged against their conditioning scale S like everywhere else
+            scale = np.maximum(np.maximum(np.abs(r), S[i]), 2e-6)
+            err = (np.abs(o - r) / scale)[sel]
             assert err.max() <= 2e-5, (variant, name, err, o, r)
 
 

@@ -9,7 +9,7 @@
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
 
-constexpr int ITERS = 2000;
+constexpr int ITERS = 100000;
 constexpr int UNROLL = 32;   // instructions per loop body
 
 template <int KIND>
@@ -19,7 +19,9 @@ __global__ void k(float* out, unsigned long long* cyc) {
   double d0 = a0, d1 = a1, d2 = a2, d3 = a3, e0 = 1.0000001, e1 = 1e-9;
   typedef float v2 __attribute__((ext_vector_type(2)));
   v2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, q0 = {b0, b1}, q1 = {b1, b0};
+  unsigned long long msk = 0x5555aaaa5555aaaaull ^ (unsigned long long)blockIdx.x;
   unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
   for (int i = 0; i < ITERS; ++i) {
     if constexpr (KIND == 0) {        // v_fma_f32, 8 independent chains
 #pragma unroll
@@ -67,9 +69,9 @@ __global__ void k(float* out, unsigned long long* cyc) {
 #pragma unroll
       for (int u = 0; u < UNROLL / 8; ++u)
         asm volatile(
-            "v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n"
-            "v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc\n"
-            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b0) : "vcc");
+            "v_cndmask_b32_e64 %0, %0, %8, %9\n v_cndmask_b32_e64 %1, %1, %8, %9\n v_cndmask_b32_e64 %2, %2, %8, %9\n v_cndmask_b32_e64 %3, %3, %8, %9\n"
+            "v_cndmask_b32_e64 %4, %4, %8, %9\n v_cndmask_b32_e64 %5, %5, %8, %9\n v_cndmask_b32_e64 %6, %6, %8, %9\n v_cndmask_b32_e64 %7, %7, %8, %9\n"
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b0), "s"(msk));
     } else if constexpr (KIND == 7) { // v_cvt_f64_f32 + v_add_f64 pair
 #pragma unroll
       for (int u = 0; u < UNROLL / 8; ++u)
@@ -86,9 +88,10 @@ __global__ void k(float* out, unsigned long long* cyc) {
     }
   }
   unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
   float s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y + (float)(d0 + d1 + d2 + d3);
   if (s == 12345.678f) out[0] = s;
-  if ((threadIdx.x & 63) == 0) cyc[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
+  if ((threadIdx.x & 63) == 0) { cyc[2 * ((blockIdx.x * blockDim.x + threadIdx.x) >> 6)] = t1 - t0; cyc[2 * ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) + 1] = r1 - r0; }
 }
 
 template <int KIND>
@@ -100,7 +103,7 @@ void run(const char* name, int waves_per_simd) {
   int grid = cus * blocks_per_cu;
   float* out; unsigned long long* cyc;
   int nw = grid * threads / 64;
-  CHECK(hipMalloc(&out, 4)); CHECK(hipMalloc(&cyc, nw * 8));
+  CHECK(hipMalloc(&out, 4)); CHECK(hipMalloc(&cyc, nw * 16));
   hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
   hipLaunchKernelGGL(k<KIND>, dim3(grid), dim3(threads), 0, 0, out, cyc);
   CHECK(hipDeviceSynchronize());
@@ -108,13 +111,14 @@ void run(const char* name, int waves_per_simd) {
   hipLaunchKernelGGL(k<KIND>, dim3(grid), dim3(threads), 0, 0, out, cyc);
   CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
   float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
-  std::vector<unsigned long long> h(nw);
-  CHECK(hipMemcpy(h.data(), cyc, nw * 8, hipMemcpyDeviceToHost));
-  double avg = 0; for (auto v : h) avg += (double)v; avg /= nw;
+  std::vector<unsigned long long> h(2 * nw);
+  CHECK(hipMemcpy(h.data(), cyc, nw * 16, hipMemcpyDeviceToHost));
+  double avg = 0, avr = 0; for (int i = 0; i < nw; ++i) { avg += (double)h[2 * i]; avr += (double)h[2 * i + 1]; } avg /= nw; avr /= nw;
+  double ghz = avg / (avr * 10.0);  // s_memrealtime ticks at 100 MHz
   double instr_per_wave = (double)ITERS * UNROLL;
   // cycles per wave-instruction per SIMD = wave cycles / (instr per wave * waves on the SIMD)
-  printf("%-28s waves/SIMD=%d  s_memtime ticks per wave-instr per SIMD = %.3f   chip rate = %.1f G wave-instr/s  (%.3f ms)\n",
-         name, waves_per_simd, avg / (instr_per_wave * waves_per_simd), nw * instr_per_wave / (ms * 1e6), ms);
+  printf("%-28s waves/SIMD=%d  cycles per wave-instr per SIMD = %.3f   clock %.2f GHz   chip rate = %.1f G wave-instr/s  (%.2f ms)\n",
+         name, waves_per_simd, avg / (instr_per_wave * waves_per_simd), ghz, nw * instr_per_wave / (ms * 1e6), ms);
   CHECK(hipFree(out)); CHECK(hipFree(cyc));
 }
 
