@@ -28,8 +28,11 @@
 // Every ds_write_b64 / ds_read_b64 / ds_read_b128 of the exchanges and twiddle
 // tables is bank-conflict free and addressed as lane_base + immediate.
 //
-// LDS per 384-thread workgroup: twiddles 15 KiB + 960 B, 6 x 8704 B exchange,
-// 6 x 1056 B sums stash = 73.9 KB -> two workgroups (12 waves, 3 per SIMD) per CU.
+// LDS per 768-thread workgroup: twiddles 15 KiB + 960 B, 12 x 8704 B exchange,
+// 12 x 1056 B sums stash = 133.4 KB -> one workgroup (12 waves, exactly 3 per
+// SIMD) per CU.  (Two 6-wave workgroups do NOT co-reside: their waves land
+// 2,2,1,1 on the SIMDs and a SIMD holds at most 3 waves of 160 VGPRs --
+// measured as half the waves' lifetime in SQ_WAVE_CYCLES, profiles/r1.)
 // Algorithmic HBM bytes per frame: 8*N read + 72 written.
 #pragma once
 
@@ -41,7 +44,7 @@
 namespace amcx {
 namespace wave {
 
-constexpr int kWavesPerWG = 6;
+constexpr int kWavesPerWG = 12;              // 3 per SIMD: one workgroup fills a CU
 constexpr int kThreads = 64 * kWavesPerWG;
 constexpr int kFramesPerWave = 8;               // frames per wave per batch (finalised together)
 constexpr int kFramesPerBatch = kWavesPerWG * kFramesPerWave;
@@ -454,12 +457,12 @@ inline hipError_t launch_wave(const float2* iq, int64_t n_frames, int32_t frame_
                               hipStream_t stream, int cus) {
   if (frame_size != 2048) return hipErrorNotSupported;
   auto kern = wave::amcx_features18_wave_kernel<2048>;
-  static_assert(wave::kLdsBytes <= 80 * 1024, "two workgroups per CU must fit in 160 KiB of LDS");
+  static_assert(wave::kLdsBytes <= 160 * 1024, "one workgroup per CU must fit in 160 KiB of LDS");
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, wave::kLdsBytes);
   if (e != hipSuccess) return e;
   const int64_t n_batches = (n_frames + wave::kFramesPerBatch - 1) / wave::kFramesPerBatch;
-  int64_t grid = (int64_t)cus * 2;                    // persistent: two resident workgroups per CU
+  int64_t grid = (int64_t)cus;                        // persistent: one resident workgroup per CU
   if (grid > n_batches) grid = n_batches;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(wave::kThreads), wave::kLdsBytes, stream, iq,
                      (long long)n_frames, (long long)row_stride, out, (long long)out_stride);

@@ -225,12 +225,22 @@ def batch_moments(frames: np.ndarray) -> Dict[str, np.ndarray]:
     }
 
 
-def conditioning_scales(frames: np.ndarray) -> np.ndarray:
+def conditioning_scales(frames: np.ndarray, absolute: bool = False) -> np.ndarray:
     """(F, 18) scale S per feature for the tolerance of SURVEY.md section 8c:
     S = sum(|term|) of the cumulant's formula for ids 12..18, S = m21 for id 10,
     S = |value| (i.e. plain relative) for every other id (returned as 0 so the
-    caller takes max(|golden|, S))."""
+    caller takes max(|golden|, S)).
+
+    ``absolute=True`` bounds every complex moment by the mean of its summands'
+    magnitudes first (|m20| <= m21, |m40|,|m41| <= m42, |m60|,|m61|,|m62| <=
+    m63): the conditioning of the moment sums themselves.  Needed only for
+    degenerate frames (a pure tone: every complex moment cancels to ~1e-17 in
+    fp64), where the plain term sum collapses to rounding dust."""
     m = batch_moments(frames)
+    if absolute:
+        m21, m42, m63 = np.abs(m["m21"]), np.abs(m["m42"]), np.abs(m["m63"])
+        m = {"m20": m21, "m21": m21, "m22": m21, "m40": m42, "m41": m42, "m42": m42,
+             "m43": m42, "m60": m63, "m61": m63, "m62": m63, "m63": m63}
     terms = cumulant_terms(m)
     F = np.asarray(frames).shape[0]
     S = np.zeros((F, N_FEATURES))

@@ -93,7 +93,7 @@ def test_golden_edges(golden_edges):
     N, g = golden_edges
     names = [str(s) for s in g["names"]]
     ref = g["golden64_f64"]
-    S = orc.conditioning_scales(np.nan_to_num(g["iq"]))
+    S = orc.conditioning_scales(np.nan_to_num(g["iq"]), absolute=True)
     for variant in _variants_for(N):
         got = _run(g["iq"], variant).astype(np.float64)
         for i, name in enumerate(names):
@@ -118,12 +118,14 @@ def test_golden_edges(golden_edges):
                 skip[4] = True
             sel = ~np.isnan(r) & ~skip
             assert not np.isnan(o[sel]).any(), (variant, name, o, r)
-            # absolute floor: constant phase/envelope series give exact zeros in
-            # fp64 but fp32 rounding dust here; cumulants (ids 10, 12-18) are
-            # judged against their conditioning scale S like everywhere else
-            scale = np.maximum(np.maximum(np.abs(r), S[i]), 2e-6)
-            err = (np.abs(o - r) / scale)[sel]
-            assert err.max() <= 2e-5, (variant, name, err, o, r)
+            # cumulants (ids 10-18): relative to max(|ref|, S) like everywhere else;
+            # ids 1-9: the same 2e-5 relative plus 2e-6 absolute, because series
+            # that are exactly constant in fp64 (zero std) carry fp32 rounding
+            # dust of ~1e-7 here
+            atol = np.where(np.arange(18) < 9, 2e-6, 0.0)
+            lim = 2e-5 * np.maximum(np.abs(r), S[i]) + atol
+            bad = (np.abs(o - r) > lim) & sel
+            assert not bad.any(), (variant, name, np.nonzero(bad)[0] + 1, o, r)
 
 
 def test_random_frames_against_oracle():

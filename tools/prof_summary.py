@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (tools/profile.sh) into a short text + JSON summary."""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+out = sys.argv[1]
+summary = {}
+
+def rows(pattern):
+    for f in glob.glob(os.path.join(out, pattern), recursive=True):
+        with open(f, newline="") as fh:
+            for r in csv.DictReader(fh):
+                yield r
+
+# kernel stats
+for r in rows("trace/**/*kernel_stats.csv"):
+    name = r.get("Name", "")
+    if "amcx" in name:
+        summary.setdefault("kernel_stats", []).append(
+            {k: r[k] for k in r if k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "Percentage", "StdDev")})
+# per-dispatch durations from the kernel trace
+dur = defaultdict(list)
+meta = {}
+for r in rows("trace/**/*kernel_trace.csv"):
+    n = r.get("Kernel_Name", "")
+    if "amcx" in n:
+        dur[n].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        meta[n] = {k: r.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size")}
+summary["dispatch_ns"] = {n: {"n": len(v), "mean": sum(v) / len(v), "min": min(v), "max": max(v), **meta[n]} for n, v in dur.items()}
+# counters: mean per dispatch of each counter for amcx feature kernels
+ctr = defaultdict(lambda: defaultdict(list))
+for d in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2"):
+    for r in rows(f"{d}/**/*counter_collection.csv"):
+        n = r.get("Kernel_Name", "")
+        if "amcx_features18" in n:
+            ctr[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
+summary["counters_mean_per_dispatch"] = {n: {c: sum(v) / len(v) for c, v in cs.items()} for n, cs in ctr.items()}
+print(json.dumps(summary, indent=1))

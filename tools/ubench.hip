@@ -9,7 +9,7 @@
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
 
-constexpr int ITERS = 100000;
+constexpr int ITERS = 40000;
 constexpr int UNROLL = 32;   // instructions per loop body
 
 template <int KIND>
@@ -86,6 +86,20 @@ __global__ void k(float* out, unsigned long long* cyc) {
             "v_pk_mul_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %5\n v_pk_mul_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %5\n"
             : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(q0), "v"(q1));
     }
+#define OP8(str, ...) \
+    _Pragma("unroll") for (int u = 0; u < UNROLL / 8; ++u) asm volatile(str : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b0), "v"(b1) __VA_ARGS__);
+    else if constexpr (KIND == 10) { OP8("v_mul_f32_e32 %0, %8, %0\n v_mul_f32_e32 %1, %8, %1\n v_mul_f32_e32 %2, %8, %2\n v_mul_f32_e32 %3, %8, %3\n v_mul_f32_e32 %4, %8, %4\n v_mul_f32_e32 %5, %8, %5\n v_mul_f32_e32 %6, %8, %6\n v_mul_f32_e32 %7, %8, %7\n") }
+    else if constexpr (KIND == 11) { OP8("v_add_f32_e32 %0, %8, %0\n v_add_f32_e32 %1, %8, %1\n v_add_f32_e32 %2, %8, %2\n v_add_f32_e32 %3, %8, %3\n v_add_f32_e32 %4, %8, %4\n v_add_f32_e32 %5, %8, %5\n v_add_f32_e32 %6, %8, %6\n v_add_f32_e32 %7, %8, %7\n") }
+    else if constexpr (KIND == 12) { OP8("v_fmac_f32_e32 %0, %8, %9\n v_fmac_f32_e32 %1, %8, %9\n v_fmac_f32_e32 %2, %8, %9\n v_fmac_f32_e32 %3, %8, %9\n v_fmac_f32_e32 %4, %8, %9\n v_fmac_f32_e32 %5, %8, %9\n v_fmac_f32_e32 %6, %8, %9\n v_fmac_f32_e32 %7, %8, %9\n") }
+    else if constexpr (KIND == 13) { OP8("v_mov_b32_e32 %0, %1\n v_mov_b32_e32 %1, %2\n v_mov_b32_e32 %2, %3\n v_mov_b32_e32 %3, %4\n v_mov_b32_e32 %4, %5\n v_mov_b32_e32 %5, %6\n v_mov_b32_e32 %6, %7\n v_mov_b32_e32 %7, %8\n") }
+    else if constexpr (KIND == 14) { OP8("v_max_f32_e32 %0, %8, %0\n v_max_f32_e32 %1, %8, %1\n v_max_f32_e32 %2, %8, %2\n v_max_f32_e32 %3, %8, %3\n v_max_f32_e32 %4, %8, %4\n v_max_f32_e32 %5, %8, %5\n v_max_f32_e32 %6, %8, %6\n v_max_f32_e32 %7, %8, %7\n") }
+    else if constexpr (KIND == 15) { OP8("v_fmaak_f32 %0, %8, %0, 0x3f800001\n v_fmaak_f32 %1, %8, %1, 0x3f800001\n v_fmaak_f32 %2, %8, %2, 0x3f800001\n v_fmaak_f32 %3, %8, %3, 0x3f800001\n v_fmaak_f32 %4, %8, %4, 0x3f800001\n v_fmaak_f32 %5, %8, %5, 0x3f800001\n v_fmaak_f32 %6, %8, %6, 0x3f800001\n v_fmaak_f32 %7, %8, %7, 0x3f800001\n") }
+    else if constexpr (KIND == 16) { OP8("v_cmp_gt_f32_e32 vcc, %8, %0\n v_cndmask_b32_e32 %1, %1, %9, vcc\n v_cmp_gt_f32_e32 vcc, %8, %2\n v_cndmask_b32_e32 %3, %3, %9, vcc\n v_cmp_gt_f32_e32 vcc, %8, %4\n v_cndmask_b32_e32 %5, %5, %9, vcc\n v_cmp_gt_f32_e32 vcc, %8, %6\n v_cndmask_b32_e32 %7, %7, %9, vcc\n", : "vcc") }
+    else if constexpr (KIND == 17) { OP8("v_mul_f32_e32 %0, %8, %0\n v_fma_f32 %1, %1, %8, %9\n v_add_f32_e32 %2, %8, %2\n v_fma_f32 %3, %3, %8, %9\n v_mul_f32_e32 %4, %8, %4\n v_fma_f32 %5, %5, %8, %9\n v_sub_f32_e32 %6, %8, %6\n v_fma_f32 %7, %7, %8, %9\n") }
+    else if constexpr (KIND == 18) { OP8("v_fma_f32 %0, %0, %8, %1\n v_fma_f32 %1, %1, %8, %2\n v_fma_f32 %2, %2, %8, %3\n v_fma_f32 %3, %3, %8, %4\n v_fma_f32 %4, %4, %8, %5\n v_fma_f32 %5, %5, %8, %6\n v_fma_f32 %6, %6, %8, %7\n v_fma_f32 %7, %7, %8, %0\n") }
+    else if constexpr (KIND == 19) { OP8("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n") }
+    else if constexpr (KIND == 20) { OP8("v_bfi_b32 %0, %8, %0, %9\n v_and_b32_e32 %1, %8, %1\n v_bfi_b32 %2, %8, %2, %9\n v_and_b32_e32 %3, %8, %3\n v_rndne_f32_e32 %4, %4\n v_min_f32_e32 %5, %8, %5\n v_rndne_f32_e32 %6, %6\n v_min_f32_e32 %7, %8, %7\n") }
+
   }
   unsigned long long t1 = __builtin_amdgcn_s_memtime();
   unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
@@ -97,7 +111,7 @@ __global__ void k(float* out, unsigned long long* cyc) {
 template <int KIND>
 void run(const char* name, int waves_per_simd) {
   int cus = 256;
-  int threads = 64 * 4 * waves_per_simd;   // one workgroup per CU, 4 SIMDs
+  int threads = 64 * 4 * waves_per_simd;   // one workgroup per CU, 4 SIMDs (3/SIMD -> 768 threads)
   if (threads > 1024) { threads = 1024; }
   int blocks_per_cu = (64 * 4 * waves_per_simd) / threads;
   int grid = cus * blocks_per_cu;
@@ -123,7 +137,7 @@ void run(const char* name, int waves_per_simd) {
 }
 
 int main() {
-  for (int w : {1, 2, 4}) {
+  for (int w : {1, 3, 4}) {
     run<0>("v_fma_f32", w);
     run<1>("v_pk_fma_f32", w);
     run<8>("v_pk_mul/add_f32", w);
@@ -133,6 +147,17 @@ int main() {
     run<5>("v_add_f32_dpp", w);
     run<6>("v_cndmask_b32", w);
     run<7>("v_cvt_f64_f32+v_add_f64", w);
+    run<10>("v_mul_f32_e32", w);
+    run<11>("v_add_f32_e32", w);
+    run<12>("v_fmac_f32_e32", w);
+    run<13>("v_mov_b32_e32", w);
+    run<14>("v_max_f32_e32", w);
+    run<15>("v_fmaak_f32 (literal)", w);
+    run<16>("v_cmp+v_cndmask vcc", w);
+    run<17>("mix mul/fma/add/fma", w);
+    run<18>("v_fma_f32 cross-dependent", w);
+    run<19>("v_fma_f32 single chain", w);
+    run<20>("bfi/and/rndne/min mix", w);
   }
   return 0;
 }
