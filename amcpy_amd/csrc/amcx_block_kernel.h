@@ -99,8 +99,8 @@ __global__ __launch_bounds__(kBlockThreads) void amcx_features18_block_kernel(
         m[6] += AP; m[7] += Bh * P;
         m[8] += AA * A; m[9] += A * BB; m[10] += AA * Bh; m[11] += BB * Bh;
         m[12] += AA * P; m[13] += BB * P; m[14] += AP * Bh;
-        const float a = __builtin_sqrtf(__builtin_fmaf(x.x, x.x, x.y * x.y));
-        const float th = fast_angle(x.x, x.y);
+        const float a = __builtin_amdgcn_sqrtf(__builtin_fmaf(x.x, x.x, __builtin_fmaf(x.y, x.y, kTinyPower)));
+        const float th = fast_angle(x.x, x.y, a);
         at[n] = make_float2(a, th);
         e[0] += a; e[1] += th; e[2] += __builtin_fabsf(th);
       }

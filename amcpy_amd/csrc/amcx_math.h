@@ -17,33 +17,40 @@ constexpr double kTwoPiD = 6.283185307179586476925286766559;
 // ---------------------------------------------------------------------------
 // angle(x) = atan2(im, re) in (-pi, pi], numpy semantics on the axes:
 // angle(0) = 0, angle(-1+0j) = +pi, angle(-1-0j) = -pi  (reference
-// features.py:28 -> np.angle).  ~23 VALU issue slots, max abs error 1.5e-7
-// (8-term minimax of atan(r)/r on [0,1], tools/fit_atan.py; fp32 Horner).
-// NaN inputs do not propagate through min/max here: a frame with a
-// non-finite sample is turned into 18 NaNs by the finaliser instead, from the
-// NaN its power sum carries.
+// features.py:28 -> np.angle).
+//
+// Half-angle form on the envelope the caller already has (a = |x|):
+//   u = im / (a + |re|) = tan(phi/2),  phi = atan2(im, |re|) in [-pi/2, pi/2], |u| <= 1
+//   theta = phi                      (re >= 0)
+//         = copysign(pi, im) - phi   (re <  0, incl. -0)
+// -- no min/max/swap, the odd polynomial carries the sign: ~16 plain VALU ops
+// plus one v_rcp_f32, against ~23 for the octant-reduction form (min/max,
+// compares and selects issue at 2/3 the rate of mul/add/fma on gfx950,
+// profiles/r1_valu_issue_rates.txt).  The denominator is a sum of
+// non-negatives, so nothing cancels; max abs error 2.5e-7 rad.
+// `a` must be > 0: callers form it as sqrt(re^2 + im^2 + kTinyPower), which
+// leaves every normal input unchanged and makes angle(0) = 0 fall out.
+// NaN inputs are not tracked here: a frame with a non-finite sample is turned
+// into 18 NaNs by the finaliser, from the NaN its power sum carries.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float fast_angle(float re, float im) {
-  const float ax = __builtin_fabsf(re);
-  const float ay = __builtin_fabsf(im);
-  const float mx = __builtin_fmaxf(ax, ay);
-  const float mn = __builtin_fminf(ax, ay);
-  // mx == 0 -> r = 0 * rcp(FLT_MIN) = 0 -> angle 0
-  const float r = mn * __builtin_amdgcn_rcpf(__builtin_fmaxf(mx, 1.17549435e-38f));
-  const float s = r * r;
-  float q = -4.054567212e-03f;
-  q = __builtin_fmaf(q, s, 2.186295787e-02f);
-  q = __builtin_fmaf(q, s, -5.591232676e-02f);
-  q = __builtin_fmaf(q, s, 9.642197328e-02f);
-  q = __builtin_fmaf(q, s, -1.390862955e-01f);
-  q = __builtin_fmaf(q, s, 1.994656565e-01f);
-  q = __builtin_fmaf(q, s, -3.332986078e-01f);
-  q = __builtin_fmaf(q, s, 9.999993356e-01f);
-  float t = q * r;                                    // atan(mn/mx) in [0, pi/4]
-  t = (ay > ax) ? (kHalfPi - t) : t;                  // first quadrant angle
-  t = (__builtin_signbitf(re)) ? (kPi - t) : t;       // re < 0 or re == -0
-  // re == -0 with im == 0 must give +-pi like atan2; the sign-bit test does that.
-  return __builtin_copysignf(t, im);
+constexpr float kTinyPower = 1.0e-37f;
+
+__device__ __forceinline__ float fast_angle(float re, float im, float a) {
+  const float den = a + __builtin_fabsf(re);
+  const float u = im * __builtin_amdgcn_rcpf(den);
+  const float s = u * u;
+  // 2*atan(u)/u, 8-term minimax on [0,1] (tools/fit_atan.py coefficients x 2)
+  float q = -8.109134424e-03f;
+  q = __builtin_fmaf(q, s, 4.372591574e-02f);
+  q = __builtin_fmaf(q, s, -1.118246535e-01f);
+  q = __builtin_fmaf(q, s, 1.928439466e-01f);
+  q = __builtin_fmaf(q, s, -2.781725910e-01f);
+  q = __builtin_fmaf(q, s, 3.989313130e-01f);
+  q = __builtin_fmaf(q, s, -6.665971279e-01f);   // +1 ulp: makes 2*atan(1) evaluate to fl(pi/2) exactly
+  q = __builtin_fmaf(q, s, 1.999998671e+00f);
+  const float phi = q * u;
+  const float flip = __builtin_copysignf(kPi, im) - phi;
+  return __builtin_signbitf(re) ? flip : phi;
 }
 
 // diff(unwrap(theta))[i] from two neighbouring angles: d - 2*pi*rint(d/2pi),
@@ -107,14 +114,17 @@ __device__ inline void finalize_features(const FrameSums& s, int N, float* __res
   out[2] = (float)__builtin_sqrt(ct2 / (n - 1.0));
 
   // ---- envelope: f4, f6, f7, f8
-  const double mu = s.sa * inv;
+  // an all-zero frame reaches here as N samples of power kTinyPower (the angle
+  // guard): restore the exact zeros so that f4 is 0/0 = NaN as in the reference
+  const bool zero_frame = s.sP <= 2.0 * n * (double)kTinyPower;
+  const double mu = zero_frame ? 0.0 : s.sa * inv;
   {
     const double mad = s.sad1 * inv;                    // mean |a-mu|
     double v = s.sad2 - n * mad * mad;                  // sum (|a-mu| - mad)^2
     if (v < 0) v = 0;
     out[3] = (float)(__builtin_sqrt(v / (n - 1.0)) / mu);   // 0/0 -> NaN for a zero frame
     out[5] = (float)mu;
-    out[6] = (float)(__builtin_sqrt(s.sa) * inv);
+    out[6] = (float)(__builtin_sqrt(zero_frame ? 0.0 : s.sa) * inv);
     const double m2 = s.sad2 * inv, m4 = s.sad4 * inv;
     out[7] = (float)(m4 / (m2 * m2));                   // m2 == 0 -> NaN (scipy rule)
   }
@@ -135,6 +145,11 @@ __device__ inline void finalize_features(const FrameSums& s, int N, float* __res
   }
 
   // ---- mixed moments (complex as (re, im) pairs)
+  if (zero_frame) {   // the guard's kTinyPower must not leak into |C20| ... |C63| of a zero frame
+#pragma unroll
+    for (int j = 9; j < 18; ++j) out[j] = 0.f;
+    return;
+  }
   const double m20r = s.sA * inv, m20i = 2.0 * s.sBh * inv;
   const double m21 = s.sP * inv;
   const double m40r = (s.sAA - 4.0 * s.sBB) * inv, m40i = 4.0 * s.sAB * inv;

@@ -36,6 +36,8 @@
 // Algorithmic HBM bytes per frame: 8*N read + 72 written.
 #pragma once
 
+#include <stdlib.h>
+
 #include <type_traits>
 #include <utility>
 
@@ -169,11 +171,31 @@ __device__ __forceinline__ void lds_wave_fence() {
 
 struct c2 { float re, im; };
 
+// Diagnostic build only (tools/wave_stamps.hip defines AMCX_WAVE_STAMPS): per-section
+// s_memtime deltas summed per wave into a buffer nothing else reads.  The product
+// build compiles none of this.
+#ifdef AMCX_WAVE_STAMPS
+#define AMCX_STAMP_ARG , unsigned long long* __restrict__ stamp_out
+#define AMCX_STAMP(sec)                                                               \
+  do {                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                \
+    unsigned long long t_;                                                            \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
+    __builtin_amdgcn_sched_barrier(0);                                                \
+    stamp_acc[sec] += t_ - stamp_last;                                                \
+    stamp_last = t_;                                                                  \
+  } while (0)
+#else
+#define AMCX_STAMP_ARG
+#define AMCX_STAMP(sec) do { } while (0)
+#endif
+constexpr int kStampSections = 8;
+
 // ---------------------------------------------------------------------------
-template <int N>
+template <int N, bool PREFETCH>
 __global__ __launch_bounds__(kThreads, 3) void amcx_features18_wave_kernel(
     const float2* __restrict__ iq, long long n_frames, long long row_stride,
-    float* __restrict__ out, long long out_stride) {
+    float* __restrict__ out, long long out_stride AMCX_STAMP_ARG) {
   static_assert(N == 2048, "register-FFT kernel is instantiated for N = 2048");
   extern __shared__ float4 amcx_wave_smem[];
   char* smem = reinterpret_cast<char*>(amcx_wave_smem);
@@ -211,21 +233,51 @@ __global__ __launch_bounds__(kThreads, 3) void amcx_features18_wave_kernel(
   char* const ex2_r = ex + (n3L * kEx2StrideK2 + kkL * 8) * 8;   // (lane&7) is k2lo for the reader
 
   const long long n_batches = (n_frames + kFramesPerBatch - 1) / kFramesPerBatch;
+#ifdef AMCX_WAVE_STAMPS
+  unsigned long long stamp_acc[kStampSections] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+  const unsigned long long real0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  float4 xv[16];                 // lane l, vector i = samples 128 i + 2 l + {0, 1}
+  bool have_next = false;        // xv already holds (or is receiving) the frame about to be processed
+  auto load_frame = [&](long long f) {
+    const float2* src = iq + f * row_stride + 2 * lane;
+    static_for<16>([&](auto ii) {
+      constexpr int i = decltype(ii)::value;
+      xv[i] = *reinterpret_cast<const float4*>(src + 128 * i);
+    });
+  };
   for (long long batch = blockIdx.x; batch < n_batches; batch += gridDim.x) {
     const long long f0 = batch * kFramesPerBatch + (long long)wave * kFramesPerWave;
     long long left = n_frames - f0;
     const int n_here = left <= 0 ? 0 : (left < kFramesPerWave ? (int)left : kFramesPerWave);
 
+    // the frame's 16 x 16-byte vectors; the NEXT frame's are requested as soon as
+    // pass 1 has parked this frame in LDS, so HBM latency hides under passes 2-3
+    if (PREFETCH && !have_next && n_here > 0) load_frame(f0);
     for (int g = 0; g < n_here; ++g) {
       asm volatile("; MARK load");
-      // ---- load: 16 x global_load_dwordx4, lane l gets samples 128 i + 2 l + {0,1}
-      const float2* src = iq + (f0 + g) * row_stride + 2 * lane;
+      AMCX_STAMP(7);
       float xr[32], xi[32];
-      static_for<16>([&](auto ii) {
-        constexpr int i = decltype(ii)::value;
-        const float4 v = *reinterpret_cast<const float4*>(src + 128 * i);
-        xr[2 * i] = v.x; xi[2 * i] = v.y; xr[2 * i + 1] = v.z; xi[2 * i + 1] = v.w;
-      });
+      if constexpr (PREFETCH) {
+        static_for<16>([&](auto ii) {
+          constexpr int i = decltype(ii)::value;
+          xr[2 * i] = xv[i].x; xi[2 * i] = xv[i].y; xr[2 * i + 1] = xv[i].z; xi[2 * i + 1] = xv[i].w;
+        });
+      } else {
+        const float2* src = iq + (f0 + g) * row_stride + 2 * lane;
+        static_for<16>([&](auto ii) {
+          constexpr int i = decltype(ii)::value;
+          const float4 v = *reinterpret_cast<const float4*>(src + 128 * i);
+          xr[2 * i] = v.x; xi[2 * i] = v.y; xr[2 * i + 1] = v.z; xi[2 * i + 1] = v.w;
+        });
+      }
+      // frame this wave handles after (f0 + g): next of the batch, else first of its next batch
+      long long f_next = f0 + g + 1;
+      if (g + 1 >= n_here) {
+        f_next = (batch + gridDim.x) * kFramesPerBatch + (long long)wave * kFramesPerWave;
+      }
+      have_next = f_next < n_frames && (g + 1 < n_here || batch + gridDim.x < n_batches);
 
       // =====================================================================
       // statistics sweep
@@ -245,7 +297,7 @@ __global__ __launch_bounds__(kThreads, 3) void amcx_features18_wave_kernel(
           constexpr int b = decltype(bb)::value;
           constexpr int e = 2 * i + b;
           const float re = xr[e], im = xi[e];
-          const float q = im * im;
+          const float q = __builtin_fmaf(im, im, kTinyPower);   // zero guard for fast_angle, free in the fma
           const float P = __builtin_fmaf(re, re, q);
           const float A = __builtin_fmaf(re, re, -q);
           const float Bh = re * im;
@@ -263,7 +315,7 @@ __global__ __launch_bounds__(kThreads, 3) void amcx_features18_wave_kernel(
           const float av = __builtin_amdgcn_sqrtf(P);
           a_lds[e * 64] = av;
           sa += av;
-          th[b] = fast_angle(re, im);
+          th[b] = fast_angle(re, im, av);
         });
         if constexpr (i == 0) {
           // shifts: mean over the wave of the first angle / first step
@@ -301,6 +353,7 @@ __global__ __launch_bounds__(kThreads, 3) void amcx_features18_wave_kernel(
       });
 
       asm volatile("; MARK envelope");
+      AMCX_STAMP(0);
       __builtin_amdgcn_sched_barrier(0);
       // envelope second sweep about the exact mean
       const float mu = bcast_l63(wave_sum_l63(sa)) * (1.0f / (float)N);
@@ -317,6 +370,7 @@ __global__ __launch_bounds__(kThreads, 3) void amcx_features18_wave_kernel(
       // spectral peak: 16 x 16 x 8 register FFT
       // =====================================================================
       asm volatile("; MARK fft1");
+      AMCX_STAMP(1);
       __builtin_amdgcn_sched_barrier(0);
       // pass 1 (both b groups), twiddle T1, exchange 1
       float v0r[16], v0i[16], v1r[16], v1i[16];
@@ -355,7 +409,11 @@ __global__ __launch_bounds__(kThreads, 3) void amcx_features18_wave_kernel(
         });
       });
 
+      // x is dead: prefetch behind passes 2 and 3 (branch-free: with nothing left, the
+      // current frame is simply requested again and never used)
+      if (PREFETCH) load_frame(have_next ? f_next : f0 + g);
       asm volatile("; MARK fft2");
+      AMCX_STAMP(2);
       __builtin_amdgcn_sched_barrier(0);
       // pass 2, twiddle T2, exchange 2, pass 3
       dif<16, 0>(zr[0], zi[0]);
@@ -402,25 +460,78 @@ __global__ __launch_bounds__(kThreads, 3) void amcx_features18_wave_kernel(
       // wave reduction of the 27 partial results -> stash row g (lane 63 writes)
       // =====================================================================
       asm volatile("; MARK reduce");
+      AMCX_STAMP(3);
       __builtin_amdgcn_sched_barrier(0);
-      float red[kNumSums] = {sA, sBh, sP, sAA, sBB, sAB, sAP, sBP, sAAA, sABB, sAAB, sBBB, sAAP, sBBP,
-                             sABP, sa, sad1, sad2, sad4, st1, st2, sabst, sw1, sw2, sw3, sw4, 0.f};
-      static_for<kNumSums - 1>([&](auto jj) {
+      // 26 sums: two swap levels (lane bits 5, 4) halve the live values each time --
+      // v_permlane32_swap / v_permlane16_swap exchange half a register pair in one
+      // instruction -- then four DPP steps inside the 16-lane rows.  70 VALU ops
+      // against 156 for 26 independent 6-step butterflies.
+      float r28[28] = {sA, sBh, sP, sAA, sBB, sAB, sAP, sBP, sAAA, sABB, sAAB, sBBB, sAAP, sBBP,
+                       sABP, sa, sad1, sad2, sad4, st1, st2, sabst, sw1, sw2, sw3, sw4, 0.f, 0.f};
+      // (inline asm: hipcc 7.2 folds the two results of __builtin_amdgcn_permlane*_swap
+      //  into one register here -- "v_add v3, v142, v142" -- so the swaps are spelled
+      //  out; one statement per level, opening with the two wait states a VALU
+      //  write -> v_permlane* read needs, which hipcc does not add inside asm.)
+      asm volatile(
+          "s_nop 1\n\t"
+          "v_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\t"
+          "v_permlane32_swap_b32 %4, %5\n\tv_permlane32_swap_b32 %6, %7\n\t"
+          "v_permlane32_swap_b32 %8, %9\n\tv_permlane32_swap_b32 %10, %11\n\t"
+          "v_permlane32_swap_b32 %12, %13\n\tv_permlane32_swap_b32 %14, %15\n\t"
+          "v_permlane32_swap_b32 %16, %17\n\tv_permlane32_swap_b32 %18, %19\n\t"
+          "v_permlane32_swap_b32 %20, %21\n\tv_permlane32_swap_b32 %22, %23\n\t"
+          "v_permlane32_swap_b32 %24, %25\n\tv_permlane32_swap_b32 %26, %27"
+          : "+v"(r28[0]), "+v"(r28[1]), "+v"(r28[2]), "+v"(r28[3]), "+v"(r28[4]), "+v"(r28[5]),
+            "+v"(r28[6]), "+v"(r28[7]), "+v"(r28[8]), "+v"(r28[9]), "+v"(r28[10]), "+v"(r28[11]),
+            "+v"(r28[12]), "+v"(r28[13]), "+v"(r28[14]), "+v"(r28[15]), "+v"(r28[16]), "+v"(r28[17]),
+            "+v"(r28[18]), "+v"(r28[19]), "+v"(r28[20]), "+v"(r28[21]), "+v"(r28[22]), "+v"(r28[23]),
+            "+v"(r28[24]), "+v"(r28[25]), "+v"(r28[26]), "+v"(r28[27]));
+      // lanes 0-31: value 2j summed over lane bit 5; lanes 32-63: value 2j+1
+      float r14[14];
+      static_for<14>([&](auto jj) {
         constexpr int j = decltype(jj)::value;
-        red[j] = wave_sum_l63(red[j]);
+        r14[j] = r28[2 * j] + r28[2 * j + 1];
       });
-      red[kNumSums - 1] = wave_max_l63(peak);
-      if (lane == 63) {
+      asm volatile(
+          "s_nop 1\n\t"
+          "v_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\t"
+          "v_permlane16_swap_b32 %4, %5\n\tv_permlane16_swap_b32 %6, %7\n\t"
+          "v_permlane16_swap_b32 %8, %9\n\tv_permlane16_swap_b32 %10, %11\n\t"
+          "v_permlane16_swap_b32 %12, %13"
+          : "+v"(r14[0]), "+v"(r14[1]), "+v"(r14[2]), "+v"(r14[3]), "+v"(r14[4]), "+v"(r14[5]),
+            "+v"(r14[6]), "+v"(r14[7]), "+v"(r14[8]), "+v"(r14[9]), "+v"(r14[10]), "+v"(r14[11]),
+            "+v"(r14[12]), "+v"(r14[13]));
+      // rows 0..3 now hold values 4j+0, 4j+2, 4j+1, 4j+3 summed over lane bits 5 and 4
+      float r7[7];
+      static_for<7>([&](auto jj) {
+        constexpr int j = decltype(jj)::value;
+        float v = r14[2 * j] + r14[2 * j + 1];
+        v += dpp<kQuadXor1>(v);
+        v += dpp<kQuadXor2>(v);
+        v += dpp<kRowHalfMirror>(v);
+        v += dpp<kRowMirror>(v);
+        r7[j] = v;
+      });
+      const float pk = wave_max_l63(peak);
+      {
         float* row = stash + g * kStashStride;
-        static_for<kNumSums>([&](auto jj) {
-          constexpr int j = decltype(jj)::value;
-          row[j] = red[j];
-        });
-        row[kNumSums] = Kt;
-        row[kNumSums + 1] = Kw;
+        if ((lane & 15) == 0) {                    // one lane per row: rows hold 4j + {0, 2, 1, 3}
+          const int rsel = lane >> 4;
+          float* dst = row + (((rsel & 1) << 1) | (rsel >> 1));
+          static_for<7>([&](auto jj) {
+            constexpr int j = decltype(jj)::value;
+            dst[4 * j] = r7[j];
+          });
+        }
+        if (lane == 63) {
+          row[kNumSums - 1] = pk;                  // overwrites the zero pad slot 26
+          row[kNumSums] = Kt;
+          row[kNumSums + 1] = Kw;
+        }
       }
     }
 
+    AMCX_STAMP(4);
     asm volatile("; MARK finalize");
     // ---- batch finalisation: lane g turns frame g's sums into 18 features ----
     lds_wave_fence();
@@ -441,7 +552,15 @@ __global__ __launch_bounds__(kThreads, 3) void amcx_features18_wave_kernel(
       for (int j = 0; j < 18; ++j) dst[j] = feat[j];
     }
     lds_wave_fence();
+    AMCX_STAMP(5);
   }
+#ifdef AMCX_WAVE_STAMPS
+  if (lane == 0) {
+    const long long w = (long long)blockIdx.x * kWavesPerWG + wave;
+    stamp_acc[6] = __builtin_amdgcn_s_memrealtime() - real0;   // wave lifetime, 100 MHz ticks
+    for (int k = 0; k < kStampSections; ++k) stamp_out[w * kStampSections + k] = stamp_acc[k];
+  }
+#endif
 }
 
 }  // namespace wave
@@ -452,11 +571,13 @@ inline const char* wave_kernel_name(int frame_size) {
   return frame_size == 2048 ? "amcx_features18_wave_kernel<2048>" : "";
 }
 
+#ifndef AMCX_WAVE_STAMPS
 inline hipError_t launch_wave(const float2* iq, int64_t n_frames, int32_t frame_size,
                               int64_t row_stride, float* out, int64_t out_stride,
                               hipStream_t stream, int cus) {
   if (frame_size != 2048) return hipErrorNotSupported;
-  auto kern = wave::amcx_features18_wave_kernel<2048>;
+  static const bool prefetch = getenv("AMCX_WAVE_PREFETCH") != nullptr;   // experiment switch
+  auto kern = prefetch ? wave::amcx_features18_wave_kernel<2048, true> : wave::amcx_features18_wave_kernel<2048, false>;
   static_assert(wave::kLdsBytes <= 160 * 1024, "one workgroup per CU must fit in 160 KiB of LDS");
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, wave::kLdsBytes);
@@ -468,5 +589,6 @@ inline hipError_t launch_wave(const float2* iq, int64_t n_frames, int32_t frame_
                      (long long)n_frames, (long long)row_stride, out, (long long)out_stride);
   return hipGetLastError();
 }
+#endif
 
 }  // namespace amcx
