@@ -1,0 +1,104 @@
+"""Batch feature extraction: the MI355X drop-in for the reference's
+``run_extraction(cfg)`` (src/amcpy/feature_extraction.py:85-99).
+
+Same call, same files: reads ``cfg.paths.mat_data / cfg.paths.mat_filename``
+(one variable per modulation, ``cfg.signals.mat_info[mod]``, shaped
+``(n_snr, n_frames, >= frame_size)`` complex; feature_extraction.py:46-48) and
+writes ``cfg.paths.calculated_features / f"{mod}_features.mat"`` holding exactly
+``"Modulation"`` and ``mat_info[mod]`` -> float32 ``(n_snr, n_frames, 18)``
+(feature_extraction.py:56,77-81), so preprocessing / plotting / training code
+that loads those files is untouched.
+
+What is different underneath:
+* the container is loaded ONCE (the reference re-loads the whole file in each
+  of its six child processes, feature_extraction.py:46-47);
+* there are no worker processes or threads: each modulation's block goes to
+  the GPU as one ``(n_snr*n_frames, frame_size)`` launch of the HIP kernel
+  behind the C ABI (``cfg.signals.num_threads`` is advisory);
+* with several ranks (one process per GPU, ``torch.distributed`` initialised by
+  the caller) frames are sharded contiguously across ranks and rank 0 writes
+  the files (amcpy_amd/sharding.py); no collective touches the IQ data;
+* a failure raises: the reference's worker threads swallow exceptions and leave
+  zero rows behind (feature_extraction.py:33-39).
+"""
+from __future__ import annotations
+
+import time
+from typing import Callable, Dict, Optional
+
+import numpy as np
+
+from .config import Config
+from .sharding import sharded_features
+
+
+def _rank_world():
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+    except Exception:
+        pass
+    return 0, 1
+
+
+def _hip_compute(frame_size: int, device: Optional[int]) -> Callable[[np.ndarray], np.ndarray]:
+    """(F, L) complex numpy -> (F, 18) float32 through device memory."""
+    import torch
+    from .features import features18
+
+    dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+
+    def compute(block: np.ndarray) -> np.ndarray:
+        x = np.ascontiguousarray(block[:, :frame_size], dtype=np.complex64)   # MATLAB doubles -> c64
+        xd = torch.from_numpy(x).to(dev, non_blocking=False)
+        y = features18(xd)
+        return y.cpu().numpy()
+
+    return compute
+
+
+def extract_modulation(parsed: np.ndarray, cfg: Config, *, compute=None, device: Optional[int] = None,
+                       group=None) -> Optional[np.ndarray]:
+    """All 18 features of one modulation's ``(n_snr, n_frames, L)`` array.
+    Returns float32 ``(n_snr, n_frames, 18)`` on rank 0 (None on other ranks)."""
+    n_snr = len(cfg.signals.snr_values)
+    n_frames = cfg.signals.num_frames
+    N = cfg.signals.frame_size
+    n_feat = len(cfg.features.all_features)
+    if n_feat != 18:
+        raise ValueError("the extraction engine always produces the 18 features of FeatureConfig.all_features")
+    if parsed.ndim != 3 or parsed.shape[0] < n_snr or parsed.shape[1] < n_frames or parsed.shape[2] < N:
+        raise ValueError(f"container array has shape {parsed.shape}, config needs "
+                         f"(>={n_snr}, >={n_frames}, >={N})")
+    rank, world = _rank_world()
+    flat = parsed[:n_snr, :n_frames].reshape(n_snr * n_frames, parsed.shape[2])
+    fn = compute or _hip_compute(N, device)
+    mat = sharded_features(flat, N, fn, rank, world, group)
+    return None if mat is None else mat.reshape(n_snr, n_frames, n_feat)
+
+
+def run_extraction(cfg: Config, *, compute=None, device: Optional[int] = None, verbose: bool = True) -> None:
+    """Drop-in for the reference's ``run_extraction(cfg)``: writes one
+    ``{mod}_features.mat`` per entry of ``cfg.signals.modulations_with_noise``."""
+    import scipy.io
+
+    rank, _ = _rank_world()
+    cfg.paths.ensure_dirs()
+    mat_path = cfg.paths.mat_data / cfg.paths.mat_filename
+    wanted = [cfg.signals.mat_info[m] for m in cfg.signals.modulations_with_noise]
+    data = scipy.io.loadmat(str(mat_path), variable_names=wanted)      # once, not once per modulation
+    for mod in cfg.signals.modulations_with_noise:
+        t0 = time.perf_counter()
+        key = cfg.signals.mat_info[mod]
+        if key not in data:
+            raise KeyError(f"{mat_path} has no variable {key!r} for modulation {mod}")
+        feats = extract_modulation(np.asarray(data[key]), cfg, compute=compute, device=device)
+        if rank == 0:
+            out_path = cfg.paths.calculated_features / f"{mod}_features.mat"
+            scipy.io.savemat(str(out_path), {"Modulation": mod, key: feats})
+            if verbose:
+                print(f"[{mod}] {feats.shape[0] * feats.shape[1]} frames in "
+                      f"{time.perf_counter() - t0:.2f}s -> {out_path}")
+    if verbose and rank == 0:
+        print("All feature calculations complete!")

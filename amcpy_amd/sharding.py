@@ -1,0 +1,58 @@
+"""Frame sharding across the GPUs of one node.
+
+Every frame is independent (reference feature_extraction.py:64-72 enqueues
+each (snr, frame) on its own), so the flattened frame index g in [0, F) is cut
+into contiguous blocks, rank r of W taking
+``[r*ceil(F/W), min(F, (r+1)*ceil(F/W)))``: contiguous in memory, never
+splitting a frame, and with no collective on the data path.  The only
+cross-rank step is gathering the tiny (F x 18) float32 result on rank 0.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import numpy as np
+
+
+def shard_range(n_frames: int, rank: int, world: int) -> Tuple[int, int]:
+    """Half-open frame range of ``rank``; empty ranges are (k, k)."""
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError(f"bad rank {rank} of {world}")
+    if n_frames < 0:
+        raise ValueError("n_frames must be >= 0")
+    per = -(-n_frames // world) if n_frames else 0
+    lo = min(n_frames, rank * per)
+    return lo, min(n_frames, lo + per)
+
+
+def gather_rows(local: np.ndarray, n_frames: int, rank: int, world: int, group=None) -> Optional[np.ndarray]:
+    """Collect every rank's (n_local, 18) block on rank 0 as (n_frames, 18).
+
+    Uses ``torch.distributed.gather_object`` on whatever backend the caller
+    initialised (RCCL for GPU jobs, gloo in the CPU tests): at 72 bytes per
+    frame this is a latency-bound host-side step, not a bandwidth one.
+    Returns the full matrix on rank 0 and None elsewhere."""
+    if world == 1:
+        return local
+    import torch.distributed as dist
+    parts = [None] * world if rank == 0 else None
+    dist.gather_object(np.ascontiguousarray(local), parts, dst=0, group=group)
+    if rank != 0:
+        return None
+    out = np.empty((n_frames, local.shape[1]), dtype=local.dtype)
+    for r, blk in enumerate(parts):
+        lo, hi = shard_range(n_frames, r, world)
+        if blk.shape[0] != hi - lo:
+            raise RuntimeError(f"rank {r} returned {blk.shape[0]} rows for [{lo}, {hi})")
+        out[lo:hi] = blk
+    return out
+
+
+def sharded_features(frames: np.ndarray, frame_size: int, compute: Callable[[np.ndarray], np.ndarray],
+                     rank: int = 0, world: int = 1, group=None) -> Optional[np.ndarray]:
+    """(F, L) complex frames -> (F, 18) float32 on rank 0, each rank computing
+    its contiguous block with ``compute`` (the HIP engine in production)."""
+    F = frames.shape[0]
+    lo, hi = shard_range(F, rank, world)
+    local = compute(frames[lo:hi]) if hi > lo else np.empty((0, 18), dtype=np.float32)
+    return gather_rows(np.asarray(local, dtype=np.float32), F, rank, world, group)

@@ -257,3 +257,31 @@ def test_linearity_properties_full_size():
     perm = torch.randperm(4096, device="cuda")
     yp = features18(x[:, perm].contiguous()).double()
     assert torch.equal(yp, y[:, perm])
+
+
+def test_run_extraction_roundtrip_on_gpu(tmp_path):
+    """The drop-in batch driver against what the reference's own
+    run_extraction wrote for the same container (fixture captured from the
+    imported reference): same files, keys, dtype, shape; values within
+    tolerance.  Rows are longer than frame_size and complex128, as MATLAB gives."""
+    import scipy.io
+    from amcpy_amd.config import Config, Paths, SignalConfig
+    from amcpy_amd.feature_extraction import run_extraction
+    g = load_npz("extract_roundtrip.npz")
+    fs, n_frames = int(g["frame_size"]), int(g["n_frames"])
+    mods = [str(m) for m in g["mods"]]
+    cfg = Config(paths=Paths(root=tmp_path),
+                 signals=SignalConfig(snr_values={0: "0", 1: "10"}, num_frames=n_frames, frame_size=fs))
+    cfg.paths.ensure_dirs()
+    scipy.io.savemat(str(cfg.paths.mat_data / cfg.paths.mat_filename),
+                     {cfg.signals.mat_info[m]: g[f"in_{m}"].astype(np.complex128) for m in mods})
+    run_extraction(cfg, verbose=False)
+    for m in mods:
+        d = scipy.io.loadmat(str(cfg.paths.calculated_features / f"{m}_features.mat"))
+        assert sorted(k for k in d if not k.startswith("__")) == sorted(["Modulation", cfg.signals.mat_info[m]])
+        arr = d[cfg.signals.mat_info[m]]
+        assert arr.dtype == np.float32 and arr.shape == (2, n_frames, 18)
+        assert str(np.ravel(d["Modulation"])[0]) == m
+        x = g[f"in_{m}"][:, :, :fs].reshape(-1, fs)
+        _assert_parity(arr.reshape(-1, 18), g[f"out_{m}"].reshape(-1, 18).astype(np.float64), x,
+                       f"run_extraction {m}")
