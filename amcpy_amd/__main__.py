@@ -1,0 +1,5 @@
+import sys
+
+from .main import main
+
+sys.exit(main())

@@ -142,8 +142,10 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ        # launched by torch.distributed.run
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # ---- resident shard: (mods, snr, frames, N) complex64 arena in HBM --------
@@ -160,7 +162,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -177,7 +179,7 @@ def main():
     fence()
     wall = time.perf_counter() - t0
     launch_ms = [a.elapsed_time(b) for a, b in ev]
-    if world > 1:
+    if use_dist:
         t = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
@@ -202,7 +204,7 @@ def main():
         torch.cuda.synchronize()
         read_peak = nbytes * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank != 0:
