@@ -109,23 +109,26 @@ __global__ __launch_bounds__(kBlockThreads) void amcx_features18_block_kernel(
       S.sA = m[0]; S.sBh = m[1]; S.sP = m[2]; S.sAA = m[3]; S.sBB = m[4]; S.sAB = m[5];
       S.sAP = m[6]; S.sBP = m[7]; S.sAAA = m[8]; S.sABB = m[9]; S.sAAB = m[10]; S.sBBB = m[11];
       S.sAAP = m[12]; S.sBBP = m[13]; S.sABP = m[14];
-      S.sa = e[0]; S.Kt = e[1] / N; S.sabst = e[2];
+      S.sa = e[0]; S.Kt = e[1] / N; S.Ka = e[2] / N;
     }
     // ---- pass B: centred envelope / phase sums, first sum of the steps ---
     {
       const double mu = S.sa / N;
-      double c[6] = {0, 0, 0, 0, 0, 0};
+      double c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       for (int n = tid; n < N; n += kBlockThreads) {
         const float2 v = at[n];
         const double d = (double)v.x - mu, d2 = d * d;
         c[0] += __builtin_fabs(d); c[1] += d2; c[2] += d2 * d2;
         const double dt = (double)v.y - S.Kt;
         c[3] += dt; c[4] += dt * dt;
+        const double da = __builtin_fabs((double)v.y) - S.Ka;
+        c[6] += da; c[7] += da * da;
         if (n + 1 < N) c[5] += wrapped_step(at[n + 1].y, v.y);
       }
       block_sum(c, scratch);
       S.sad1 = c[0]; S.sad2 = c[1]; S.sad4 = c[2]; S.std1 = c[3]; S.std2 = c[4];
       S.Kw = c[5] / (N - 1);
+      S.sab1 = c[6]; S.sab2 = c[7];
     }
     // ---- pass C: centred sums of the wrapped phase step ------------------
     {

@@ -78,7 +78,7 @@ struct FrameSums {
   double sad1, sad2, sad4;       // sum |a-mu|, (a-mu)^2, (a-mu)^4
   // phase theta, shifted by Kt: d = theta - Kt
   double Kt, std1, std2;         // shift, sum d, sum d^2
-  double sabst;                  // sum |theta|
+  double Ka, sab1, sab2;         // |theta| shifted by Ka: sum e, sum e^2 with e = |theta| - Ka
   // wrapped phase step w (N-1 values), shifted by Kw: d = w - Kw
   double Kw, swd1, swd2, swd3, swd4;
   double gmax_raw;               // max_k |X_k|^2 (unnormalised FFT)
@@ -101,14 +101,14 @@ __device__ inline void finalize_features(const FrameSums& s, int N, float* __res
   // ---- f1: gamma_max
   out[0] = (float)(s.gmax_raw * inv);
 
-  // ---- phase: f2 = std1(|theta|), f3 = std1(theta)
+  // ---- phase: f2 = std1(|theta|), f3 = std1(theta); both from sums about a shift
+  // close to the mean (no E[v^2] - E[v]^2 on raw values: |theta| can have a tiny
+  // variance around pi/2 while theta itself spans +-pi)
   const double md = s.std1 * inv;                       // mean of shifted theta
   double ct2 = s.std2 - n * md * md;                    // sum (theta-mean)^2
   if (ct2 < 0) ct2 = 0;
-  const double tbar = s.Kt + md;
-  const double sum_t2 = ct2 + n * tbar * tbar;          // sum theta^2
-  const double mabs = s.sabst * inv;
-  double cabs2 = sum_t2 - n * mabs * mabs;              // sum (|theta|-mean)^2
+  const double ma = s.sab1 * inv;                       // mean of shifted |theta|
+  double cabs2 = s.sab2 - n * ma * ma;                  // sum (|theta|-mean)^2
   if (cabs2 < 0) cabs2 = 0;
   out[1] = (float)__builtin_sqrt(cabs2 / (n - 1.0));
   out[2] = (float)__builtin_sqrt(ct2 / (n - 1.0));

@@ -1,38 +1,45 @@
 // AMCX_VARIANT_WAVE: one wavefront (64 lanes) per frame, frame held in registers.
+// Instantiated for frame sizes 1024, 2048 and 4096.
 //
-// Why not "one 256-thread workgroup per frame": this path is VALU-bound, not
-// HBM-bound (~110 fp32 lane-ops per sample against ~100 available at the HBM
-// roofline), so the design minimises instructions per sample:
-//   * 32 samples per lane (N = 2048) amortise every cross-lane reduction
-//     over 32x more work than a 256-thread block would (8 samples per lane);
-//   * waves never synchronise with each other: no s_barrier in the frame
-//     loop, the LDS exchange buffer is private to the wave;
-//   * the FFT is three register passes (radix 16, 16, 8 with constant
-//     twiddles) joined by two conflict-free LDS transposes, instead of 11
+// Why not "one 256-thread workgroup per frame": this path is VALU/power-bound, not
+// HBM-bound (~103 fp32 VALU ops per sample), so the design
+// minimises instructions per sample:
+//   * 16-64 samples per lane amortise every cross-lane reduction over 4-8x more
+//     work than a 256-thread block would (8 samples per lane at N = 2048);
+//   * waves never synchronise with each other: no s_barrier in the frame loop,
+//     the LDS exchange buffer is private to the wave;
+//   * the FFT is three register passes (radix 16/8, 16, 8 with compile-time
+//     twiddles) joined by two conflict-free LDS transposes, instead of log2(N)
 //     shared-memory radix-2 stages (176 B/sample of LDS traffic -> 32 B);
 //   * centred statistics are one-pass shifted sums (shift = mean of the first
-//     64 samples' value), the envelope alone needs a second sweep over |x|
-//     kept in registers, because f4 needs mean|a - mu| with the exact mu;
+//     64 samples' value); the envelope alone needs a second sweep over |x|,
+//     because f4 needs mean|a - mu| with the exact mu;
 //   * the fp64 scalar algebra that turns 27 sums into 18 features runs once
 //     per batch of kFramesPerWave frames with one frame per lane.
 //
 // Index maps (verified against np.fft.fft with the LDS bank rules in
-// tools/wave_fft_model.py), N = 2048 = R1*R2*R3 = 16*16*8:
-//   load     lane l, register (i, b)  <- x[128 i + 2 l + b]   (global_load_dwordx4, coalesced)
-//   pass 1   16-point DFT over i  -> k1 ; twiddle W_2048^((2l+b) k1)
-//   xchg 1   two phases g = k1>>3:  LDS[kk*136 + b*68 + l] (kk = k1&7), reader lane l'
+// tools/wave_fft_model.py).  A frame is ROWS = N/128 rows of 128 samples:
+//   load     lane l, row i, b in {0,1}  <- x[128 i + 2 l + b]   (global_load_dwordx4, coalesced)
+// Register FFT of NF = 128 R points (R = 16 -> 2048, R = 8 -> 1024), NF = R * 16 * 8:
+//   pass 1   R-point DFT over i   -> k1 ; twiddle W_NF^((2l+b) k1)
+//   xchg 1   phases g = k1>>3:  LDS[kk*136 + b*68 + l] (kk = k1&7); reader lane l'
 //            (kk = l'>>3, n3 = l'&7) takes n2 = 0..15 at [kk*136 + (n3&1)*68 + 4 n2 + (n3>>1)]
 //   pass 2   16-point DFT over n2 -> k2 ; twiddle W_128^(n3 k2)
-//   xchg 2   LDS[k2*65 + 8 kk + n3], reader lane l'' (kk = l''>>3, k2 = (l''&7) + 8 j)
-//   pass 3   8-point DFT over n3  -> X[k1 + 16 k2 + 256 k3], only max |X|^2 is kept
+//   xchg 2   LDS[k2*65 + 8 kk + n3]; reader lane l'' (kk = l''>>3, k2 = (l''&7) + 8 j)
+//   pass 3   8-point DFT over n3  -> X[k1 + R k2 + 16 R k3]; only max |X|^2 is kept
+// N = 4096 is one radix-2 decimation-in-frequency split in front of that machine:
+//   X[2k]   = FFT_2048(x[n] + x[n+2048]),  X[2k+1] = FFT_2048((x[n] - x[n+2048]) W_4096^n):
+// the upper half is streamed once for the statistics while the sum is formed in
+// place; both halves are read a second time (from L2 / Infinity Cache) for the
+// difference FFT, which is also where the envelope's second sweep happens.
 // Every ds_write_b64 / ds_read_b64 / ds_read_b128 of the exchanges and twiddle
 // tables is bank-conflict free and addressed as lane_base + immediate.
 //
-// LDS per 768-thread workgroup: twiddles 15 KiB + 960 B, 12 x 8704 B exchange,
-// 12 x 1056 B sums stash = 133.4 KB -> one workgroup (12 waves, exactly 3 per
-// SIMD) per CU.  (Two 6-wave workgroups do NOT co-reside: their waves land
-// 2,2,1,1 on the SIMDs and a SIMD holds at most 3 waves of 160 VGPRs --
-// measured as half the waves' lifetime in SQ_WAVE_CYCLES, profiles/r1.)
+// 768-thread workgroups: 12 waves = exactly 3 per SIMD, one workgroup per CU.
+// (Two 6-wave workgroups do NOT co-reside: their waves land 2,2,1,1 on the SIMDs
+// and a SIMD holds at most 3 waves of 160 VGPRs -- seen as half the waves'
+// lifetime in SQ_WAVE_CYCLES, profiles/r1a.)  LDS per workgroup at N = 2048:
+// twiddles 15 KiB + 960 B, 12 x 8704 B exchange, 12 x 1056 B stash = 133.4 KB.
 // Algorithmic HBM bytes per frame: 8*N read + 72 written.
 #pragma once
 
@@ -46,20 +53,33 @@
 namespace amcx {
 namespace wave {
 
-constexpr int kWavesPerWG = 12;              // 3 per SIMD: one workgroup fills a CU
+constexpr int kWavesPerWG = 12;
 constexpr int kThreads = 64 * kWavesPerWG;
 constexpr int kFramesPerWave = 8;               // frames per wave per batch (finalised together)
 constexpr int kFramesPerBatch = kWavesPerWG * kFramesPerWave;
-constexpr int kNumSums = 27;
+constexpr int kNumSums = 27;                    // reduced per-lane sums; the spectral peak rides in slot 27
 constexpr int kStashStride = 33;                // floats; odd -> conflict-free column reads
+constexpr int kStashBytes = kFramesPerWave * kStashStride * 4;
 
 constexpr int kEx1StrideKK = 136, kEx1StrideB = 68;   // complex units (tools/wave_fft_model.py)
 constexpr int kEx2StrideK2 = 65;
 constexpr int kExchangeBytes = 8 * kEx1StrideKK * 8;   // 8704 >= 16*65*8 = 8320
+constexpr int kT2Bytes = 15 * 8 * 8;                   // [k2-1][n3] complex
 
-constexpr int kT1Bytes = 15 * 64 * 16;          // [k1-1][lane][b] complex
-constexpr int kT2Bytes = 15 * 8 * 8;            // [k2-1][n3] complex
-constexpr int kLdsBytes = kT1Bytes + kT2Bytes + kWavesPerWG * (kExchangeBytes + kFramesPerWave * kStashStride * 4);
+template <int N>
+struct Cfg {
+  static_assert(N == 1024 || N == 2048 || N == 4096, "wave kernel frame sizes");
+  static constexpr bool kSplit = N == 4096;            // radix-2 DIF split in front of a 2048 FFT
+  static constexpr int kRows = N / 128;                // rows of 128 samples per frame
+  static constexpr int kFftRows = kSplit ? 16 : kRows; // R: rows one register FFT holds
+  static constexpr int kFftN = 128 * kFftRows;
+  static constexpr int kT1Bytes = (kFftRows - 1) * 64 * 16;   // [k1-1][lane][b] complex
+  static constexpr int kT4Bytes = kSplit ? 64 * 16 : 0;       // [lane][b] complex: W_4096^(2l+b)
+  static constexpr int kTableBytes = kT1Bytes + kT2Bytes + kT4Bytes;
+  static constexpr int kLdsBytes = kTableBytes + kWavesPerWG * (kExchangeBytes + kStashBytes);
+  static_assert(kLdsBytes <= 163840, "one workgroup per CU must fit in 160 KiB of LDS");
+  static_assert(kSplit || 2 * kRows * 64 * 4 <= kExchangeBytes, "|x| parking must fit the exchange buffer");
+};
 
 // ---- compile-time loop -------------------------------------------------------
 template <int... I, class F>
@@ -77,36 +97,36 @@ constexpr int bitrev(int v, int bits) {
   return r;
 }
 
-// cos / sin of 2*pi*j/16
-constexpr float kC16[16] = {1.f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f,
-                            0.f, -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f,
-                            -1.f, -0.92387953251128674f, -0.70710678118654752f, -0.38268343236508977f,
-                            0.f, 0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f};
-constexpr float kS16[16] = {0.f, 0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f,
-                            1.f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f,
-                            0.f, -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f,
-                            -1.f, -0.92387953251128674f, -0.70710678118654752f, -0.38268343236508977f};
+// cos / sin of 2*pi*j/32, j = 0..15
+constexpr float kC32[16] = {1.f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f,
+                            0.70710678118654752f, 0.55557023301960218f, 0.38268343236508977f, 0.19509032201612825f,
+                            0.f, -0.19509032201612825f, -0.38268343236508977f, -0.55557023301960218f,
+                            -0.70710678118654752f, -0.83146961230254524f, -0.92387953251128674f, -0.98078528040323043f};
+constexpr float kS32[16] = {0.f, 0.19509032201612825f, 0.38268343236508977f, 0.55557023301960218f,
+                            0.70710678118654752f, 0.83146961230254524f, 0.92387953251128674f, 0.98078528040323043f,
+                            1.f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f,
+                            0.70710678118654752f, 0.55557023301960218f, 0.38268343236508977f, 0.19509032201612825f};
 
-// (r, i) *= W_16^J = cos - i sin, with the trivial cases folded at compile time
+// (r, i) *= W_32^J = cos - i sin (J = 0..15), trivial cases folded at compile time
 template <int J>
-__device__ __forceinline__ void mul_w16(float& r, float& i) {
+__device__ __forceinline__ void mul_w32(float& r, float& i) {
   constexpr float h = 0.70710678118654752f;
   if constexpr (J == 0) {
-  } else if constexpr (J == 4) {            // -i
+  } else if constexpr (J == 8) {            // -i
     const float t = r; r = i; i = -t;
-  } else if constexpr (J == 2) {            // (1 - i)/sqrt2
+  } else if constexpr (J == 4) {            // (1 - i)/sqrt2
     const float t = (r + i) * h; i = (i - r) * h; r = t;
-  } else if constexpr (J == 6) {            // (-1 - i)/sqrt2
+  } else if constexpr (J == 12) {           // (-1 - i)/sqrt2
     const float t = (i - r) * h; i = (-r - i) * h; r = t;
   } else {
-    constexpr float c = kC16[J], s = kS16[J];
+    constexpr float c = kC32[J], s = kS32[J];
     const float t = __builtin_fmaf(r, c, i * s);
     i = __builtin_fmaf(i, c, -(r * s));
     r = t;
   }
 }
 
-// In-place radix-2 decimation-in-frequency DFT of LEN points at [OFF, OFF+LEN);
+// In-place radix-2 decimation-in-frequency DFT of LEN <= 16 points at [OFF, OFF+LEN);
 // result for frequency k sits at OFF + bitrev(k).
 template <int LEN, int OFF, int R>
 __device__ __forceinline__ void dif(float (&re)[R], float (&im)[R]) {
@@ -118,7 +138,7 @@ __device__ __forceinline__ void dif(float (&re)[R], float (&im)[R]) {
       re[OFF + j] = ar + br;
       im[OFF + j] = ai + bi;
       float dr = ar - br, di = ai - bi;
-      mul_w16<j * (16 / LEN)>(dr, di);
+      mul_w32<j * (32 / LEN)>(dr, di);
       re[OFF + j + H] = dr;
       im[OFF + j + H] = di;
     });
@@ -148,12 +168,12 @@ __device__ __forceinline__ float wave_sum_l63(float v) {
   v += dpp<kRowBcast31, 0xc, 0xf, false>(v);
   return v;
 }
+// maximum of non-negative values, valid in lane 63 (lanes without a source row take 0)
 __device__ __forceinline__ float wave_max_l63(float v) {
   v = __builtin_fmaxf(v, dpp<kQuadXor1>(v));
   v = __builtin_fmaxf(v, dpp<kQuadXor2>(v));
   v = __builtin_fmaxf(v, dpp<kRowHalfMirror>(v));
   v = __builtin_fmaxf(v, dpp<kRowMirror>(v));
-  // bound_ctrl=false keeps the lane's own value where the source row does not exist
   v = __builtin_fmaxf(v, dpp<kRowBcast15, 0xa, 0xf, false>(v));
   v = __builtin_fmaxf(v, dpp<kRowBcast31, 0xc, 0xf, false>(v));
   return v;
@@ -168,8 +188,6 @@ __device__ __forceinline__ void lds_wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
-
-struct c2 { float re, im; };
 
 // Diagnostic build only (tools/wave_stamps.hip defines AMCX_WAVE_STAMPS): per-section
 // s_memtime deltas summed per wave into a buffer nothing else reads.  The product
@@ -192,27 +210,215 @@ struct c2 { float re, im; };
 constexpr int kStampSections = 8;
 
 // ---------------------------------------------------------------------------
-template <int N, bool PREFETCH>
+// Per-lane running sums of the statistics sweep (27 values + the three shifts)
+// ---------------------------------------------------------------------------
+struct Stats {
+  float sA = 0, sBh = 0, sP = 0, sAA = 0, sBB = 0, sAB = 0, sAP = 0, sBP = 0;
+  float sAAA = 0, sABB = 0, sAAB = 0, sBBB = 0, sAAP = 0, sBBP = 0, sABP = 0;
+  float sa = 0, st1 = 0, st2 = 0, sab1 = 0, sab2 = 0, sw1 = 0, sw2 = 0, sw3 = 0, sw4 = 0;
+  float sad1 = 0, sad2 = 0, sad4 = 0;
+  float Kt = 0, Kw = 0, Ka = 0;
+  float th_b1_prev = 0;   // angle of sample (i-1, b=1), waiting for its right neighbour
+  float rot_prev = 0;     // wave_rol1(angle(i-1, b=0))
+
+  __device__ __forceinline__ void step(float w) {
+    const float d = w - Kw, d2 = d * d;
+    sw1 += d; sw2 += d2;
+    sw3 = __builtin_fmaf(d2, d, sw3);
+    sw4 = __builtin_fmaf(d2, d2, sw4);
+  }
+
+  // one row = samples (i, b=0) and (i, b=1) of this lane; returns |x| of both
+  template <bool FIRST, bool LAST>
+  __device__ __forceinline__ void row(float re0, float im0, float re1, float im1, int lane,
+                                      float& a0, float& a1) {
+    float th[2];
+    const float res[2] = {re0, re1}, ims[2] = {im0, im1};
+    float av[2];
+    static_for<2>([&](auto bb) {
+      constexpr int b = decltype(bb)::value;
+      const float re = res[b], im = ims[b];
+      const float q = __builtin_fmaf(im, im, kTinyPower);   // zero guard for fast_angle, free in the fma
+      const float P = __builtin_fmaf(re, re, q);
+      const float A = __builtin_fmaf(re, re, -q);
+      const float Bh = re * im;
+      const float AA = A * A, BB = Bh * Bh, AP = A * P;
+      sA += A; sBh += Bh; sP += P; sAA += AA; sBB += BB; sAP += AP;
+      sAB = __builtin_fmaf(A, Bh, sAB);
+      sBP = __builtin_fmaf(Bh, P, sBP);
+      sAAA = __builtin_fmaf(AA, A, sAAA);
+      sABB = __builtin_fmaf(A, BB, sABB);
+      sAAB = __builtin_fmaf(AA, Bh, sAAB);
+      sBBB = __builtin_fmaf(BB, Bh, sBBB);
+      sAAP = __builtin_fmaf(AA, P, sAAP);
+      sBBP = __builtin_fmaf(BB, P, sBBP);
+      sABP = __builtin_fmaf(AP, Bh, sABP);
+      av[b] = __builtin_amdgcn_sqrtf(P);
+      sa += av[b];
+      th[b] = fast_angle(re, im, av[b]);
+    });
+    a0 = av[0]; a1 = av[1];
+    if constexpr (FIRST) {
+      // shifts: mean over the wave of the first angle / first step
+      const float w00 = wrapped_step(th[1], th[0]);
+      Kt = bcast_l63(wave_sum_l63(th[0])) * (1.0f / 64.0f);
+      Kw = bcast_l63(wave_sum_l63(w00)) * (1.0f / 64.0f);
+      Ka = bcast_l63(wave_sum_l63(__builtin_fabsf(th[0]))) * (1.0f / 64.0f);
+    }
+    static_for<2>([&](auto bb) {
+      constexpr int b = decltype(bb)::value;
+      const float d = th[b] - Kt;
+      st1 += d;
+      st2 = __builtin_fmaf(d, d, st2);
+      const float e = __builtin_fabsf(th[b]) - Ka;
+      sab1 += e;
+      sab2 = __builtin_fmaf(e, e, sab2);
+    });
+    step(wrapped_step(th[1], th[0]));                     // sample (i,0) -> (i,1), same lane
+    const float rot = dpp<kWaveRol1>(th[0]);              // lane l: angle(i,0) of lane l+1 (63 -> lane 0)
+    if constexpr (!FIRST) {
+      // right neighbour of (i-1, b=1) is (i-1, b=0) of lane l+1, or (i, b=0) of lane 0 for lane 63
+      const float nxt = (lane == 63) ? rot : rot_prev;
+      step(wrapped_step(nxt, th_b1_prev));
+    }
+    if constexpr (LAST) {
+      // (last row, b=1): lane 63 holds the frame's last sample, which has no step
+      const float w = wrapped_step(rot, th[1]);
+      step(lane == 63 ? Kw : w);
+    }
+    th_b1_prev = th[1];
+    rot_prev = rot;
+  }
+
+  __device__ __forceinline__ void envelope(float a, float mu) {
+    const float d = a - mu, d2 = d * d;
+    sad1 += __builtin_fabsf(d);
+    sad2 += d2;
+    sad4 = __builtin_fmaf(d2, d2, sad4);
+  }
+};
+
+// LDS addresses that depend only on the lane (bytes)
+struct LaneAddr {
+  const char* t1;     // T1 + lane*16
+  const char* t2;     // T2 + (lane&7)*8
+  char* ex1_w;        // exchange + lane*8
+  const char* ex1_r;
+  char* ex2_w;
+  const char* ex2_r;
+};
+
+// Register FFT of 128*R points held as xr/xi[2*i+b] (see header); returns this
+// lane's max |X|^2 over the 2R bins it ends up with.
+template <int R>
+__device__ __forceinline__ float fft_peak(const float (&xr)[2 * R], const float (&xi)[2 * R],
+                                          const LaneAddr& la) {
+  constexpr int LOG2R = R == 16 ? 4 : 3;
+  constexpr int PH = R / 8;
+  // pass 1 (both b groups), twiddle T1, exchange 1
+  float v0r[R], v0i[R], v1r[R], v1i[R];
+  static_for<R>([&](auto ii) {
+    constexpr int i = decltype(ii)::value;
+    v0r[i] = xr[2 * i]; v0i[i] = xi[2 * i]; v1r[i] = xr[2 * i + 1]; v1i[i] = xi[2 * i + 1];
+  });
+  dif<R, 0>(v0r, v0i);
+  dif<R, 0>(v1r, v1i);
+  static_for<R - 1>([&](auto kk1) {
+    constexpr int k1 = decltype(kk1)::value + 1;
+    constexpr int p = bitrev(k1, LOG2R);
+    const float4 t = *reinterpret_cast<const float4*>(la.t1 + (k1 - 1) * 1024);
+    float r = v0r[p], im = v0i[p];
+    v0r[p] = __builtin_fmaf(r, t.x, -(im * t.y));
+    v0i[p] = __builtin_fmaf(r, t.y, im * t.x);
+    r = v1r[p]; im = v1i[p];
+    v1r[p] = __builtin_fmaf(r, t.z, -(im * t.w));
+    v1i[p] = __builtin_fmaf(r, t.w, im * t.z);
+  });
+  float zr[PH][16], zi[PH][16];
+  static_for<PH>([&](auto gg) {
+    constexpr int gph = decltype(gg)::value;
+    lds_wave_fence();
+    static_for<8>([&](auto kk_) {
+      constexpr int kk = decltype(kk_)::value;
+      constexpr int p = bitrev(8 * gph + kk, LOG2R);
+      *reinterpret_cast<float2*>(la.ex1_w + (kk * kEx1StrideKK) * 8) = make_float2(v0r[p], v0i[p]);
+      *reinterpret_cast<float2*>(la.ex1_w + (kk * kEx1StrideKK + kEx1StrideB) * 8) = make_float2(v1r[p], v1i[p]);
+    });
+    lds_wave_fence();
+    static_for<16>([&](auto nn) {
+      constexpr int n2 = decltype(nn)::value;
+      const float2 v = *reinterpret_cast<const float2*>(la.ex1_r + n2 * 32);
+      zr[gph][n2] = v.x; zi[gph][n2] = v.y;
+    });
+  });
+  asm volatile("; MARK fft2");
+  __builtin_amdgcn_sched_barrier(0);
+  // pass 2, twiddle T2, exchange 2, pass 3
+  static_for<PH>([&](auto gg) { dif<16, 0>(zr[decltype(gg)::value], zi[decltype(gg)::value]); });
+  static_for<15>([&](auto kk2) {
+    constexpr int k2 = decltype(kk2)::value + 1;
+    constexpr int p = bitrev(k2, 4);
+    const float2 t = *reinterpret_cast<const float2*>(la.t2 + (k2 - 1) * 64);
+    static_for<PH>([&](auto gg) {
+      constexpr int gph = decltype(gg)::value;
+      const float r = zr[gph][p], im = zi[gph][p];
+      zr[gph][p] = __builtin_fmaf(r, t.x, -(im * t.y));
+      zi[gph][p] = __builtin_fmaf(r, t.y, im * t.x);
+    });
+  });
+  float peak = 0.f;
+  static_for<PH>([&](auto gg) {
+    constexpr int gph = decltype(gg)::value;
+    lds_wave_fence();
+    static_for<16>([&](auto kk2) {
+      constexpr int k2 = decltype(kk2)::value;
+      constexpr int p = bitrev(k2, 4);
+      *reinterpret_cast<float2*>(la.ex2_w + (k2 * kEx2StrideK2) * 8) = make_float2(zr[gph][p], zi[gph][p]);
+    });
+    lds_wave_fence();
+    static_for<2>([&](auto jj) {
+      constexpr int j = decltype(jj)::value;
+      float ur[8], ui[8];
+      static_for<8>([&](auto nn) {
+        constexpr int n3 = decltype(nn)::value;
+        const float2 v = *reinterpret_cast<const float2*>(la.ex2_r + (j * 8 * kEx2StrideK2 + n3) * 8);
+        ur[n3] = v.x; ui[n3] = v.y;
+      });
+      dif<8, 0>(ur, ui);
+      static_for<8>([&](auto pp) {
+        constexpr int p = decltype(pp)::value;
+        peak = __builtin_fmaxf(peak, __builtin_fmaf(ur[p], ur[p], ui[p] * ui[p]));
+      });
+    });
+  });
+  lds_wave_fence();
+  return peak;
+}
+
+// ---------------------------------------------------------------------------
+template <int N>
 __global__ __launch_bounds__(kThreads, 3) void amcx_features18_wave_kernel(
     const float2* __restrict__ iq, long long n_frames, long long row_stride,
     float* __restrict__ out, long long out_stride AMCX_STAMP_ARG) {
-  static_assert(N == 2048, "register-FFT kernel is instantiated for N = 2048");
+  using C = Cfg<N>;
+  constexpr int R = C::kFftRows;
   extern __shared__ float4 amcx_wave_smem[];
   char* smem = reinterpret_cast<char*>(amcx_wave_smem);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  char* t1 = smem;                                        // [15][64][2] complex
-  char* t2 = smem + kT1Bytes;                             // [15][8] complex
-  char* ex = smem + kT1Bytes + kT2Bytes + wave * kExchangeBytes;
-  float* stash = reinterpret_cast<float*>(smem + kT1Bytes + kT2Bytes + kWavesPerWG * kExchangeBytes) +
+  char* t1 = smem;                                        // [R-1][64][2] complex
+  char* t2 = smem + C::kT1Bytes;                          // [15][8] complex
+  char* t4 = smem + C::kT1Bytes + kT2Bytes;               // [64][2] complex (N = 4096 only)
+  char* ex = smem + C::kTableBytes + wave * kExchangeBytes;
+  float* stash = reinterpret_cast<float*>(smem + C::kTableBytes + kWavesPerWG * kExchangeBytes) +
                  wave * (kFramesPerWave * kStashStride);
 
   // ---- twiddle tables, once per workgroup -----------------------------------
-  for (int e = tid; e < 15 * 128; e += kThreads) {         // T1[k1-1][l][b] = W_2048^((2l+b) k1)
+  for (int e = tid; e < (R - 1) * 128; e += kThreads) {    // T1[k1-1][l][b] = W_NF^((2l+b) k1)
     const int k1 = e / 128 + 1, lb = e % 128;
     float sn, cs;
-    sincospif((float)(lb * k1) * (1.0f / 1024.0f), &sn, &cs);
+    sincospif((float)(lb * k1) * (2.0f / (float)C::kFftN), &sn, &cs);
     reinterpret_cast<float2*>(t1)[e] = make_float2(cs, -sn);
   }
   for (int e = tid; e < 15 * 8; e += kThreads) {           // T2[k2-1][n3] = W_128^(n3 k2)
@@ -221,16 +427,25 @@ __global__ __launch_bounds__(kThreads, 3) void amcx_features18_wave_kernel(
     sincospif((float)(n3 * k2) * (1.0f / 64.0f), &sn, &cs);
     reinterpret_cast<float2*>(t2)[e] = make_float2(cs, -sn);
   }
+  if constexpr (C::kSplit) {
+    for (int e = tid; e < 128; e += kThreads) {            // T4[l][b] = W_4096^(2l+b)
+      float sn, cs;
+      sincospif((float)e * (1.0f / 2048.0f), &sn, &cs);
+      reinterpret_cast<float2*>(t4)[e] = make_float2(cs, -sn);
+    }
+  }
   __syncthreads();
 
   // lane-constant LDS byte addresses
   const int kkL = lane >> 3, n3L = lane & 7;
-  char* const t1_lane = t1 + lane * 16;
-  char* const t2_lane = t2 + n3L * 8;
-  char* const ex1_w = ex + lane * 8;
-  char* const ex1_r = ex + (kkL * kEx1StrideKK + (n3L & 1) * kEx1StrideB + (n3L >> 1)) * 8;
-  char* const ex2_w = ex + lane * 8;
-  char* const ex2_r = ex + (n3L * kEx2StrideK2 + kkL * 8) * 8;   // (lane&7) is k2lo for the reader
+  LaneAddr la;
+  la.t1 = t1 + lane * 16;
+  la.t2 = t2 + n3L * 8;
+  la.ex1_w = ex + lane * 8;
+  la.ex1_r = ex + (kkL * kEx1StrideKK + (n3L & 1) * kEx1StrideB + (n3L >> 1)) * 8;
+  la.ex2_w = ex + lane * 8;
+  la.ex2_r = ex + (n3L * kEx2StrideK2 + kkL * 8) * 8;   // (lane&7) is k2lo for the reader
+  float* const a_lds = reinterpret_cast<float*>(ex) + lane;   // |x| parked in the wave's LDS: [e][lane]
 
   const long long n_batches = (n_frames + kFramesPerBatch - 1) / kFramesPerBatch;
 #ifdef AMCX_WAVE_STAMPS
@@ -238,236 +453,103 @@ __global__ __launch_bounds__(kThreads, 3) void amcx_features18_wave_kernel(
   unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
   const unsigned long long real0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  float4 xv[16];                 // lane l, vector i = samples 128 i + 2 l + {0, 1}
-  bool have_next = false;        // xv already holds (or is receiving) the frame about to be processed
-  auto load_frame = [&](long long f) {
-    const float2* src = iq + f * row_stride + 2 * lane;
-    static_for<16>([&](auto ii) {
-      constexpr int i = decltype(ii)::value;
-      xv[i] = *reinterpret_cast<const float4*>(src + 128 * i);
-    });
-  };
   for (long long batch = blockIdx.x; batch < n_batches; batch += gridDim.x) {
     const long long f0 = batch * kFramesPerBatch + (long long)wave * kFramesPerWave;
     long long left = n_frames - f0;
     const int n_here = left <= 0 ? 0 : (left < kFramesPerWave ? (int)left : kFramesPerWave);
 
-    // the frame's 16 x 16-byte vectors; the NEXT frame's are requested as soon as
-    // pass 1 has parked this frame in LDS, so HBM latency hides under passes 2-3
-    if (PREFETCH && !have_next && n_here > 0) load_frame(f0);
     for (int g = 0; g < n_here; ++g) {
       asm volatile("; MARK load");
       AMCX_STAMP(7);
-      float xr[32], xi[32];
-      if constexpr (PREFETCH) {
-        static_for<16>([&](auto ii) {
-          constexpr int i = decltype(ii)::value;
-          xr[2 * i] = xv[i].x; xi[2 * i] = xv[i].y; xr[2 * i + 1] = xv[i].z; xi[2 * i + 1] = xv[i].w;
-        });
-      } else {
-        const float2* src = iq + (f0 + g) * row_stride + 2 * lane;
-        static_for<16>([&](auto ii) {
-          constexpr int i = decltype(ii)::value;
-          const float4 v = *reinterpret_cast<const float4*>(src + 128 * i);
-          xr[2 * i] = v.x; xi[2 * i] = v.y; xr[2 * i + 1] = v.z; xi[2 * i + 1] = v.w;
-        });
-      }
-      // frame this wave handles after (f0 + g): next of the batch, else first of its next batch
-      long long f_next = f0 + g + 1;
-      if (g + 1 >= n_here) {
-        f_next = (batch + gridDim.x) * kFramesPerBatch + (long long)wave * kFramesPerWave;
-      }
-      have_next = f_next < n_frames && (g + 1 < n_here || batch + gridDim.x < n_batches);
+      // ---- load: R x global_load_dwordx4, lane l gets samples 128 i + 2 l + {0,1}
+      const float2* src = iq + (f0 + g) * row_stride + 2 * lane;
+      float xr[2 * R], xi[2 * R];
+      static_for<R>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        const float4 v = *reinterpret_cast<const float4*>(src + 128 * i);
+        xr[2 * i] = v.x; xi[2 * i] = v.y; xr[2 * i + 1] = v.z; xi[2 * i + 1] = v.w;
+      });
 
       // =====================================================================
       // statistics sweep
       // =====================================================================
-      float sA = 0, sBh = 0, sP = 0, sAA = 0, sBB = 0, sAB = 0, sAP = 0, sBP = 0;
-      float sAAA = 0, sABB = 0, sAAB = 0, sBBB = 0, sAAP = 0, sBBP = 0, sABP = 0;
-      float sa = 0, st1 = 0, st2 = 0, sabst = 0, sw1 = 0, sw2 = 0, sw3 = 0, sw4 = 0;
-      float Kt = 0, Kw = 0;
-      float* const a_lds = reinterpret_cast<float*>(ex) + lane;   // |x| parked in the wave's LDS: [e][lane]
-      float th_b1_prev = 0.f;     // angle of sample (i-1, b=1), waiting for its right neighbour
-      float rot_prev = 0.f;       // wave_rol1(angle(i-1, b=0))
-
-      static_for<16>([&](auto ii) {
+      Stats S;
+      static_for<R>([&](auto ii) {
         constexpr int i = decltype(ii)::value;
-        float th[2];
-        static_for<2>([&](auto bb) {
-          constexpr int b = decltype(bb)::value;
-          constexpr int e = 2 * i + b;
-          const float re = xr[e], im = xi[e];
-          const float q = __builtin_fmaf(im, im, kTinyPower);   // zero guard for fast_angle, free in the fma
-          const float P = __builtin_fmaf(re, re, q);
-          const float A = __builtin_fmaf(re, re, -q);
-          const float Bh = re * im;
-          const float AA = A * A, BB = Bh * Bh, AP = A * P;
-          sA += A; sBh += Bh; sP += P; sAA += AA; sBB += BB; sAP += AP;
-          sAB = __builtin_fmaf(A, Bh, sAB);
-          sBP = __builtin_fmaf(Bh, P, sBP);
-          sAAA = __builtin_fmaf(AA, A, sAAA);
-          sABB = __builtin_fmaf(A, BB, sABB);
-          sAAB = __builtin_fmaf(AA, Bh, sAAB);
-          sBBB = __builtin_fmaf(BB, Bh, sBBB);
-          sAAP = __builtin_fmaf(AA, P, sAAP);
-          sBBP = __builtin_fmaf(BB, P, sBBP);
-          sABP = __builtin_fmaf(AP, Bh, sABP);
-          const float av = __builtin_amdgcn_sqrtf(P);
-          a_lds[e * 64] = av;
-          sa += av;
-          th[b] = fast_angle(re, im, av);
-        });
-        if constexpr (i == 0) {
-          // shifts: mean over the wave of the first angle / first step
-          const float w00 = wrapped_step(th[1], th[0]);
-          Kt = bcast_l63(wave_sum_l63(th[0])) * (1.0f / 64.0f);
-          Kw = bcast_l63(wave_sum_l63(w00)) * (1.0f / 64.0f);
+        float a0, a1;
+        S.template row<i == 0, (!C::kSplit && i == R - 1)>(xr[2 * i], xi[2 * i], xr[2 * i + 1], xi[2 * i + 1],
+                                                          lane, a0, a1);
+        if constexpr (!C::kSplit) {
+          a_lds[(2 * i) * 64] = a0;
+          a_lds[(2 * i + 1) * 64] = a1;
         }
-        static_for<2>([&](auto bb) {
-          constexpr int b = decltype(bb)::value;
-          const float d = th[b] - Kt;
-          st1 += d;
-          st2 = __builtin_fmaf(d, d, st2);
-          sabst += __builtin_fabsf(th[b]);
-        });
-        auto add_step = [&](float w) {
-          const float d = w - Kw, d2 = d * d;
-          sw1 += d; sw2 += d2;
-          sw3 = __builtin_fmaf(d2, d, sw3);
-          sw4 = __builtin_fmaf(d2, d2, sw4);
-        };
-        add_step(wrapped_step(th[1], th[0]));                 // sample (i,0) -> (i,1), same lane
-        const float rot = dpp<kWaveRol1>(th[0]);              // lane l: angle(i,0) of lane l+1 (63 -> lane 0)
-        if constexpr (i > 0) {
-          // right neighbour of (i-1, b=1) is (i-1, b=0) of lane l+1, or (i, b=0) of lane 0 for lane 63
-          const float nxt = (lane == 63) ? rot : rot_prev;
-          add_step(wrapped_step(nxt, th_b1_prev));
-        }
-        if constexpr (i == 15) {
-          // (15, b=1): lane 63 holds the frame's last sample, which has no step
-          const float w = wrapped_step(rot, th[1]);
-          add_step(lane == 63 ? Kw : w);
-        }
-        th_b1_prev = th[1];
-        rot_prev = rot;
       });
-
+      if constexpr (C::kSplit) {
+        // upper half: streamed through the same sweep while x <- x[n] + x[n+2048]
+        static_for<R>([&](auto ii) {
+          constexpr int i = decltype(ii)::value;
+          const float4 v = *reinterpret_cast<const float4*>(src + 128 * (R + i));
+          float a0, a1;
+          S.template row<false, i == R - 1>(v.x, v.y, v.z, v.w, lane, a0, a1);
+          xr[2 * i] += v.x; xi[2 * i] += v.y; xr[2 * i + 1] += v.z; xi[2 * i + 1] += v.w;
+        });
+      }
       asm volatile("; MARK envelope");
       AMCX_STAMP(0);
       __builtin_amdgcn_sched_barrier(0);
       // envelope second sweep about the exact mean
-      const float mu = bcast_l63(wave_sum_l63(sa)) * (1.0f / (float)N);
-      float sad1 = 0, sad2 = 0, sad4 = 0;
-      static_for<32>([&](auto ee) {
-        constexpr int e = decltype(ee)::value;
-        const float d = a_lds[e * 64] - mu, d2 = d * d;
-        sad1 += __builtin_fabsf(d);
-        sad2 += d2;
-        sad4 = __builtin_fmaf(d2, d2, sad4);
-      });
+      const float mu = bcast_l63(wave_sum_l63(S.sa)) * (1.0f / (float)N);
+      if constexpr (!C::kSplit) {
+        static_for<2 * R>([&](auto ee) {
+          constexpr int e = decltype(ee)::value;
+          S.envelope(a_lds[e * 64], mu);
+        });
+      }
 
       // =====================================================================
-      // spectral peak: 16 x 16 x 8 register FFT
+      // spectral peak
       // =====================================================================
       asm volatile("; MARK fft1");
       AMCX_STAMP(1);
       __builtin_amdgcn_sched_barrier(0);
-      // pass 1 (both b groups), twiddle T1, exchange 1
-      float v0r[16], v0i[16], v1r[16], v1i[16];
-      static_for<16>([&](auto ii) {
-        constexpr int i = decltype(ii)::value;
-        v0r[i] = xr[2 * i]; v0i[i] = xi[2 * i]; v1r[i] = xr[2 * i + 1]; v1i[i] = xi[2 * i + 1];
-      });
-      dif<16, 0>(v0r, v0i);
-      dif<16, 0>(v1r, v1i);
-      static_for<15>([&](auto kk1) {
-        constexpr int k1 = decltype(kk1)::value + 1;
-        constexpr int p = bitrev(k1, 4);
-        const float4 t = *reinterpret_cast<const float4*>(t1_lane + (k1 - 1) * 1024);
-        float r = v0r[p], im = v0i[p];
-        v0r[p] = __builtin_fmaf(r, t.x, -(im * t.y));
-        v0i[p] = __builtin_fmaf(r, t.y, im * t.x);
-        r = v1r[p]; im = v1i[p];
-        v1r[p] = __builtin_fmaf(r, t.z, -(im * t.w));
-        v1i[p] = __builtin_fmaf(r, t.w, im * t.z);
-      });
-      float zr[2][16], zi[2][16];
-      static_for<2>([&](auto gg) {
-        constexpr int gph = decltype(gg)::value;
-        lds_wave_fence();
-        static_for<8>([&](auto kk_) {
-          constexpr int kk = decltype(kk_)::value;
-          constexpr int p = bitrev(8 * gph + kk, 4);
-          *reinterpret_cast<float2*>(ex1_w + (kk * kEx1StrideKK) * 8) = make_float2(v0r[p], v0i[p]);
-          *reinterpret_cast<float2*>(ex1_w + (kk * kEx1StrideKK + kEx1StrideB) * 8) = make_float2(v1r[p], v1i[p]);
+      float peak = fft_peak<R>(xr, xi, la);
+      if constexpr (C::kSplit) {
+        // second visit of both halves: envelope sweep, and the difference branch
+        // x <- (x[n] - x[n+2048]) * W_4096^n,  n = 128 i + 2 l + b,  W^n = W_32^i * W_4096^(2l+b)
+        const float4 w4 = *reinterpret_cast<const float4*>(t4 + lane * 16);
+        static_for<R>([&](auto ii) {
+          constexpr int i = decltype(ii)::value;
+          const float4 lo = *reinterpret_cast<const float4*>(src + 128 * i);
+          const float4 hi = *reinterpret_cast<const float4*>(src + 128 * (R + i));
+          S.envelope(__builtin_amdgcn_sqrtf(__builtin_fmaf(lo.x, lo.x, lo.y * lo.y)), mu);
+          S.envelope(__builtin_amdgcn_sqrtf(__builtin_fmaf(lo.z, lo.z, lo.w * lo.w)), mu);
+          S.envelope(__builtin_amdgcn_sqrtf(__builtin_fmaf(hi.x, hi.x, hi.y * hi.y)), mu);
+          S.envelope(__builtin_amdgcn_sqrtf(__builtin_fmaf(hi.z, hi.z, hi.w * hi.w)), mu);
+          float d0r = lo.x - hi.x, d0i = lo.y - hi.y, d1r = lo.z - hi.z, d1i = lo.w - hi.w;
+          mul_w32<i>(d0r, d0i);
+          mul_w32<i>(d1r, d1i);
+          xr[2 * i] = __builtin_fmaf(d0r, w4.x, -(d0i * w4.y));
+          xi[2 * i] = __builtin_fmaf(d0r, w4.y, d0i * w4.x);
+          xr[2 * i + 1] = __builtin_fmaf(d1r, w4.z, -(d1i * w4.w));
+          xi[2 * i + 1] = __builtin_fmaf(d1r, w4.w, d1i * w4.z);
         });
-        lds_wave_fence();
-        static_for<16>([&](auto nn) {
-          constexpr int n2 = decltype(nn)::value;
-          const float2 v = *reinterpret_cast<const float2*>(ex1_r + n2 * 32);
-          zr[gph][n2] = v.x; zi[gph][n2] = v.y;
-        });
-      });
-
-      // x is dead: prefetch behind passes 2 and 3 (branch-free: with nothing left, the
-      // current frame is simply requested again and never used)
-      if (PREFETCH) load_frame(have_next ? f_next : f0 + g);
-      asm volatile("; MARK fft2");
-      AMCX_STAMP(2);
-      __builtin_amdgcn_sched_barrier(0);
-      // pass 2, twiddle T2, exchange 2, pass 3
-      dif<16, 0>(zr[0], zi[0]);
-      dif<16, 0>(zr[1], zi[1]);
-      static_for<15>([&](auto kk2) {
-        constexpr int k2 = decltype(kk2)::value + 1;
-        constexpr int p = bitrev(k2, 4);
-        const float2 t = *reinterpret_cast<const float2*>(t2_lane + (k2 - 1) * 64);
-        static_for<2>([&](auto gg) {
-          constexpr int gph = decltype(gg)::value;
-          const float r = zr[gph][p], im = zi[gph][p];
-          zr[gph][p] = __builtin_fmaf(r, t.x, -(im * t.y));
-          zi[gph][p] = __builtin_fmaf(r, t.y, im * t.x);
-        });
-      });
-      float peak = 0.f;
-      static_for<2>([&](auto gg) {
-        constexpr int gph = decltype(gg)::value;
-        lds_wave_fence();
-        static_for<16>([&](auto kk2) {
-          constexpr int k2 = decltype(kk2)::value;
-          constexpr int p = bitrev(k2, 4);
-          *reinterpret_cast<float2*>(ex2_w + (k2 * kEx2StrideK2) * 8) = make_float2(zr[gph][p], zi[gph][p]);
-        });
-        lds_wave_fence();
-        static_for<2>([&](auto jj) {
-          constexpr int j = decltype(jj)::value;
-          float ur[8], ui[8];
-          static_for<8>([&](auto nn) {
-            constexpr int n3 = decltype(nn)::value;
-            const float2 v = *reinterpret_cast<const float2*>(ex2_r + (j * 8 * kEx2StrideK2 + n3) * 8);
-            ur[n3] = v.x; ui[n3] = v.y;
-          });
-          dif<8, 0>(ur, ui);
-          static_for<8>([&](auto pp) {
-            constexpr int p = decltype(pp)::value;
-            peak = __builtin_fmaxf(peak, __builtin_fmaf(ur[p], ur[p], ui[p] * ui[p]));
-          });
-        });
-      });
-      lds_wave_fence();
+        __builtin_amdgcn_sched_barrier(0);
+        peak = __builtin_fmaxf(peak, fft_peak<R>(xr, xi, la));
+      }
 
       // =====================================================================
-      // wave reduction of the 27 partial results -> stash row g (lane 63 writes)
+      // wave reduction of the 27 sums + peak -> stash row g
       // =====================================================================
       asm volatile("; MARK reduce");
       AMCX_STAMP(3);
       __builtin_amdgcn_sched_barrier(0);
-      // 26 sums: two swap levels (lane bits 5, 4) halve the live values each time --
+      // two swap levels (lane bits 5, 4) halve the live values each time --
       // v_permlane32_swap / v_permlane16_swap exchange half a register pair in one
       // instruction -- then four DPP steps inside the 16-lane rows.  70 VALU ops
-      // against 156 for 26 independent 6-step butterflies.
-      float r28[28] = {sA, sBh, sP, sAA, sBB, sAB, sAP, sBP, sAAA, sABB, sAAB, sBBB, sAAP, sBBP,
-                       sABP, sa, sad1, sad2, sad4, st1, st2, sabst, sw1, sw2, sw3, sw4, 0.f, 0.f};
+      // against 162 for 27 independent 6-step butterflies.
+      float r28[28] = {S.sA, S.sBh, S.sP, S.sAA, S.sBB, S.sAB, S.sAP, S.sBP, S.sAAA, S.sABB,
+                       S.sAAB, S.sBBB, S.sAAP, S.sBBP, S.sABP, S.sa, S.sad1, S.sad2, S.sad4,
+                       S.st1, S.st2, S.sab1, S.sab2, S.sw1, S.sw2, S.sw3, S.sw4, 0.f};
       // (inline asm: hipcc 7.2 folds the two results of __builtin_amdgcn_permlane*_swap
       //  into one register here -- "v_add v3, v142, v142" -- so the swaps are spelled
       //  out; one statement per level, opening with the two wait states a VALU
@@ -524,9 +606,10 @@ __global__ __launch_bounds__(kThreads, 3) void amcx_features18_wave_kernel(
           });
         }
         if (lane == 63) {
-          row[kNumSums - 1] = pk;                  // overwrites the zero pad slot 26
-          row[kNumSums] = Kt;
-          row[kNumSums + 1] = Kw;
+          row[kNumSums] = pk;                      // overwrites the zero pad slot 27
+          row[kNumSums + 1] = S.Kt;
+          row[kNumSums + 2] = S.Kw;
+          row[kNumSums + 3] = S.Ka;
         }
       }
     }
@@ -537,16 +620,16 @@ __global__ __launch_bounds__(kThreads, 3) void amcx_features18_wave_kernel(
     lds_wave_fence();
     if (lane < n_here) {
       const float* row = stash + lane * kStashStride;
-      FrameSums S;
-      S.sA = row[0]; S.sBh = row[1]; S.sP = row[2]; S.sAA = row[3]; S.sBB = row[4]; S.sAB = row[5];
-      S.sAP = row[6]; S.sBP = row[7]; S.sAAA = row[8]; S.sABB = row[9]; S.sAAB = row[10];
-      S.sBBB = row[11]; S.sAAP = row[12]; S.sBBP = row[13]; S.sABP = row[14];
-      S.sa = row[15]; S.sad1 = row[16]; S.sad2 = row[17]; S.sad4 = row[18];
-      S.std1 = row[19]; S.std2 = row[20]; S.sabst = row[21];
-      S.swd1 = row[22]; S.swd2 = row[23]; S.swd3 = row[24]; S.swd4 = row[25];
-      S.gmax_raw = row[26]; S.Kt = row[27]; S.Kw = row[28];
+      FrameSums F;
+      F.sA = row[0]; F.sBh = row[1]; F.sP = row[2]; F.sAA = row[3]; F.sBB = row[4]; F.sAB = row[5];
+      F.sAP = row[6]; F.sBP = row[7]; F.sAAA = row[8]; F.sABB = row[9]; F.sAAB = row[10];
+      F.sBBB = row[11]; F.sAAP = row[12]; F.sBBP = row[13]; F.sABP = row[14];
+      F.sa = row[15]; F.sad1 = row[16]; F.sad2 = row[17]; F.sad4 = row[18];
+      F.std1 = row[19]; F.std2 = row[20]; F.sab1 = row[21]; F.sab2 = row[22];
+      F.swd1 = row[23]; F.swd2 = row[24]; F.swd3 = row[25]; F.swd4 = row[26];
+      F.gmax_raw = row[27]; F.Kt = row[28]; F.Kw = row[29]; F.Ka = row[30];
       float feat[18];
-      finalize_features(S, N, feat);
+      finalize_features(F, N, feat);
       float* dst = out + (f0 + lane) * out_stride;
 #pragma unroll
       for (int j = 0; j < 18; ++j) dst[j] = feat[j];
@@ -565,29 +648,45 @@ __global__ __launch_bounds__(kThreads, 3) void amcx_features18_wave_kernel(
 
 }  // namespace wave
 
-inline bool wave_supports(int frame_size) { return frame_size == 2048; }
+inline bool wave_supports(int frame_size) {
+  return frame_size == 1024 || frame_size == 2048 || frame_size == 4096;
+}
 
 inline const char* wave_kernel_name(int frame_size) {
-  return frame_size == 2048 ? "amcx_features18_wave_kernel<2048>" : "";
+  switch (frame_size) {
+    case 1024: return "amcx_features18_wave_kernel<1024>";
+    case 2048: return "amcx_features18_wave_kernel<2048>";
+    case 4096: return "amcx_features18_wave_kernel<4096>";
+    default: return "";
+  }
 }
 
 #ifndef AMCX_WAVE_STAMPS
-inline hipError_t launch_wave(const float2* iq, int64_t n_frames, int32_t frame_size,
-                              int64_t row_stride, float* out, int64_t out_stride,
-                              hipStream_t stream, int cus) {
-  if (frame_size != 2048) return hipErrorNotSupported;
-  static const bool prefetch = getenv("AMCX_WAVE_PREFETCH") != nullptr;   // experiment switch
-  auto kern = prefetch ? wave::amcx_features18_wave_kernel<2048, true> : wave::amcx_features18_wave_kernel<2048, false>;
-  static_assert(wave::kLdsBytes <= 160 * 1024, "one workgroup per CU must fit in 160 KiB of LDS");
+template <int N>
+inline hipError_t launch_wave_n(const float2* iq, int64_t n_frames, int64_t row_stride, float* out,
+                                int64_t out_stride, hipStream_t stream, int cus) {
+  auto kern = wave::amcx_features18_wave_kernel<N>;
+  constexpr int lds = wave::Cfg<N>::kLdsBytes;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, wave::kLdsBytes);
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return e;
   const int64_t n_batches = (n_frames + wave::kFramesPerBatch - 1) / wave::kFramesPerBatch;
   int64_t grid = (int64_t)cus;                        // persistent: one resident workgroup per CU
   if (grid > n_batches) grid = n_batches;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(wave::kThreads), wave::kLdsBytes, stream, iq,
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(wave::kThreads), lds, stream, iq,
                      (long long)n_frames, (long long)row_stride, out, (long long)out_stride);
   return hipGetLastError();
+}
+
+inline hipError_t launch_wave(const float2* iq, int64_t n_frames, int32_t frame_size,
+                              int64_t row_stride, float* out, int64_t out_stride,
+                              hipStream_t stream, int cus) {
+  switch (frame_size) {
+    case 1024: return launch_wave_n<1024>(iq, n_frames, row_stride, out, out_stride, stream, cus);
+    case 2048: return launch_wave_n<2048>(iq, n_frames, row_stride, out, out_stride, stream, cus);
+    case 4096: return launch_wave_n<4096>(iq, n_frames, row_stride, out, out_stride, stream, cus);
+    default: return hipErrorNotSupported;
+  }
 }
 #endif
 

@@ -117,10 +117,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=N_FRAMES, help="frames per (mod, SNR) block")
     ap.add_argument("--variant", default="auto", choices=["auto", "block", "wave"])
+    ap.add_argument("--frame-size", type=int, default=FRAME_SIZE,
+                    help="samples per frame (the BASELINE metric is quoted at 2048; 1024/4096 are the other configs)")
     ap.add_argument("--no-cpu-baseline", action="store_true",
                     help="skip the host baseline (use under rocprofv3: no worker processes)")
     ap.add_argument("--cpu-procs", type=int, default=None)
     args = ap.parse_args()
+    FS = args.frame_size
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -149,9 +152,9 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # ---- resident shard: (mods, snr, frames, N) complex64 arena in HBM --------
-    arena = torch.empty((N_MODS, N_SNR, args.frames, FRAME_SIZE), dtype=torch.complex64, device=dev)
+    arena = torch.empty((N_MODS, N_SNR, args.frames, FS), dtype=torch.complex64, device=dev)
     for mi, mod in enumerate(synth.MODS6):
-        synth.device_frames(mod, N_SNR, args.frames, FRAME_SIZE, device=dev, rank=rank,
+        synth.device_frames(mod, N_SNR, args.frames, FS, device=dev, rank=rank,
                             mod_idx=mi, out=arena[mi])
     frames_per_launch = N_MODS * N_SNR * args.frames
     out = torch.empty((N_MODS, N_SNR, args.frames, 18), dtype=torch.float32, device=dev)
@@ -213,24 +216,25 @@ def main():
     total_frames = frames_per_launch * world * args.steps
     value = total_frames / wall
     mean_launch_s = sum(launch_ms) / len(launch_ms) * 1e-3
-    alg_bytes = (8 * FRAME_SIZE + 72) * frames_per_launch
+    alg_bytes = (8 * FS + 72) * frames_per_launch
     achieved = alg_bytes / mean_launch_s / 1e9
     rec = {
-        "metric": "IQ frames/sec (18 features, 2048-sample complex64)",
+        "metric": f"IQ frames/sec (18 features, {FS}-sample complex64)",
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": f"{N_MODS} mods x {N_SNR} SNR x {args.frames} frames x {FRAME_SIZE} samples "
+            "workload": f"{N_MODS} mods x {N_SNR} SNR x {args.frames} frames x {FS} samples "
                         f"complex64 per GPU (BASELINE configs[1]), resident in HBM; one launch per step",
-            "frames_per_gpu_per_step": frames_per_launch, "frame_size": FRAME_SIZE,
-            "kernel": _lib.kernel_name(FRAME_SIZE, _lib.VARIANTS[args.variant]),
+            "frames_per_gpu_per_step": frames_per_launch, "frame_size": FS,
+            "kernel": _lib.kernel_name(FS, _lib.VARIANTS[args.variant]),
             "sharding": f"frames x{world}, no collective on the data path",
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "traffic": _pmc_traffic(frames_per_launch),
+            "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": _pmc_traffic(frames_per_launch) if FS == FRAME_SIZE else None,
             "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_ms": mean_launch_s * 1e3,
             "measured_read_peak_GBps": read_peak,
         },

@@ -8,14 +8,15 @@
 #include <vector>
 #include <random>
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
-template <bool PF> void run(const float2* d_iq, long long F, float* d_out, unsigned long long* d_st, int grid) {
+template <int N> void run(const float2* d_iq, long long F, float* d_out, unsigned long long* d_st, int grid) {
   using namespace amcx::wave;
-  auto kern = amcx_features18_wave_kernel<2048, PF>;
+  auto kern = amcx_features18_wave_kernel<N>;
+  constexpr int kLdsBytes = Cfg<N>::kLdsBytes;
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
   hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
   for (int rep = 0; rep < 3; ++rep) {
     CHECK(hipEventRecord(e0));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), kLdsBytes, 0, d_iq, F, 2048LL, d_out, 18LL, d_st);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), kLdsBytes, 0, d_iq, F, (long long)N, d_out, 18LL, d_st);
     CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
   }
   float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -28,7 +29,7 @@ template <bool PF> void run(const float2* d_iq, long long F, float* d_out, unsig
   double real_us = s[6] / nw / 100.0; s[6] = 0;
   double tot = 0; for (double v : s) tot += v;
   double frames_per_wave = (double)F / nw;
-  printf("prefetch=%d  kernel %.3f ms  (%.1f M frames/s)  mean wave lifetime %.1f us -> s_memtime clock %.2f GHz; cycles per frame per wave: %.0f\n", (int)PF, ms, F / ms / 1e3, real_us, tot / nw / real_us / 1e3, tot / nw / frames_per_wave);
+  printf("N=%d  kernel %.3f ms  (%.1f M frames/s)  mean wave lifetime %.1f us -> s_memtime clock %.2f GHz; cycles per frame per wave: %.0f\n", N, ms, F / ms / 1e3, real_us, tot / nw / real_us / 1e3, tot / nw / frames_per_wave);
   for (int k = 0; k < kStampSections; ++k) if (s[k] > 0) printf("   %-20s %6.1f %%   %8.0f cycles/frame\n", names[k], 100.0 * s[k] / tot, s[k] / nw / frames_per_wave);
 }
 int main() {
@@ -38,9 +39,10 @@ int main() {
   for (long long i = 0; i < 2048LL * 4096; ++i) h[i] = make_float2(nd(rng), nd(rng));
   for (long long i = 2048LL * 4096; i < F * 2048; ++i) h[i] = h[i % (2048LL * 4096)];
   float2* d_iq; float* d_out; unsigned long long* d_st;
-  CHECK(hipMalloc(&d_iq, F * 2048 * 8)); CHECK(hipMalloc(&d_out, F * 18 * 4)); CHECK(hipMalloc(&d_st, 256 * 16 * 8 * 8));
+  CHECK(hipMalloc(&d_iq, F * 2048 * 8)); CHECK(hipMalloc(&d_out, 2 * F * 18 * 4)); CHECK(hipMalloc(&d_st, 256 * 16 * 8 * 8));
   CHECK(hipMemcpy(d_iq, h.data(), F * 2048 * 8, hipMemcpyHostToDevice));
-  run<false>(d_iq, F, d_out, d_st, 256);
-  run<true>(d_iq, F, d_out, d_st, 256);
+  run<2048>(d_iq, F, d_out, d_st, 256);
+  run<1024>(d_iq, F * 2, d_out, d_st, 256);
+  run<4096>(d_iq, F / 2, d_out, d_st, 256);
   return 0;
 }
