@@ -95,10 +95,11 @@ __global__ __launch_bounds__(kBlockThreads) void amcx_features18_block_kernel(
         const double A = re * re - im * im, Bh = re * im, P = re * re + im * im;
         const double AA = A * A, BB = Bh * Bh, AP = A * P;
         m[0] += A; m[1] += Bh; m[2] += P;
-        m[3] += AA; m[4] += BB; m[5] += A * Bh;
+        const double X4 = AA - 4.0 * BB;
+        m[3] += AA; m[4] += X4; m[5] += A * Bh;
         m[6] += AP; m[7] += Bh * P;
         m[8] += AA * A; m[9] += A * BB; m[10] += AA * Bh; m[11] += BB * Bh;
-        m[12] += AA * P; m[13] += BB * P; m[14] += AP * Bh;
+        m[12] += AA * P; m[13] += X4 * P; m[14] += AP * Bh;
         const float a = __builtin_amdgcn_sqrtf(__builtin_fmaf(x.x, x.x, __builtin_fmaf(x.y, x.y, kTinyPower)));
         const float th = fast_angle(x.x, x.y, a);
         at[n] = make_float2(a, th);
@@ -106,9 +107,9 @@ __global__ __launch_bounds__(kBlockThreads) void amcx_features18_block_kernel(
       }
       block_sum(m, scratch);
       block_sum(e, scratch);   // the barrier inside also publishes `at`
-      S.sA = m[0]; S.sBh = m[1]; S.sP = m[2]; S.sAA = m[3]; S.sBB = m[4]; S.sAB = m[5];
+      S.sA = m[0]; S.sBh = m[1]; S.sP = m[2]; S.sAA = m[3]; S.sX4 = m[4]; S.sAB = m[5];
       S.sAP = m[6]; S.sBP = m[7]; S.sAAA = m[8]; S.sABB = m[9]; S.sAAB = m[10]; S.sBBB = m[11];
-      S.sAAP = m[12]; S.sBBP = m[13]; S.sABP = m[14];
+      S.sAAP = m[12]; S.sX4P = m[13]; S.sABP = m[14];
       S.sa = e[0]; S.Kt = e[1] / N; S.Ka = e[2] / N;
     }
     // ---- pass B: centred envelope / phase sums, first sum of the steps ---

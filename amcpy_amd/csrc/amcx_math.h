@@ -65,14 +65,17 @@ __device__ __forceinline__ float wrapped_step(float th_next, float th) {
 // ---------------------------------------------------------------------------
 // Reduced per-frame sums, everything the 18 features need.
 // A = re^2 - im^2, Bh = re*im (so x^2 = A + 2i*Bh), P = re^2 + im^2.
+// Re(x^4) = A^2 - 4 Bh^2 is summed as such, not as two large positive sums that
+// cancel: for noise-like frames m40 and m61 are near zero and would otherwise
+// inherit the rounding of sums the size of m42 / m63.
 // ---------------------------------------------------------------------------
 struct FrameSums {
   // mixed-moment sums over the N samples
   double sA, sBh, sP;            // -> m20, m21
-  double sAA, sBB, sAB;          // A^2, Bh^2, A*Bh          -> m40, m42
+  double sAA, sX4, sAB;          // A^2, A^2 - 4 Bh^2 (= Re x^4), A*Bh -> m40, m42
   double sAP, sBP;               // A*P, Bh*P                -> m41
   double sAAA, sABB, sAAB, sBBB; // A^3, A*Bh^2, A^2*Bh, Bh^3 -> m60, m62
-  double sAAP, sBBP, sABP;       // A^2*P, Bh^2*P, A*Bh*P    -> m61, m63
+  double sAAP, sX4P, sABP;       // A^2*P, Re(x^4)*P, A*Bh*P  -> m61, m63
   // envelope a = |x| : exact mean, then centred sums about it
   double sa;                     // sum a
   double sad1, sad2, sad4;       // sum |a-mu|, (a-mu)^2, (a-mu)^4
@@ -152,14 +155,14 @@ __device__ inline void finalize_features(const FrameSums& s, int N, float* __res
   }
   const double m20r = s.sA * inv, m20i = 2.0 * s.sBh * inv;
   const double m21 = s.sP * inv;
-  const double m40r = (s.sAA - 4.0 * s.sBB) * inv, m40i = 4.0 * s.sAB * inv;
+  const double m40r = s.sX4 * inv, m40i = 4.0 * s.sAB * inv;
   const double m41r = s.sAP * inv, m41i = 2.0 * s.sBP * inv;
-  const double m42 = (s.sAA + 4.0 * s.sBB) * inv;                     // mean P^2
+  const double m42 = (2.0 * s.sAA - s.sX4) * inv;                     // mean P^2 = A^2 + 4 Bh^2
   const double m60r = (s.sAAA - 12.0 * s.sABB) * inv;                 // Re (A+iB)^3, B = 2Bh
   const double m60i = (6.0 * s.sAAB - 8.0 * s.sBBB) * inv;
-  const double m61r = (s.sAAP - 4.0 * s.sBBP) * inv, m61i = 4.0 * s.sABP * inv;
+  const double m61r = s.sX4P * inv, m61i = 4.0 * s.sABP * inv;
   const double m62 = (s.sAAA + 4.0 * s.sABB) * inv;                   // mean A*P^2 (real only)
-  const double m63 = (s.sAAP + 4.0 * s.sBBP) * inv;                   // mean P^3
+  const double m63 = (2.0 * s.sAAP - s.sX4P) * inv;                   // mean P^3
   // m22 = conj(m20), m43 = conj(m41)
 
   auto cabs = [](double r, double i) { return __builtin_sqrt(r * r + i * i); };

@@ -213,8 +213,8 @@ constexpr int kStampSections = 8;
 // Per-lane running sums of the statistics sweep (27 values + the three shifts)
 // ---------------------------------------------------------------------------
 struct Stats {
-  float sA = 0, sBh = 0, sP = 0, sAA = 0, sBB = 0, sAB = 0, sAP = 0, sBP = 0;
-  float sAAA = 0, sABB = 0, sAAB = 0, sBBB = 0, sAAP = 0, sBBP = 0, sABP = 0;
+  float sA = 0, sBh = 0, sP = 0, sAA = 0, sX4 = 0, sAB = 0, sAP = 0, sBP = 0;
+  float sAAA = 0, sABB = 0, sAAB = 0, sBBB = 0, sAAP = 0, sX4P = 0, sABP = 0;
   float sa = 0, st1 = 0, st2 = 0, sab1 = 0, sab2 = 0, sw1 = 0, sw2 = 0, sw3 = 0, sw4 = 0;
   float sad1 = 0, sad2 = 0, sad4 = 0;
   float Kt = 0, Kw = 0, Ka = 0;
@@ -243,7 +243,8 @@ struct Stats {
       const float A = __builtin_fmaf(re, re, -q);
       const float Bh = re * im;
       const float AA = A * A, BB = Bh * Bh, AP = A * P;
-      sA += A; sBh += Bh; sP += P; sAA += AA; sBB += BB; sAP += AP;
+      const float X4 = __builtin_fmaf(-4.0f, BB, AA);       // Re x^4, summed as such (amcx_math.h)
+      sA += A; sBh += Bh; sP += P; sAA += AA; sX4 += X4; sAP += AP;
       sAB = __builtin_fmaf(A, Bh, sAB);
       sBP = __builtin_fmaf(Bh, P, sBP);
       sAAA = __builtin_fmaf(AA, A, sAAA);
@@ -251,7 +252,7 @@ struct Stats {
       sAAB = __builtin_fmaf(AA, Bh, sAAB);
       sBBB = __builtin_fmaf(BB, Bh, sBBB);
       sAAP = __builtin_fmaf(AA, P, sAAP);
-      sBBP = __builtin_fmaf(BB, P, sBBP);
+      sX4P = __builtin_fmaf(X4, P, sX4P);
       sABP = __builtin_fmaf(AP, Bh, sABP);
       av[b] = __builtin_amdgcn_sqrtf(P);
       sa += av[b];
@@ -547,8 +548,8 @@ __global__ __launch_bounds__(kThreads, 3) void amcx_features18_wave_kernel(
       // v_permlane32_swap / v_permlane16_swap exchange half a register pair in one
       // instruction -- then four DPP steps inside the 16-lane rows.  70 VALU ops
       // against 162 for 27 independent 6-step butterflies.
-      float r28[28] = {S.sA, S.sBh, S.sP, S.sAA, S.sBB, S.sAB, S.sAP, S.sBP, S.sAAA, S.sABB,
-                       S.sAAB, S.sBBB, S.sAAP, S.sBBP, S.sABP, S.sa, S.sad1, S.sad2, S.sad4,
+      float r28[28] = {S.sA, S.sBh, S.sP, S.sAA, S.sX4, S.sAB, S.sAP, S.sBP, S.sAAA, S.sABB,
+                       S.sAAB, S.sBBB, S.sAAP, S.sX4P, S.sABP, S.sa, S.sad1, S.sad2, S.sad4,
                        S.st1, S.st2, S.sab1, S.sab2, S.sw1, S.sw2, S.sw3, S.sw4, 0.f};
       // (inline asm: hipcc 7.2 folds the two results of __builtin_amdgcn_permlane*_swap
       //  into one register here -- "v_add v3, v142, v142" -- so the swaps are spelled
@@ -621,9 +622,9 @@ __global__ __launch_bounds__(kThreads, 3) void amcx_features18_wave_kernel(
     if (lane < n_here) {
       const float* row = stash + lane * kStashStride;
       FrameSums F;
-      F.sA = row[0]; F.sBh = row[1]; F.sP = row[2]; F.sAA = row[3]; F.sBB = row[4]; F.sAB = row[5];
+      F.sA = row[0]; F.sBh = row[1]; F.sP = row[2]; F.sAA = row[3]; F.sX4 = row[4]; F.sAB = row[5];
       F.sAP = row[6]; F.sBP = row[7]; F.sAAA = row[8]; F.sABB = row[9]; F.sAAB = row[10];
-      F.sBBB = row[11]; F.sAAP = row[12]; F.sBBP = row[13]; F.sABP = row[14];
+      F.sBBB = row[11]; F.sAAP = row[12]; F.sX4P = row[13]; F.sABP = row[14];
       F.sa = row[15]; F.sad1 = row[16]; F.sad2 = row[17]; F.sad4 = row[18];
       F.std1 = row[19]; F.std2 = row[20]; F.sab1 = row[21]; F.sab2 = row[22];
       F.swd1 = row[23]; F.swd2 = row[24]; F.swd3 = row[25]; F.swd4 = row[26];
