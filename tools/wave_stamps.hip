@@ -27,13 +27,15 @@ template <int N> void run(const float2* d_iq, long long F, float* d_out, unsigne
   for (int w = 0; w < nw; ++w) for (int k = 0; k < kStampSections; ++k) s[k] += (double)h[w * kStampSections + k];
   const char* names[kStampSections] = {"load+stats sweep", "envelope sweep", "fft pass1+xchg1", "fft pass2/3+xchg2", "reduce(last of batch)", "finalize(batch)", "-", "reduce+stash+loop"};
   double real_us = s[6] / nw / 100.0; s[6] = 0;
+  { double mn = 1e30, mx = 0; for (int w = 0; w < nw; ++w) { double v = (double)h[w * kStampSections + 6] / 100.0; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+    printf("   wave lifetime us: min %.1f  mean %.1f  max %.1f   (kernel %.1f)\n", mn, real_us, mx, ms * 1e3); }
   double tot = 0; for (double v : s) tot += v;
   double frames_per_wave = (double)F / nw;
   printf("N=%d  kernel %.3f ms  (%.1f M frames/s)  mean wave lifetime %.1f us -> s_memtime clock %.2f GHz; cycles per frame per wave: %.0f\n", N, ms, F / ms / 1e3, real_us, tot / nw / real_us / 1e3, tot / nw / frames_per_wave);
   for (int k = 0; k < kStampSections; ++k) if (s[k] > 0) printf("   %-20s %6.1f %%   %8.0f cycles/frame\n", names[k], 100.0 * s[k] / tot, s[k] / nw / frames_per_wave);
 }
 int main() {
-  const long long F = 6 * 26 * 4096 / 4;   // 159744 frames, 2.6 GB
+  const long long F = 6 * 26 * 4096 / 2;   // 319488 frames, 5.2 GB
   std::vector<float2> h(F * 2048);
   std::mt19937 rng(1); std::normal_distribution<float> nd(0.f, 1.f);
   for (long long i = 0; i < 2048LL * 4096; ++i) h[i] = make_float2(nd(rng), nd(rng));
