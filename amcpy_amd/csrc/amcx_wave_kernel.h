@@ -53,13 +53,10 @@
 namespace amcx {
 namespace wave {
 
-constexpr int kWavesPerWG = 12;
-constexpr int kThreads = 64 * kWavesPerWG;
 constexpr int kFramesPerWave = 8;               // frames per wave per batch (finalised together)
 constexpr int kTailChunk = 2;                   // frames per grab over the last stretch of a workgroup's slice
-constexpr int kTailFrames = kWavesPerWG * kFramesPerWave;
 constexpr int kNumSums = 27;                    // reduced per-lane sums; the spectral peak rides in slot 27
-constexpr int kStashStride = 33;                // floats; odd -> conflict-free column reads
+constexpr int kStashStride = 31;                // floats used per frame; odd -> conflict-free column reads
 constexpr int kStashBytes = kFramesPerWave * kStashStride * 4;
 
 constexpr int kEx1StrideKK = 136, kEx1StrideB = 68;   // complex units (tools/wave_fft_model.py)
@@ -71,6 +68,10 @@ template <int N>
 struct Cfg {
   static_assert(N == 1024 || N == 2048 || N == 4096, "wave kernel frame sizes");
   static constexpr bool kSplit = N == 4096;            // radix-2 DIF split in front of a 2048 FFT
+  // waves per workgroup = waves per CU: 3 per SIMD at 161-168 VGPRs
+  static constexpr int kWavesPerWG = 12;   // (16 waves at N = 1024, 114 VGPRs, measured no faster: power-bound)
+  static constexpr int kThreads = 64 * kWavesPerWG;
+  static constexpr int kTailFrames = kWavesPerWG * kFramesPerWave;
   static constexpr int kRows = N / 128;                // rows of 128 samples per frame
   static constexpr int kFftRows = kSplit ? 16 : kRows; // R: rows one register FFT holds
   static constexpr int kFftN = 128 * kFftRows;
@@ -400,11 +401,12 @@ __device__ __forceinline__ float fft_peak(const float (&xr)[2 * R], const float 
 
 // ---------------------------------------------------------------------------
 template <int N>
-__global__ __launch_bounds__(kThreads, 3) void amcx_features18_wave_kernel(
+__global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amcx_features18_wave_kernel(
     const float2* __restrict__ iq, long long n_frames, long long row_stride,
     float* __restrict__ out, long long out_stride AMCX_STAMP_ARG) {
   using C = Cfg<N>;
   constexpr int R = C::kFftRows;
+  constexpr int kWavesPerWG = C::kWavesPerWG, kThreads = C::kThreads, kTailFrames = C::kTailFrames;
   extern __shared__ float4 amcx_wave_smem[];
   char* smem = reinterpret_cast<char*>(amcx_wave_smem);
   const int tid = threadIdx.x;
@@ -505,7 +507,10 @@ __global__ __launch_bounds__(kThreads, 3) void amcx_features18_wave_kernel(
       float xr[2 * R], xi[2 * R];
       static_for<R>([&](auto ii) {
         constexpr int i = decltype(ii)::value;
-        const float4 v = *reinterpret_cast<const float4*>(src + 128 * i);
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f* p = reinterpret_cast<const v4f*>(src + 128 * i);
+        // read once -> non-temporal, except at N = 4096 where both halves are read again
+        const v4f v = C::kSplit ? *p : __builtin_nontemporal_load(p);
         xr[2 * i] = v.x; xi[2 * i] = v.y; xr[2 * i + 1] = v.z; xi[2 * i + 1] = v.w;
       });
 
@@ -710,9 +715,9 @@ inline hipError_t launch_wave_n(const float2* iq, int64_t n_frames, int64_t row_
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return e;
   int64_t grid = (int64_t)cus;                        // persistent: one resident workgroup per CU
-  const int64_t min_slice = wave::kWavesPerWG;        // at least a frame per wave
+  const int64_t min_slice = wave::Cfg<N>::kWavesPerWG;   // at least a frame per wave
   if (grid * min_slice > n_frames) grid = (n_frames + min_slice - 1) / min_slice;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(wave::kThreads), lds, stream, iq,
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(wave::Cfg<N>::kThreads), lds, stream, iq,
                      (long long)n_frames, (long long)row_stride, out, (long long)out_stride);
   return hipGetLastError();
 }

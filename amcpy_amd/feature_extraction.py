@@ -42,18 +42,55 @@ def _rank_world():
     return 0, 1
 
 
-def _hip_compute(frame_size: int, device: Optional[int]) -> Callable[[np.ndarray], np.ndarray]:
-    """(F, L) complex numpy -> (F, 18) float32 through device memory."""
+def _hip_compute(frame_size: int, device: Optional[int], chunk_bytes: int = 1 << 30
+                 ) -> Callable[[np.ndarray], np.ndarray]:
+    """(F, L) complex numpy -> (F, 18) float32 through device memory.
+
+    Frames go up in chunks of about ``chunk_bytes`` through a pinned staging
+    buffer; a complex128 container (MATLAB doubles) is uploaded as is and
+    rounded to complex64 on the GPU (torch cast: plumbing, PCIe is ~20x faster
+    than a host-side ``astype``), and the copy of chunk k+1 overlaps the kernel
+    on chunk k (separate copy stream)."""
     import torch
     from .features import features18
 
     dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
 
     def compute(block: np.ndarray) -> np.ndarray:
-        x = np.ascontiguousarray(block[:, :frame_size], dtype=np.complex64)   # MATLAB doubles -> c64
-        xd = torch.from_numpy(x).to(dev, non_blocking=False)
-        y = features18(xd)
-        return y.cpu().numpy()
+        F = block.shape[0]
+        out = torch.empty((F, 18), dtype=torch.float32, device=dev)
+        if F == 0:
+            return out.cpu().numpy()
+        src = block[:, :frame_size]
+        if not np.iscomplexobj(src):
+            src = src.astype(np.complex64)
+        if src.dtype not in (np.complex64, np.complex128):
+            src = src.astype(np.complex128)
+        per = max(1, chunk_bytes // (frame_size * src.dtype.itemsize))
+        copy_stream = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        pending = None          # (device tensor, event, f0, f1)
+        for f0 in range(0, F, per):
+            f1 = min(F, f0 + per)
+            host = torch.from_numpy(np.ascontiguousarray(src[f0:f1])).pin_memory()
+            with torch.cuda.stream(copy_stream):
+                xd = host.to(dev, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(copy_stream)
+            if pending is not None:
+                _launch(pending, out, main)
+            pending = (xd, ev, f0, f1, host)
+        _launch(pending, out, main)
+        torch.cuda.synchronize(dev)
+        return out.cpu().numpy()
+
+    def _launch(item, out, main):
+        xd, ev, f0, f1, _host = item
+        main.wait_event(ev)
+        if xd.dtype != torch.complex64:
+            xd = xd.to(torch.complex64)
+        features18(xd, out=out[f0:f1])
+        xd.record_stream(main)
 
     return compute
 

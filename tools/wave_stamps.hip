@@ -16,10 +16,11 @@ template <int N> void run(const float2* d_iq, long long F, float* d_out, unsigne
   hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
   for (int rep = 0; rep < 3; ++rep) {
     CHECK(hipEventRecord(e0));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), kLdsBytes, 0, d_iq, F, (long long)N, d_out, 18LL, d_st);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg<N>::kThreads), kLdsBytes, 0, d_iq, F, (long long)N, d_out, 18LL, d_st);
     CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
   }
   float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+  constexpr int kWavesPerWG = Cfg<N>::kWavesPerWG;
   int nw = grid * kWavesPerWG;
   std::vector<unsigned long long> h(nw * kStampSections);
   CHECK(hipMemcpy(h.data(), d_st, h.size() * 8, hipMemcpyDeviceToHost));
