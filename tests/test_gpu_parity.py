@@ -285,3 +285,47 @@ def test_run_extraction_roundtrip_on_gpu(tmp_path):
         x = g[f"in_{m}"][:, :, :fs].reshape(-1, fs)
         _assert_parity(arr.reshape(-1, 18), g[f"out_{m}"].reshape(-1, 18).astype(np.float64), x,
                        f"run_extraction {m}")
+
+
+def test_odd_row_stride_and_ragged_counts():
+    """Rows that start on 8-byte (not 16-byte) boundaries and frame counts that
+    are not a multiple of any chunk size: every frame must still be computed once,
+    by both kernels, with identical results to the packed layout."""
+    torch = _torch()
+    from amcpy_amd.features import features18
+    rng = np.random.default_rng(11)
+    for N, F in ((1024, 1237), (2048, 611), (4096, 205)):
+        L = N + 3                                             # odd stride: frames 8-byte aligned only
+        x = (rng.standard_normal((F, L)) + 1j * rng.standard_normal((F, L))).astype(np.complex64)
+        xd = torch.from_numpy(x).cuda()
+        y_strided = features18(xd, frame_size=N, variant="wave").cpu().numpy()
+        y_packed = features18(xd[:, :N].contiguous(), variant="wave").cpu().numpy()
+        assert np.array_equal(y_strided, y_packed), N
+        y_block = features18(xd, frame_size=N, variant="block").cpu().numpy()
+        S = orc.conditioning_scales(x[:, :N])
+        _, scaled = orc.parity_errors(y_strided, y_block, S)
+        assert scaled.max() <= TOL, (N, scaled.max(axis=0))
+        assert np.isfinite(y_strided).all()
+
+
+def test_concurrent_streams_are_independent():
+    """The library keeps no global mutable state: launches on two streams with
+    different inputs give the same answers as serial launches."""
+    torch = _torch()
+    from amcpy_amd.features import features18
+    from amcpy_amd import synth
+    a = torch.from_numpy(synth.host_block("8PSK", 5.0, 3000, 2048, seed=31)).cuda()
+    b = torch.from_numpy(synth.host_block("64QAM", 15.0, 3000, 2048, seed=32)).cuda()
+    ya, yb = features18(a), features18(b)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for _ in range(3):
+        with torch.cuda.stream(s1):
+            oa = features18(a)
+        with torch.cuda.stream(s2):
+            ob = features18(b)
+        outs.append((oa, ob))
+    torch.cuda.synchronize()
+    for oa, ob in outs:
+        assert torch.equal(oa, ya) and torch.equal(ob, yb)
