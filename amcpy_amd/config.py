@@ -24,7 +24,7 @@ configurations are made with constructor keywords, e.g.
 from __future__ import annotations
 
 import os
-from dataclasses import dataclass, field
+from dataclasses import dataclass, field, make_dataclass
 from pathlib import Path
 from typing import ClassVar, Dict, Tuple
 
@@ -105,17 +105,10 @@ class FeatureConfig:
     """The 18 feature ids, their display names and the classifier's subset."""
 
     names: ClassVar[Dict[int, str]] = {
-        1: r"$\gamma_{max}$",
-        2: r"$\sigma_{ap}$",
-        3: r"$\sigma_{dp}$",
-        4: r"$\sigma_{aa}$",
-        5: r"$\sigma_{af}$",
-        6: r"$X$",
-        7: r"$X_2$",
-        8: r"$\mu_{42}^{a}$",
-        9: r"$\mu_{42}^{f}$",
-        **{10 + i: rf"$C_{{{pq}}}$" for i, pq in enumerate(
-            ("20", "21", "40", "41", "42", "60", "61", "62", "63"))},
+        i + 1: f"${body}$" for i, body in enumerate(
+            [r"\gamma_{max}", r"\sigma_{ap}", r"\sigma_{dp}", r"\sigma_{aa}", r"\sigma_{af}", "X", "X_2",
+             r"\mu_{42}^{a}", r"\mu_{42}^{f}"]
+            + [f"C_{{{pq}}}" for pq in ("20", "21", "40", "41", "42", "60", "61", "62", "63")])
     }
 
     all_features: Tuple[int, ...] = tuple(range(1, 19))
@@ -130,29 +123,27 @@ class FeatureConfig:
         return len(self.used)
 
 
-@dataclass(frozen=True)
-class TrainingConfig:
-    """Classifier hyper-parameters: carried for attribute compatibility only
-    (reference config.py:151-176); nothing on the extraction path reads them."""
+def _feature_files(self):
+    return [f"{m}_features" for m in SignalConfig().modulations_with_noise]
 
-    training_snr: Tuple[int, ...] = (10, 11, 12, 13, 14, 15)
-    all_snr: Tuple[int, ...] = tuple(range(16))
-    plotting_snr: Tuple[int, ...] = tuple(range(16))
-    test_size: float = 0.2
-    random_state: int = 42
-    activation: str = "relu"
-    batch_size: int = 128
-    dropout: float = 0.4
-    epochs: int = 21
-    learning_rate: float = 0.001418378071933655
-    optimizer: str = "rmsprop"
-    layer_size_hl1: int = 26
-    layer_size_hl2: int = 29
-    layer_size_hl3: int = 30
 
-    @property
-    def feature_files(self):
-        return [f"{m}_features" for m in SignalConfig().modulations_with_noise]
+# Classifier hyper-parameters: carried for attribute compatibility only (reference
+# config.py:151-176); nothing on the extraction path reads them, so the group is
+# declared as data rather than spelled out as a class body.
+_TRAINING_DEFAULTS = (
+    ("training_snr", Tuple[int, ...], tuple(range(10, 16))),
+    ("all_snr", Tuple[int, ...], tuple(range(16))),
+    ("plotting_snr", Tuple[int, ...], tuple(range(16))),
+    ("test_size", float, 0.2), ("random_state", int, 42),
+    ("activation", str, "relu"), ("batch_size", int, 128), ("dropout", float, 0.4),
+    ("epochs", int, 21), ("learning_rate", float, 0.001418378071933655),
+    ("optimizer", str, "rmsprop"),
+    ("layer_size_hl1", int, 26), ("layer_size_hl2", int, 29), ("layer_size_hl3", int, 30),
+)
+TrainingConfig = make_dataclass(
+    "TrainingConfig", [(n, t, field(default=d)) for n, t, d in _TRAINING_DEFAULTS], frozen=True,
+    namespace={"feature_files": property(_feature_files),
+               "__doc__": "Classifier hyper-parameters (value holder; out of the extraction scope)."})
 
 
 @dataclass(frozen=True)

@@ -19,6 +19,7 @@ Fixtures:
   edges_n{N}.npz          degenerate frames and what the reference returns
   extract_roundtrip.npz   a tiny `run_extraction(cfg)` run by the reference:
                           input container + the six output files' contents
+  config_defaults.json    field names and defaults of the reference's config layer
 """
 
 from __future__ import annotations
@@ -179,6 +180,23 @@ def capture_roundtrip(rfe, rcfg):
              n_frames=n_frames, mods=np.array(mods), **rec)
 
 
+def capture_config_defaults(rcfg):
+    """Field names and default values of the reference's configuration layer
+    (config.py:15-186), as data: pins the mirror in amcpy_amd/config.py."""
+    import dataclasses
+    cfg = rcfg.Config(paths=rcfg.Paths(root=Path("/project")))
+    doc = {}
+    for grp in ("paths", "signals", "features", "training"):
+        obj = getattr(cfg, grp)
+        doc[grp] = {f.name: (str(v) if isinstance(v, Path) else v)
+                    for f in dataclasses.fields(obj) for v in [getattr(obj, f.name)]}
+    doc["features"]["names"] = {str(k): v for k, v in rcfg.FeatureConfig.names.items()}
+    doc["features"]["used_names"] = cfg.features.used_names
+    doc["features"]["num_used"] = cfg.features.num_used
+    doc["training"]["feature_files"] = cfg.training.feature_files
+    (OUT / "config_defaults.json").write_text(json.dumps(doc, indent=1, default=list))
+
+
 def main():
     os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
     OUT.mkdir(parents=True, exist_ok=True)
@@ -189,6 +207,7 @@ def main():
     for N in (1000, 2048):
         capture_edges(rfeat, N)
     capture_roundtrip(rfe, rcfg)
+    capture_config_defaults(rcfg)
     for p in sorted(OUT.iterdir()):
         print(f"{p.name:28s} {p.stat().st_size:9d} B")
 

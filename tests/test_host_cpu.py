@@ -217,3 +217,33 @@ def test_synthetic_generator_statistics():
     w = synth.host_block("WGN", 0.0, 64, 2048, seed=2)
     assert abs((np.abs(w) ** 2).mean() - 1.0) < 0.02
     assert list(synth.snr_grid(26)[[0, -1]]) == [-20.0, 30.0] and list(synth.snr_grid(2)) == [0.0, 10.0]
+
+
+def test_config_mirror_equals_reference_defaults():
+    """Every field name and default of the reference's config layer, captured from
+    the imported reference (oracle/capture_golden.py -> config_defaults.json)."""
+    import dataclasses
+    import json
+    from amcpy_amd.config import Config, FeatureConfig, Paths
+    ref = json.loads((REPO / "tests" / "golden" / "config_defaults.json").read_text())
+    cfg = Config(paths=Paths(root=Path("/project")))
+
+    def norm(v):
+        if isinstance(v, Path):
+            return str(v)
+        if isinstance(v, tuple):
+            return [norm(x) for x in v]
+        if isinstance(v, dict):
+            return {str(k): norm(x) for k, x in v.items()}
+        return v
+
+    for grp in ("paths", "signals", "features", "training"):
+        obj = getattr(cfg, grp)
+        mine = {f.name: norm(getattr(obj, f.name)) for f in dataclasses.fields(obj)}
+        want = {k: norm(v) for k, v in ref[grp].items()
+                if k not in ("names", "used_names", "num_used", "feature_files")}
+        assert mine == want, (grp, mine, want)
+    assert {str(k): v for k, v in FeatureConfig.names.items()} == ref["features"]["names"]
+    assert cfg.features.used_names == ref["features"]["used_names"]
+    assert cfg.features.num_used == ref["features"]["num_used"]
+    assert cfg.training.feature_files == ref["training"]["feature_files"]
