@@ -8,6 +8,7 @@
 
 #include "amcx_block_kernel.h"
 #include "amcx_wave_kernel.h"
+#include "amcx_tie_fix_kernel.h"
 
 namespace {
 
@@ -137,6 +138,10 @@ int amcx_features18_c64_ex(const void* iq_dev, int64_t n_frames, int32_t frame_s
     hipError_t e = amcx::launch_wave(iq, n_frames, frame_size, row_stride_elems, out_dev,
                                      out_row_stride, stream, cu_count());
     if (e != hipSuccess) return hip_fail(e, "wave kernel launch");
+    // frames with a phase step within one angle rounding of +-pi: exact f5/f9 (amcx_tie_fix_kernel.h)
+    e = amcx::launch_tie_fix(iq, n_frames, frame_size, row_stride_elems, out_dev, out_row_stride, stream,
+                             cu_count());
+    if (e != hipSuccess) return hip_fail(e, "tie-fix kernel launch");
     return AMCX_OK;
   }
   return launch_block(iq, n_frames, frame_size, row_stride_elems, out_dev, out_row_stride, stream);

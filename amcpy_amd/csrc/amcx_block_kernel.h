@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kBlockThreads) void amcx_features18_block_kernel(
         c[3] += dt; c[4] += dt * dt;
         const double da = __builtin_fabs((double)v.y) - S.Ka;
         c[6] += da; c[7] += da * da;
-        if (n + 1 < N) c[5] += wrapped_step(at[n + 1].y, v.y);
+        if (n + 1 < N) c[5] += exact_step(at[n + 1].y, v.y, xs[n].x, xs[n].y, xs[n + 1].x, xs[n + 1].y);
       }
       block_sum(c, scratch);
       S.sad1 = c[0]; S.sad2 = c[1]; S.sad4 = c[2]; S.std1 = c[3]; S.std2 = c[4];
@@ -135,7 +135,8 @@ __global__ __launch_bounds__(kBlockThreads) void amcx_features18_block_kernel(
     {
       double c[4] = {0, 0, 0, 0};
       for (int n = tid; n + 1 < N; n += kBlockThreads) {
-        const double d = (double)wrapped_step(at[n + 1].y, at[n].y) - S.Kw, d2 = d * d;
+        const double d = (double)exact_step(at[n + 1].y, at[n].y, xs[n].x, xs[n].y, xs[n + 1].x, xs[n + 1].y) - S.Kw,
+                     d2 = d * d;
         c[0] += d; c[1] += d2; c[2] += d2 * d; c[3] += d2 * d2;
       }
       block_sum(c, scratch);   // trailing barrier: `at` may now be overwritten

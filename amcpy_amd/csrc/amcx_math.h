@@ -62,6 +62,29 @@ __device__ __forceinline__ float wrapped_step(float th_next, float th) {
   return __builtin_fmaf(-kTwoPi, k, d);
 }
 
+// |step| > pi - kTieBand: rounding of the two fp32 angles (<= 1e-6 together) may
+// have decided the sign of the wrapped step.  The fp64 reference resolves such a
+// step from the 17th digit; the throughput kernel only FLAGS the frame (it stores
+// -f5, and f5 >= 0) and amcx_step_tie_fix_kernel recomputes f5/f9 of flagged frames
+// with exact_step below.  About 1 frame in 400 is flagged at low SNR; every frame
+// of noiseless axis-aligned data is.
+constexpr float kTieBand = 2.0e-6f;
+
+// Wrapped step p -> q with an exact tie decision: sign(sin(step)) = sign(Re p Im q -
+// Im p Re q), the cross product evaluated with two error-free products, so the
+// decision matches the fp64 reference down to ~1e-14 rad; an exact zero
+// (antiparallel samples) follows numpy's unwrap rule, the sign of the raw difference.
+__device__ __forceinline__ float exact_step(float th_q, float th_p, float re_p, float im_p,
+                                            float re_q, float im_q) {
+  const float w = wrapped_step(th_q, th_p);
+  if (!(__builtin_fabsf(w) > kPi - kTieBand)) return w;
+  const float p1 = re_p * im_q, p2 = im_p * re_q;
+  const float e1 = __builtin_fmaf(re_p, im_q, -p1), e2 = __builtin_fmaf(im_p, re_q, -p2);
+  const float c = (p1 - p2) + (e1 - e2);
+  const float sgn = (c != 0.f) ? c : (th_q - th_p);
+  return __builtin_copysignf(__builtin_fabsf(w), sgn);
+}
+
 // ---------------------------------------------------------------------------
 // Reduced per-frame sums, everything the 18 features need.
 // A = re^2 - im^2, Bh = re*im (so x^2 = A + 2i*Bh), P = re^2 + im^2.
@@ -84,8 +107,25 @@ struct FrameSums {
   double Ka, sab1, sab2;         // |theta| shifted by Ka: sum e, sum e^2 with e = |theta| - Ka
   // wrapped phase step w (N-1 values), shifted by Kw: d = w - Kw
   double Kw, swd1, swd2, swd3, swd4;
+  bool pi_tie = false;           // some step within kTieBand of +-pi: f5 is stored negated as the flag
   double gmax_raw;               // max_k |X_k|^2 (unnormalised FFT)
 };
+
+// f5 = std1(phi), f9 = kurt(phi) of phi = w / 2pi from sums of d = w - Kw over the N-1 steps
+__device__ inline void frequency_features(double Kw, double swd1, double swd2, double swd3, double swd4,
+                                          int N, float& f5, float& f9) {
+  const double n1 = (double)N - 1.0, inv1 = 1.0 / n1;
+  const double d1 = swd1 * inv1;                        // mean of shifted w
+  const double r2 = swd2 * inv1, r3 = swd3 * inv1, r4 = swd4 * inv1;
+  double c2 = r2 - d1 * d1;                             // central moments of w
+  if (c2 < 0) c2 = 0;
+  const double c4 = r4 - 4.0 * d1 * r3 + 6.0 * d1 * d1 * r2 - 3.0 * d1 * d1 * d1 * d1;
+  f5 = (float)(__builtin_sqrt(c2 * n1 / (n1 - 1.0)) / kTwoPiD);
+  const double wbar = (Kw + d1) / kTwoPiD;              // mean phi, for scipy's rule
+  const double m2phi = c2 / (kTwoPiD * kTwoPiD);
+  const double eps_mean = 2.220446049250313e-16 * wbar;
+  f9 = (m2phi <= eps_mean * eps_mean) ? __builtin_nanf("") : (float)(c4 / (c2 * c2));
+}
 
 // All 18 features from the sums, fp64 (the reference evaluates in fp64 and
 // stores float32: feature_extraction.py:35,56).  Formulas: features.py:66-185;
@@ -133,19 +173,9 @@ __device__ inline void finalize_features(const FrameSums& s, int N, float* __res
   }
 
   // ---- frequency phi = w / 2pi over N-1 values: f5, f9
-  {
-    const double n1 = n - 1.0, inv1 = 1.0 / n1;
-    const double d1 = s.swd1 * inv1;                    // mean of shifted w
-    const double r2 = s.swd2 * inv1, r3 = s.swd3 * inv1, r4 = s.swd4 * inv1;
-    double c2 = r2 - d1 * d1;                           // central moments of w
-    if (c2 < 0) c2 = 0;
-    const double c4 = r4 - 4.0 * d1 * r3 + 6.0 * d1 * d1 * r2 - 3.0 * d1 * d1 * d1 * d1;
-    out[4] = (float)(__builtin_sqrt(c2 * n1 / (n1 - 1.0)) / kTwoPiD);
-    const double wbar = (s.Kw + d1) / kTwoPiD;          // mean phi, for scipy's rule
-    const double m2phi = c2 / (kTwoPiD * kTwoPiD);
-    const double eps_mean = 2.220446049250313e-16 * wbar;
-    out[8] = (m2phi <= eps_mean * eps_mean) ? __builtin_nanf("") : (float)(c4 / (c2 * c2));
-  }
+  frequency_features(s.Kw, s.swd1, s.swd2, s.swd3, s.swd4, N, out[4], out[8]);
+
+  if (s.pi_tie) out[4] = -out[4];   // picked up by amcx_step_tie_fix_kernel
 
   // ---- mixed moments (complex as (re, im) pairs)
   if (zero_frame) {   // the guard's kTinyPower must not leak into |C20| ... |C63| of a zero frame

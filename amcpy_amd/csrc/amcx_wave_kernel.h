@@ -56,7 +56,7 @@ namespace wave {
 constexpr int kFramesPerWave = 8;               // frames per wave per batch (finalised together)
 constexpr int kTailChunk = 2;                   // frames per grab over the last stretch of a workgroup's slice
 constexpr int kNumSums = 27;                    // reduced per-lane sums; the spectral peak rides in slot 27
-constexpr int kStashStride = 31;                // floats used per frame; odd -> conflict-free column reads
+constexpr int kStashStride = 33;                // 32 floats used per frame; odd -> conflict-free column reads
 constexpr int kStashBytes = kFramesPerWave * kStashStride * 4;
 
 constexpr int kEx1StrideKK = 136, kEx1StrideB = 68;   // complex units (tools/wave_fft_model.py)
@@ -223,8 +223,10 @@ struct Stats {
   float Kt = 0, Kw = 0, Ka = 0;
   float th_b1_prev = 0;   // angle of sample (i-1, b=1), waiting for its right neighbour
   float rot_prev = 0;     // wave_rol1(angle(i-1, b=0))
+  unsigned long long tie = 0;   // wave-uniform: lanes that saw a step within kTieBand of +-pi
 
   __device__ __forceinline__ void step(float w) {
+    tie |= __builtin_amdgcn_ballot_w64(__builtin_fabsf(w) > kPi - kTieBand);   // v_cmp + s_or
     const float d = w - Kw, d2 = d * d;
     sw1 += d; sw2 += d2;
     sw3 = __builtin_fmaf(d2, d, sw3);
@@ -654,6 +656,7 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
           row[kNumSums + 1] = S.Kt;
           row[kNumSums + 2] = S.Kw;
           row[kNumSums + 3] = S.Ka;
+          row[kNumSums + 4] = S.tie != 0 ? 1.0f : 0.0f;
         }
       }
     }
@@ -672,6 +675,7 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
       F.std1 = row[19]; F.std2 = row[20]; F.sab1 = row[21]; F.sab2 = row[22];
       F.swd1 = row[23]; F.swd2 = row[24]; F.swd3 = row[25]; F.swd4 = row[26];
       F.gmax_raw = row[27]; F.Kt = row[28]; F.Kw = row[29]; F.Ka = row[30];
+      F.pi_tie = row[31] != 0.0f;
       float feat[18];
       finalize_features(F, N, feat);
       float* dst = out + (f0 + lane) * out_stride;

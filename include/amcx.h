@@ -54,8 +54,9 @@ extern "C" {
                                    radix-2 LDS FFT (power of two) or direct DFT (any N);
                                    fp64 accumulation; 2 <= frame_size <= AMCX_MAX_FRAME_SIZE */
 #define AMCX_VARIANT_WAVE 2     /* one wavefront per frame, frame held in registers,
-                                   register radix-16/8 FFT with LDS exchanges;
-                                   frame_size in {1024, 2048, 4096} */
+                                   register radix-16/8 FFT with LDS exchanges, followed by a
+                                   small fix-up launch for frames with a phase step within
+                                   an fp32 ulp of +-pi; frame_size in {1024, 2048, 4096} */
 
 #define AMCX_MIN_FRAME_SIZE 2
 #define AMCX_MAX_FRAME_SIZE 8192

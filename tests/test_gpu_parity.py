@@ -329,3 +329,48 @@ def test_concurrent_streams_are_independent():
     torch.cuda.synchronize()
     for oa, ob in outs:
         assert torch.equal(oa, ya) and torch.equal(ob, yb)
+
+
+def _near_pi_tie_frames(N, n_frames, seed):
+    """Noisy frames with ~40 planted phase steps that are antiparallel to within +-1 or
+    +-2 fp32 ulps of one component: the wrapped step is +-pi to ~1e-8..1e-7 rad, which
+    fp32 angles cannot resolve but the fp64 reference does (from the same fp32 samples).
+    (Exactly antiparallel pairs are left out: there the reference's own sign hangs on the
+    1e-16 rounding of np.angle -- unless both angles are exact, as in the axis-aligned case
+    checked separately.)"""
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal((n_frames, N)) + 1j * rng.standard_normal((n_frames, N))).astype(np.complex64)
+    for f in range(n_frames):
+        pos = rng.choice(np.arange(2, N - 2, 3), size=40, replace=False)
+        for n in pos:
+            re, im = np.float32(x[f, n].real), np.float32(x[f, n].imag)
+            k = int(rng.choice([-2, -1, 1, 2]))
+            scale = np.float32(2.0 ** int(rng.integers(-1, 2)))
+            re2 = np.float32(-re * scale)
+            im2 = np.float32(-im * scale)
+            for _ in range(abs(k)):                       # nudge the imaginary part by |k| ulps
+                im2 = np.nextafter(im2, np.float32(np.inf if k > 0 else -np.inf), dtype=np.float32)
+            x[f, n + 1] = re2 + 1j * im2
+    return x
+
+
+def test_phase_steps_within_an_ulp_of_pi():
+    """Frames the fast kernel flags (a step within kTieBand of +-pi) get f5/f9 from the
+    exact-sign fix-up launch; the block kernel decides exactly in place.  Both must follow
+    the fp64 reference, including exact ties (numpy's unwrap rule)."""
+    for N in (1024, 2048, 4096):
+        x = _near_pi_tie_frames(N, 24, seed=1234 + N)
+        th = np.angle(x.astype(np.complex128))
+        d = np.abs(np.abs(np.diff(th, axis=-1)) - np.pi)
+        assert (d < 2.5e-7).sum() >= 24 * 30, "fixture lost its near-ties"
+        gold = orc.features18_batch(x)
+        for variant in _variants_for(N):
+            got = _run(x, variant)
+            assert (got[:, 4] > 0).all(), "tie flag (negative f5) leaked to the caller"
+            _assert_parity(got, gold, x, f"near-pi ties N={N} {variant}")
+    # exact antiparallel neighbours everywhere: every step is a true tie
+    alt = np.tile(np.array([1 + 1j, -1 - 1j], dtype=np.complex64), 1024)[None, :]
+    gold = orc.features18_batch(alt)
+    for variant in _variants_for(2048):
+        got = _run(alt, variant)
+        assert np.isclose(got[0, 4], gold[0, 4], rtol=1e-5), (variant, got[0, 4], gold[0, 4])
