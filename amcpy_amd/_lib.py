@@ -30,6 +30,8 @@ SIGNATURES = {
     "amcx_features18_c64_host": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i64, _i32, _i32]),
     "amcx_kernel_name": (C.c_int, [_i32, _i32, C.c_char_p, _i32]),
     "amcx_probe_read_bw": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "amcx_group_stats_f32": (C.c_int, [_vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp]),
+    "amcx_select_scale_f32": (C.c_int, [_vp, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _i64, _vp]),
 }
 
 _lib = None

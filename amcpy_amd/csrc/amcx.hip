@@ -9,6 +9,7 @@
 #include "amcx_block_kernel.h"
 #include "amcx_wave_kernel.h"
 #include "amcx_tie_fix_kernel.h"
+#include "amcx_post_kernels.h"
 
 namespace {
 
@@ -220,6 +221,39 @@ int amcx_probe_read_bw(const void* src_dev, int64_t n_bytes, float* partial_dev,
   hipLaunchKernelGGL(amcx_probe_read_kernel, dim3(4096), dim3(256), 0,
                      static_cast<hipStream_t>(hip_stream), static_cast<const float4*>(src_dev),
                      (long long)(n_bytes / 16), partial_dev);
+  AMCX_HIP(hipGetLastError());
+  return AMCX_OK;
+}
+
+int amcx_group_stats_f32(const float* x_dev, int64_t n_groups, int64_t rows_per_group,
+                         int64_t row_stride, int32_t n_cols, double* mean_dev, double* std_dev,
+                         void* hip_stream) {
+  if (n_groups < 0 || rows_per_group < 1 || n_cols < 1 || n_cols > amcx::kStatMaxCols ||
+      row_stride < n_cols || n_groups > 0x7fffffffLL)
+    return AMCX_EINVAL;
+  if (n_groups == 0) return AMCX_OK;
+  if (x_dev == nullptr || mean_dev == nullptr || std_dev == nullptr) return AMCX_EINVAL;
+  hipLaunchKernelGGL(amcx::amcx_group_stats_kernel, dim3((unsigned)n_groups), dim3(amcx::kBlockThreads), 0,
+                     static_cast<hipStream_t>(hip_stream), x_dev, (long long)rows_per_group,
+                     (long long)row_stride, (int)n_cols, mean_dev, std_dev);
+  AMCX_HIP(hipGetLastError());
+  return AMCX_OK;
+}
+
+int amcx_select_scale_f32(const float* x_dev, int64_t n_rows, int64_t row_stride,
+                          const int32_t* cols_dev, int32_t n_sel, const double* mean_dev,
+                          const double* scale_dev, float* out_dev, int64_t out_stride,
+                          void* hip_stream) {
+  if (n_rows < 0 || n_sel < 1 || out_stride < n_sel || row_stride < 1) return AMCX_EINVAL;
+  if (n_rows == 0) return AMCX_OK;
+  if (!x_dev || !cols_dev || !mean_dev || !scale_dev || !out_dev) return AMCX_EINVAL;
+  const int64_t total = n_rows * n_sel;
+  int64_t grid = (total + amcx::kBlockThreads - 1) / amcx::kBlockThreads;
+  const int64_t cap = (int64_t)cu_count() * 8;
+  if (grid > cap) grid = cap;
+  hipLaunchKernelGGL(amcx::amcx_select_scale_kernel, dim3((unsigned)grid), dim3(amcx::kBlockThreads), 0,
+                     static_cast<hipStream_t>(hip_stream), x_dev, (long long)n_rows, (long long)row_stride,
+                     cols_dev, (int)n_sel, mean_dev, scale_dev, out_dev, (long long)out_stride);
   AMCX_HIP(hipGetLastError());
   return AMCX_OK;
 }

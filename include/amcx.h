@@ -115,6 +115,31 @@ int amcx_kernel_name(int32_t frame_size, int32_t variant, char* buf, int32_t buf
 int amcx_probe_read_bw(const void* src_dev, int64_t n_bytes, float* partial_dev,
                        void* hip_stream);
 
+/*
+ * Consumers directly behind the path, on the device-resident
+ * (rows x >=18) float32 feature matrix.
+ *
+ * amcx_group_stats_f32: for each of n_groups consecutive blocks of rows_per_group
+ * rows, column mean and POPULATION standard deviation (ddof = 0) of the first n_cols
+ * (<= 32) columns, fp64: mean_dev / std_dev are [n_groups][n_cols] doubles.
+ * Replaces the per-SNR np.mean / np.std triple loop, graphics.py:50-62, and the fit
+ * of StandardScaler, preprocessing.py:59-61.
+ */
+int amcx_group_stats_f32(const float* x_dev, int64_t n_groups, int64_t rows_per_group,
+                         int64_t row_stride, int32_t n_cols, double* mean_dev, double* std_dev,
+                         void* hip_stream);
+
+/*
+ * amcx_select_scale_f32: out[r][j] = (x[r][cols[j]] - mean[j]) / scale[j], rounded to
+ * float32 after each of the two operations as numpy's in-place float32 arithmetic does
+ * (column pick preprocessing.py:55, StandardScaler.transform :62).  cols_dev: n_sel
+ * int32 column indices (0-based, as the reference passes list(FeatureConfig.used)).
+ */
+int amcx_select_scale_f32(const float* x_dev, int64_t n_rows, int64_t row_stride,
+                          const int32_t* cols_dev, int32_t n_sel, const double* mean_dev,
+                          const double* scale_dev, float* out_dev, int64_t out_stride,
+                          void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif
