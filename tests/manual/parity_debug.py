@@ -1,7 +1,7 @@
 import sys
 from pathlib import Path
 import numpy as np
-sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 import torch
 from amcpy_amd import synth
 from amcpy_amd.features import features18

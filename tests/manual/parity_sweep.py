@@ -5,7 +5,7 @@ plain relative error per feature; not part of the test-suite (takes ~1 min)."""
 import sys, time
 from pathlib import Path
 import numpy as np
-sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 import torch
 from amcpy_amd import synth
 from amcpy_amd.features import features18
