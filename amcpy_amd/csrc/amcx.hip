@@ -75,9 +75,20 @@ int launch_block(const float2* iq, int64_t n_frames, int32_t N, int64_t row_stri
 
 __global__ __launch_bounds__(256) void amcx_probe_read_kernel(const float4* __restrict__ src,
                                                              long long n_vec, float* partial) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
   float acc = 0.f;
   const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  // four independent 16-byte loads in flight per lane and iteration
+  for (; i + 3 * stride < n_vec; i += 4 * stride) {
+    const v4f a = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src + i));
+    const v4f b = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src + i + stride));
+    const v4f c = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src + i + 2 * stride));
+    const v4f d = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src + i + 3 * stride));
+    acc += ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w)) + ((c.x + c.y) + (c.z + c.w)) +
+           ((d.x + d.y) + (d.z + d.w));
+  }
+  for (; i < n_vec; i += stride) {
     const float4 v = src[i];
     acc += (v.x + v.y) + (v.z + v.w);
   }

@@ -715,9 +715,16 @@ inline hipError_t launch_wave_n(const float2* iq, int64_t n_frames, int64_t row_
                                 int64_t out_stride, hipStream_t stream, int cus) {
   auto kern = wave::amcx_features18_wave_kernel<N>;
   constexpr int lds = wave::Cfg<N>::kLdsBytes;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  // > 64 KiB of dynamic LDS needs the attribute; it is per device, so once per (kernel, device)
+  static bool lds_attr_set[64] = {};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= 64 || !lds_attr_set[dev]) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64) lds_attr_set[dev] = true;   // benign race: idempotent
+  }
   int64_t grid = (int64_t)cus;                        // persistent: one resident workgroup per CU
   const int64_t min_slice = wave::Cfg<N>::kWavesPerWG;   // at least a frame per wave
   if (grid * min_slice > n_frames) grid = (n_frames + min_slice - 1) / min_slice;
