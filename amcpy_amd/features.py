@@ -81,6 +81,19 @@ def features18(iq, out=None, *, frame_size: int | None = None, variant="auto"):
     return out[..., :_lib.NUM_FEATURES]
 
 
+def features18_iq_pairs(iq_pairs, **kw):
+    """Zero-copy entry for data stored as float32 (I, Q) pairs: RadioML-style
+    ``(..., N, 2)`` float32 arrays and raw GNU-Radio complex64 streams reshaped to
+    ``(F, N, 2)`` (reference old/dataset.py:50-56, old/read_binary_stream.py:28,48) are
+    bit-identical to the kernel's complex64 layout, so the tensor is only re-viewed."""
+    import torch
+    if not isinstance(iq_pairs, torch.Tensor) or iq_pairs.dtype != torch.float32 or iq_pairs.shape[-1] != 2:
+        raise TypeError("expected a float32 tensor whose last dimension is (I, Q)")
+    if iq_pairs.stride(-1) != 1 or (iq_pairs.shape[-2] > 1 and iq_pairs.stride(-2) != 2):
+        raise ValueError("(I, Q) pairs must be interleaved in memory")
+    return features18(torch.view_as_complex(iq_pairs), **kw)
+
+
 def features18_host(frames: np.ndarray, *, frame_size: int | None = None, device: int = 0,
                     variant="auto") -> np.ndarray:
     """numpy (..., L) complex -> numpy (..., 18) float32 via the GPU.

@@ -374,3 +374,20 @@ def test_phase_steps_within_an_ulp_of_pi():
     for variant in _variants_for(2048):
         got = _run(alt, variant)
         assert np.isclose(got[0, 4], gold[0, 4], rtol=1e-5), (variant, got[0, 4], gold[0, 4])
+
+
+def test_iq_pair_layout_is_zero_copy():
+    """RadioML-style (F, N, 2) float32 input: same bits as
+    complex64, so the result equals the complex path exactly and no copy is made."""
+    torch = _torch()
+    from amcpy_amd.features import features18, features18_iq_pairs
+    from amcpy_amd import synth
+    x = synth.host_block("16QAM", 6.0, 64, 1024, seed=77)
+    pairs = torch.from_numpy(np.stack([x.real, x.imag], axis=-1).astype(np.float32)).cuda()
+    a = features18_iq_pairs(pairs)
+    b = features18(torch.from_numpy(x).cuda())
+    assert torch.equal(a, b)
+    with pytest.raises(TypeError):
+        features18_iq_pairs(pairs.double())
+    with pytest.raises(ValueError):
+        features18_iq_pairs(pairs.transpose(1, 2).contiguous().transpose(1, 2))
