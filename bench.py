@@ -110,6 +110,24 @@ def _pmc_traffic(frames_per_launch: int):
     return best
 
 
+def _valu_note(frames_per_s: float):
+    """Secondary bound from the committed PMC summary: the kernel is VALU/power-bound
+    (DESIGN.md section 4.3), so report the issue rate next to the HBM fraction."""
+    for p in sorted((REPO / "profiles").glob("*final_summary.json"), reverse=True):
+        try:
+            d = json.loads(p.read_text())
+            for name, c in d["counters_mean_per_dispatch"].items():
+                if "wave_kernel<2048>" in name and "SQ_INSTS_VALU" in c:
+                    per_frame = c["SQ_INSTS_VALU"] / (6 * 26 * 4096)
+                    return {"bound": "valu-issue/power", "valu_instr_per_frame": per_frame,
+                            "achieved_Gwaveinstr_per_s": per_frame * frames_per_s / 1e9,
+                            "plain_fma_stream_Gwaveinstr_per_s": 890.0,
+                            "source": f"profiles/{p.name}; profiles/r1_valu_issue_rates.txt (3 waves/SIMD)"}
+        except Exception:
+            continue
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -237,6 +255,7 @@ def main():
             "traffic": _pmc_traffic(frames_per_launch) if FS == FRAME_SIZE else None,
             "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_ms": mean_launch_s * 1e3,
             "measured_read_peak_GBps": read_peak,
+            "secondary": _valu_note(value / world) if FS == FRAME_SIZE else None,
         },
         "cpu_baseline": cpu,
     }
