@@ -28,6 +28,7 @@ SIGNATURES = {
     "amcx_features18_c64": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i64, _vp]),
     "amcx_features18_c64_ex": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i64, _vp, _i32]),
     "amcx_features18_c64_host": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i64, _i32, _i32]),
+    "amcx_features18_c128_host": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i64, _i32, _i32]),
     "amcx_kernel_name": (C.c_int, [_i32, _i32, C.c_char_p, _i32]),
     "amcx_probe_read_bw": (C.c_int, [_vp, _i64, _vp, _vp]),
     "amcx_group_stats_f32": (C.c_int, [_vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp]),

@@ -100,6 +100,20 @@ __global__ __launch_bounds__(256) void amcx_probe_read_kernel(const float4* __re
   if (threadIdx.x == 0) partial[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
 }
 
+// complex128 -> complex64, row-packed: dst[f][n] = (float2) src[f][n], n < N
+__global__ __launch_bounds__(256) void amcx_c128_to_c64_kernel(const double2* __restrict__ src,
+                                                              long long n_frames, int N,
+                                                              long long src_stride, float2* __restrict__ dst) {
+  const long long total = n_frames * N;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long f = i / N;
+    const int n = (int)(i - f * N);
+    const double2 v = src[f * src_stride + n];
+    dst[i] = make_float2((float)v.x, (float)v.y);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -210,6 +224,65 @@ int amcx_features18_c64_host(const void* iq_host, int64_t n_frames, int32_t fram
   if (rc == AMCX_OK && e != hipSuccess) rc = hip_fail(e, "amcx_features18_c64_host");
   if (stream) (void)hipStreamDestroy(stream);
   if (d_iq) (void)hipFree(d_iq);
+  if (d_out) (void)hipFree(d_out);
+  (void)hipSetDevice(prev);
+  return rc;
+}
+
+int amcx_features18_c128_host(const void* iq_host, int64_t n_frames, int32_t frame_size,
+                              int64_t row_stride_elems, float* out_host, int64_t out_row_stride,
+                              int32_t device, int32_t variant) {
+  if (n_frames < 0 || row_stride_elems < frame_size || out_row_stride < AMCX_NUM_FEATURES)
+    return AMCX_EINVAL;
+  const int v = resolve_variant(frame_size, variant);
+  if (v < 0) return v;
+  if (n_frames == 0) return AMCX_OK;
+  if (iq_host == nullptr || out_host == nullptr) return AMCX_EINVAL;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
+    return AMCX_ENODEV;
+  int prev = 0;
+  AMCX_HIP(hipGetDevice(&prev));
+  AMCX_HIP(hipSetDevice(device));
+  // chunk: at most ~512 MiB of doubles on the device at a time
+  const size_t row16 = (size_t)frame_size * 16;
+  int64_t per = (int64_t)((512ull << 20) / row16);
+  if (per < 1) per = 1;
+  if (per > n_frames) per = n_frames;
+  void *d_in = nullptr, *d_c64 = nullptr;
+  float* d_out = nullptr;
+  hipStream_t stream = nullptr;
+  int rc = AMCX_OK;
+  hipError_t e = hipSuccess;
+  if (hipMalloc(&d_in, row16 * (size_t)per) != hipSuccess ||
+      hipMalloc(&d_c64, (row16 / 2) * (size_t)per) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&d_out), sizeof(float) * AMCX_NUM_FEATURES * (size_t)per) != hipSuccess) {
+    (void)hipGetLastError();
+    rc = AMCX_ENOMEM;
+  }
+  if (rc == AMCX_OK) e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+  const char* src = static_cast<const char*>(iq_host);
+  for (int64_t f0 = 0; rc == AMCX_OK && e == hipSuccess && f0 < n_frames; f0 += per) {
+    const int64_t nf = (n_frames - f0) < per ? (n_frames - f0) : per;
+    e = hipMemcpy2DAsync(d_in, row16, src + (size_t)f0 * (size_t)row_stride_elems * 16,
+                         (size_t)row_stride_elems * 16, row16, (size_t)nf, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) break;
+    hipLaunchKernelGGL(amcx_c128_to_c64_kernel, dim3(2048), dim3(256), 0, stream,
+                       static_cast<const double2*>(d_in), (long long)nf, (int)frame_size,
+                       (long long)frame_size, static_cast<float2*>(d_c64));
+    e = hipGetLastError();
+    if (e != hipSuccess) break;
+    rc = amcx_features18_c64_ex(d_c64, nf, frame_size, frame_size, d_out, AMCX_NUM_FEATURES, stream, v);
+    if (rc != AMCX_OK) break;
+    e = hipMemcpy2DAsync(out_host + (size_t)f0 * (size_t)out_row_stride, sizeof(float) * (size_t)out_row_stride,
+                         d_out, sizeof(float) * AMCX_NUM_FEATURES, sizeof(float) * AMCX_NUM_FEATURES,
+                         (size_t)nf, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);   // d_in / d_out are reused by the next chunk
+  }
+  if (rc == AMCX_OK && e != hipSuccess) rc = hip_fail(e, "amcx_features18_c128_host");
+  if (stream) (void)hipStreamDestroy(stream);
+  if (d_in) (void)hipFree(d_in);
+  if (d_c64) (void)hipFree(d_c64);
   if (d_out) (void)hipFree(d_out);
   (void)hipSetDevice(prev);
   return rc;

@@ -98,8 +98,8 @@ def features18_host(frames: np.ndarray, *, frame_size: int | None = None, device
                     variant="auto") -> np.ndarray:
     """numpy (..., L) complex -> numpy (..., 18) float32 via the GPU.
 
-    complex128 input (MATLAB doubles) is rounded to complex64, the engine's
-    input type.  Raises if no MI355X is present (AMCX_ENODEV)."""
+    complex128 input (MATLAB doubles) is uploaded as it is and rounded to complex64,
+    the engine's input type, on the GPU.  Raises if no MI355X is present (AMCX_ENODEV)."""
     x = np.asarray(frames)
     if not np.iscomplexobj(x):
         x = x.astype(np.complex64)
@@ -108,12 +108,17 @@ def features18_host(frames: np.ndarray, *, frame_size: int | None = None, device
     if N > L:
         raise ValueError(f"frame_size {N} exceeds row length {L}")
     lead = x.shape[:-1]
-    x2 = np.ascontiguousarray(x.reshape(-1, L), dtype=np.complex64)
-    out = np.empty((x2.shape[0], _lib.NUM_FEATURES), dtype=np.float32)
     lib = _lib.load()
-    _lib.check(lib.amcx_features18_c64_host(
-        x2.ctypes.data, x2.shape[0], N, L, out.ctypes.data, _lib.NUM_FEATURES,
-        int(device), _variant(variant)))
+    if x.dtype == np.complex128:
+        # MATLAB doubles: uploaded as they are, rounded to complex64 on the GPU
+        x2 = np.ascontiguousarray(x.reshape(-1, L))
+        entry = lib.amcx_features18_c128_host
+    else:
+        x2 = np.ascontiguousarray(x.reshape(-1, L), dtype=np.complex64)
+        entry = lib.amcx_features18_c64_host
+    out = np.empty((x2.shape[0], _lib.NUM_FEATURES), dtype=np.float32)
+    _lib.check(entry(x2.ctypes.data, x2.shape[0], N, L, out.ctypes.data, _lib.NUM_FEATURES,
+                     int(device), _variant(variant)))
     return out.reshape(lead + (_lib.NUM_FEATURES,))
 
 

@@ -100,6 +100,18 @@ int amcx_features18_c64_host(const void* iq_host, int64_t n_frames, int32_t fram
                              int32_t device, int32_t variant);
 
 /*
+ * Same for a HOST container of complex128 (MATLAB doubles, what scipy.io.loadmat
+ * returns for the reference's all_modulations.mat, feature_extraction.py:46-48):
+ * rows go up as doubles in bounded chunks and are rounded to complex64 on the GPU
+ * (round-to-nearest-even, identical to numpy's astype) -- PCIe moves 16 B/sample
+ * several times faster than a host-side conversion produces 8 B/sample.
+ * row_stride_elems is in complex128 elements.
+ */
+int amcx_features18_c128_host(const void* iq_host, int64_t n_frames, int32_t frame_size,
+                              int64_t row_stride_elems, float* out_host, int64_t out_row_stride,
+                              int32_t device, int32_t variant);
+
+/*
  * Name of the kernel `variant` resolves to for this frame_size (as it shows in
  * rocprofv3 kernel traces), written NUL-terminated into buf.  Returns 0, or
  * AMCX_ENOTSUP / AMCX_EINVAL.

@@ -428,3 +428,17 @@ def test_full_benchmark_shard_properties():
     _assert_parity(alone.cpu().numpy(), orc.features18_batch(x), x, "sample of the full shard")
     # SNR trend sanity on the signal classes: mean |x| falls towards 1 as noise vanishes
     assert (whole[0, 0, :, 5].mean() > whole[0, -1, :, 5].mean())
+
+
+def test_complex128_host_entry_chunks_and_rounds_on_device():
+    """MATLAB-double containers go up as doubles and are rounded on the GPU exactly as
+    numpy's astype(complex64) would; more than one 512 MiB chunk, rows longer than the
+    frame."""
+    from amcpy_amd.features import features18_host
+    rng = np.random.default_rng(8)
+    F, L, N = 9000, 4100, 4096                       # 590 MB of complex128 -> two chunks
+    x = rng.standard_normal((F, L)) + 1j * rng.standard_normal((F, L))
+    got = features18_host(x, frame_size=N)
+    want = features18_host(x.astype(np.complex64), frame_size=N)
+    assert np.array_equal(got, want)
+    assert np.isfinite(got).all()
