@@ -29,7 +29,12 @@ template <int N> void run(const float2* d_iq, long long F, float* d_out, unsigne
   const char* names[kStampSections] = {"load+stats sweep", "envelope sweep", "fft pass1+xchg1", "fft pass2/3+xchg2", "reduce(last of batch)", "finalize(batch)", "-", "reduce+stash+loop"};
   double real_us = s[6] / nw / 100.0; s[6] = 0;
   { double mn = 1e30, mx = 0; for (int w = 0; w < nw; ++w) { double v = (double)h[w * kStampSections + 6] / 100.0; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
-    printf("   wave lifetime us: min %.1f  mean %.1f  max %.1f   (kernel %.1f)\n", mn, real_us, mx, ms * 1e3); }
+    printf("   wave lifetime us: min %.1f  mean %.1f  max %.1f   (kernel %.1f)\n", mn, real_us, mx, ms * 1e3);
+    double xs[8] = {0}; int xn[8] = {0};
+    for (int w = 0; w < nw; ++w) { int wg = w / kWavesPerWG; xs[wg % 8] += (double)h[w * kStampSections + 6] / 100.0; xn[wg % 8]++; }
+    printf("   mean lifetime by blockIdx %% 8:"); for (int x = 0; x < 8; ++x) printf(" %.0f", xs[x] / xn[x]); printf("\n");
+    double lo = 1e30, hi = 0; for (int wg = 0; wg < nw / kWavesPerWG; ++wg) { double m = 0; for (int k = 0; k < kWavesPerWG; ++k) m += (double)h[(wg * kWavesPerWG + k) * kStampSections + 6] / 100.0; m /= kWavesPerWG; lo = m < lo ? m : lo; hi = m > hi ? m : hi; }
+    printf("   per-workgroup mean lifetime: min %.0f max %.0f\n", lo, hi); }
   double tot = 0; for (double v : s) tot += v;
   double frames_per_wave = (double)F / nw;
   printf("N=%d  kernel %.3f ms  (%.1f M frames/s)  mean wave lifetime %.1f us -> s_memtime clock %.2f GHz; cycles per frame per wave: %.0f\n", N, ms, F / ms / 1e3, real_us, tot / nw / real_us / 1e3, tot / nw / frames_per_wave);
