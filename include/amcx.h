@@ -27,6 +27,8 @@
  *     yields 18 NaNs, as numpy's arithmetic does for the reference.
  *   - re-entrant and thread-safe; launches are asynchronous on `hip_stream`
  *     (a hipStream_t, NULL = default stream); completion = caller's stream sync.
+ *     The device entry points allocate nothing and never synchronise, so after one
+ *     warm call per kernel and device they can be captured in a HIP graph.
  */
 #ifndef AMCX_H_
 #define AMCX_H_

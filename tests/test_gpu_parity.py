@@ -442,3 +442,27 @@ def test_complex128_host_entry_chunks_and_rounds_on_device():
     want = features18_host(x.astype(np.complex64), frame_size=N)
     assert np.array_equal(got, want)
     assert np.isfinite(got).all()
+
+
+def test_launch_is_graph_capturable():
+    """The launch path makes no allocation or synchronisation, so after one warm call
+    (which sets the kernel's LDS attribute) it can be captured in a HIP graph and
+    replayed (both launches: wave kernel + tie fix-up)."""
+    torch = _torch()
+    from amcpy_amd.features import features18
+    from amcpy_amd import synth
+    x = torch.from_numpy(synth.host_block("QPSK", 8.0, 500, 2048, seed=3)).cuda()
+    out = torch.empty((500, 18), dtype=torch.float32, device="cuda")
+    want = features18(x).clone()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        features18(x, out=out)                       # warm on the capture stream
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            features18(x, out=out)
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
