@@ -50,6 +50,8 @@ int main() {
   CHECK(hipMalloc(&d_iq, F * 2048 * 8)); CHECK(hipMalloc(&d_out, 2 * F * 18 * 4)); CHECK(hipMalloc(&d_st, 256 * 16 * 8 * 8));
   CHECK(hipMemcpy(d_iq, h.data(), F * 2048 * 8, hipMemcpyHostToDevice));
   run<2048>(d_iq, F, d_out, d_st, 256);
+  run<2048>(d_iq, F, d_out, d_st, 128);   // half the CUs: does the clock rise (power-bound)?
+  run<2048>(d_iq, F, d_out, d_st, 64);
   run<1024>(d_iq, F * 2, d_out, d_st, 256);
   run<4096>(d_iq, F / 2, d_out, d_st, 256);
   return 0;
