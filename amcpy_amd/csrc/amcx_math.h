@@ -111,6 +111,15 @@ struct FrameSums {
   double gmax_raw;               // max_k |X_k|^2 (unnormalised FFT)
 };
 
+// The finaliser's results are stored as float32, so its square roots and quotients
+// need ~1e-7, not 1e-16: the raw v_sqrt_f64 / v_rcp_f64 (accurate to about float
+// precision) replace the ~20-instruction IEEE expansions hipcc emits for sqrt() and
+// '/', cutting the finaliser from ~500 to ~200 instructions per batch.  Special values
+// behave the same way (0 * rcp(0) = NaN, x * rcp(0) = inf).
+__device__ __forceinline__ double q_sqrt(double x) { return __builtin_amdgcn_sqrt(x); }
+__device__ __forceinline__ double q_div(double a, double b) { return a * __builtin_amdgcn_rcp(b); }
+constexpr double kInvTwoPiD = 1.0 / 6.283185307179586476925286766559;
+
 // f5 = std1(phi), f9 = kurt(phi) of phi = w / 2pi from sums of d = w - Kw over the N-1 steps
 __device__ inline void frequency_features(double Kw, double swd1, double swd2, double swd3, double swd4,
                                           int N, float& f5, float& f9) {
@@ -120,11 +129,11 @@ __device__ inline void frequency_features(double Kw, double swd1, double swd2, d
   double c2 = r2 - d1 * d1;                             // central moments of w
   if (c2 < 0) c2 = 0;
   const double c4 = r4 - 4.0 * d1 * r3 + 6.0 * d1 * d1 * r2 - 3.0 * d1 * d1 * d1 * d1;
-  f5 = (float)(__builtin_sqrt(c2 * n1 / (n1 - 1.0)) / kTwoPiD);
-  const double wbar = (Kw + d1) / kTwoPiD;              // mean phi, for scipy's rule
-  const double m2phi = c2 / (kTwoPiD * kTwoPiD);
+  f5 = (float)(q_sqrt(c2 * (n1 * (1.0 / (n1 - 1.0)))) * kInvTwoPiD);   // N is a constant where it matters
+  const double wbar = (Kw + d1) * kInvTwoPiD;            // mean phi, for scipy's rule
+  const double m2phi = c2 * (kInvTwoPiD * kInvTwoPiD);
   const double eps_mean = 2.220446049250313e-16 * wbar;
-  f9 = (m2phi <= eps_mean * eps_mean) ? __builtin_nanf("") : (float)(c4 / (c2 * c2));
+  f9 = (m2phi <= eps_mean * eps_mean) ? __builtin_nanf("") : (float)q_div(c4, c2 * c2);
 }
 
 // All 18 features from the sums, fp64 (the reference evaluates in fp64 and
@@ -133,7 +142,7 @@ __device__ inline void frequency_features(double Kw, double swd1, double swd2, d
 // (features.py:147,57).
 __device__ inline void finalize_features(const FrameSums& s, int N, float* __restrict__ out) {
   const double n = (double)N;
-  const double inv = 1.0 / n;
+  const double inv = 1.0 / n, inv_nm1 = 1.0 / (n - 1.0);
   // non-finite input anywhere -> the reference's numpy arithmetic yields NaN
   // in every feature (SURVEY.md Appendix C "one NaN sample")
   if (!(__builtin_fabs(s.sP) <= 1.79e308) || !(s.gmax_raw == s.gmax_raw)) {
@@ -153,8 +162,8 @@ __device__ inline void finalize_features(const FrameSums& s, int N, float* __res
   const double ma = s.sab1 * inv;                       // mean of shifted |theta|
   double cabs2 = s.sab2 - n * ma * ma;                  // sum (|theta|-mean)^2
   if (cabs2 < 0) cabs2 = 0;
-  out[1] = (float)__builtin_sqrt(cabs2 / (n - 1.0));
-  out[2] = (float)__builtin_sqrt(ct2 / (n - 1.0));
+  out[1] = (float)q_sqrt(cabs2 * inv_nm1);
+  out[2] = (float)q_sqrt(ct2 * inv_nm1);
 
   // ---- envelope: f4, f6, f7, f8
   // an all-zero frame reaches here as N samples of power kTinyPower (the angle
@@ -165,11 +174,11 @@ __device__ inline void finalize_features(const FrameSums& s, int N, float* __res
     const double mad = s.sad1 * inv;                    // mean |a-mu|
     double v = s.sad2 - n * mad * mad;                  // sum (|a-mu| - mad)^2
     if (v < 0) v = 0;
-    out[3] = (float)(__builtin_sqrt(v / (n - 1.0)) / mu);   // 0/0 -> NaN for a zero frame
+    out[3] = (float)q_div(q_sqrt(v * inv_nm1), mu);       // 0/0 -> NaN for a zero frame
     out[5] = (float)mu;
-    out[6] = (float)(__builtin_sqrt(zero_frame ? 0.0 : s.sa) * inv);
+    out[6] = (float)(q_sqrt(zero_frame ? 0.0 : s.sa) * inv);
     const double m2 = s.sad2 * inv, m4 = s.sad4 * inv;
-    out[7] = (float)(m4 / (m2 * m2));                   // m2 == 0 -> NaN (scipy rule)
+    out[7] = (float)q_div(m4, m2 * m2);                 // m2 == 0 -> NaN (scipy rule)
   }
 
   // ---- frequency phi = w / 2pi over N-1 values: f5, f9
@@ -195,7 +204,7 @@ __device__ inline void finalize_features(const FrameSums& s, int N, float* __res
   const double m63 = (2.0 * s.sAAP - s.sX4P) * inv;                   // mean P^3
   // m22 = conj(m20), m43 = conj(m41)
 
-  auto cabs = [](double r, double i) { return __builtin_sqrt(r * r + i * i); };
+  auto cabs = [](double r, double i) { return q_sqrt(r * r + i * i); };
   const double q20r = m20r * m20r - m20i * m20i, q20i = 2.0 * m20r * m20i;   // m20^2
   const double n20 = m20r * m20r + m20i * m20i;                              // |m20|^2
 
