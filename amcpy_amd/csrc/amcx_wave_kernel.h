@@ -2,7 +2,7 @@
 // Instantiated for frame sizes 1024, 2048 and 4096.
 //
 // Why not "one 256-thread workgroup per frame": this path is VALU/power-bound, not
-// HBM-bound (~103 fp32 VALU ops per sample), so the design
+// HBM-bound (~107 fp32 VALU ops per sample), so the design
 // minimises instructions per sample:
 //   * 16-64 samples per lane amortise every cross-lane reduction over 4-8x more
 //     work than a 256-thread block would (8 samples per lane at N = 2048);
@@ -42,8 +42,6 @@
 // twiddles 15 KiB + 960 B, 12 x 8704 B exchange, 12 x 1056 B stash = 133.4 KB.
 // Algorithmic HBM bytes per frame: 8*N read + 72 written.
 #pragma once
-
-#include <stdlib.h>
 
 #include <type_traits>
 #include <utility>
