@@ -68,7 +68,7 @@ __device__ __forceinline__ float block_max(float v, double* scratch) {
 }
 
 template <bool POW2>
-__global__ __launch_bounds__(kBlockThreads) void amcx_features18_block_kernel(
+__global__ __launch_bounds__(kBlockThreads, 2) void amcx_features18_block_kernel(
     const float2* __restrict__ iq, long long n_frames, int N, long long row_stride,
     float* __restrict__ out, long long out_stride) {
   extern __shared__ float4 amcx_block_smem[];
@@ -148,14 +148,23 @@ __global__ __launch_bounds__(kBlockThreads) void amcx_features18_block_kernel(
     float peak = 0.f;
     if constexpr (POW2) {
       // in-place radix-2 decimation-in-frequency; output order is bit-reversed,
-      // which a maximum does not care about
-      for (int half = N >> 1; half >= 1; half >>= 1) {
-        for (int b = tid; b < (N >> 1); b += kBlockThreads) {
+      // which a maximum does not care about.  Twiddles W_N^m, m < N/2, are tabulated
+      // once per frame in the (|x|, angle) stash, which is dead by now: N/512
+      // sincospif per thread instead of one per butterfly.
+      const int half_n = N >> 1;
+      for (int mI = tid; mI < half_n; mI += kBlockThreads) {
+        float sn, cs;
+        sincospif((float)mI / (float)half_n, &sn, &cs);        // W_N^m = cs - i*sn
+        at[mI] = make_float2(cs, sn);
+      }
+      __syncthreads();
+      for (int half = half_n, step = 1; half >= 1; half >>= 1, step <<= 1) {
+        for (int b = tid; b < half_n; b += kBlockThreads) {
           const int j = b & (half - 1);
           const int i0 = ((b - j) << 1) + j, i1 = i0 + half;
           const float2 u = xs[i0], v = xs[i1];
-          float sn, cs;
-          sincospif((float)j / (float)half, &sn, &cs);       // W = cs - i*sn
+          const float2 w = at[j * step];                       // W_(2 half)^j = W_N^(j N/(2 half))
+          const float cs = w.x, sn = w.y;
           const float dr = u.x - v.x, di = u.y - v.y;
           xs[i0] = make_float2(u.x + v.x, u.y + v.y);
           xs[i1] = make_float2(__builtin_fmaf(dr, cs, di * sn), __builtin_fmaf(di, cs, -dr * sn));
