@@ -28,14 +28,17 @@
 //   xchg 2   LDS[k2*65 + 8 kk + n3]; reader lane l'' (kk = l''>>3, k2 = (l''&7) + 8 j)
 //   pass 3   8-point DFT over n3  -> X[k1 + R k2 + 16 R k3]; only max |X|^2 is kept
 // N = 4096 is one radix-2 decimation-in-frequency split in front of that machine:
-//   X[2k]   = FFT_2048(x[n] + x[n+2048]),  X[2k+1] = FFT_2048((x[n] - x[n+2048]) W_4096^n):
-// the upper half is streamed once for the statistics while the sum is formed in
-// place; both halves are read a second time (from L2 / Infinity Cache) for the
-// difference FFT, which is also where the envelope's second sweep happens.
+//   X[2k]   = FFT_2048(x[n] + x[n+2048]),  X[2k+1] = FFT_2048((x[n] - x[n+2048]) W_4096^n).
+// The whole 32 KiB frame sits in 128 VGPRs, so that variant runs 2 waves per SIMD
+// (8-wave workgroups, 256 VGPRs each) and reads every byte exactly once.  (Round 1c
+// kept 3 waves per SIMD and read both halves a second time for the difference
+// branch: L2 holds 4 MiB per XCD against 12 MiB of frames in flight, so the second
+// read came over the fabric -- FETCH_SIZE 2.0x the algorithmic bytes and 23 % of
+// wave-cycles waiting on it, profiles/r1d_n4096_summary.json.)
 // Every ds_write_b64 / ds_read_b64 / ds_read_b128 of the exchanges and twiddle
 // tables is bank-conflict free and addressed as lane_base + immediate.
 //
-// 768-thread workgroups: 12 waves = exactly 3 per SIMD, one workgroup per CU.
+// 768-thread workgroups (N <= 2048): 12 waves = exactly 3 per SIMD, one workgroup per CU.
 // (Two 6-wave workgroups do NOT co-reside: their waves land 2,2,1,1 on the SIMDs
 // and a SIMD holds at most 3 waves of 160 VGPRs -- seen as half the waves'
 // lifetime in SQ_WAVE_CYCLES, profiles/r1a.)  LDS per workgroup at N = 2048:
@@ -66,8 +69,9 @@ template <int N>
 struct Cfg {
   static_assert(N == 1024 || N == 2048 || N == 4096, "wave kernel frame sizes");
   static constexpr bool kSplit = N == 4096;            // radix-2 DIF split in front of a 2048 FFT
-  // waves per workgroup = waves per CU: 3 per SIMD at 161-168 VGPRs
-  static constexpr int kWavesPerWG = 12;   // (16 waves at N = 1024, 114 VGPRs, measured no faster: power-bound)
+  // waves per workgroup = waves per CU: 3 per SIMD at 161-168 VGPRs, 2 per SIMD when the
+  // frame alone takes 128 VGPRs (16 waves at N = 1024, 114 VGPRs, measured no faster: power-bound)
+  static constexpr int kWavesPerWG = kSplit ? 8 : 12;
   static constexpr int kThreads = 64 * kWavesPerWG;
   static constexpr int kTailFrames = kWavesPerWG * kFramesPerWave;
   static constexpr int kRows = N / 128;                // rows of 128 samples per frame
@@ -79,6 +83,8 @@ struct Cfg {
   static constexpr int kCounterOffset = kTableBytes + kWavesPerWG * (kExchangeBytes + kStashBytes);
   static constexpr int kLdsBytes = kCounterOffset + 16;       // + the workgroup's two work counters
   static_assert(kLdsBytes <= 163840, "one workgroup per CU must fit in 160 KiB of LDS");
+  // the envelope's second sweep reads |x| back from the exchange buffer, or, when the frame is too
+  // large to park there, takes the square roots again from the registers
   static_assert(kSplit || 2 * kRows * 64 * 4 <= kExchangeBytes, "|x| parking must fit the exchange buffer");
 };
 
@@ -405,7 +411,7 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
     const float2* __restrict__ iq, long long n_frames, long long row_stride,
     float* __restrict__ out, long long out_stride AMCX_STAMP_ARG) {
   using C = Cfg<N>;
-  constexpr int R = C::kFftRows;
+  constexpr int R = C::kFftRows, ROWS = C::kRows;
   constexpr int kWavesPerWG = C::kWavesPerWG, kThreads = C::kThreads, kTailFrames = C::kTailFrames;
   extern __shared__ float4 amcx_wave_smem[];
   char* smem = reinterpret_cast<char*>(amcx_wave_smem);
@@ -502,15 +508,14 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
     for (int g = 0; g < n_here; ++g) {
       asm volatile("; MARK load");
       AMCX_STAMP(7);
-      // ---- load: R x global_load_dwordx4, lane l gets samples 128 i + 2 l + {0,1}
+      // ---- load: kRows x global_load_dwordx4, lane l gets samples 128 i + 2 l + {0,1};
+      // every byte is read once -> non-temporal
       const float2* src = iq + (f0 + g) * row_stride + 2 * lane;
-      float xr[2 * R], xi[2 * R];
-      static_for<R>([&](auto ii) {
+      float xr[2 * ROWS], xi[2 * ROWS];
+      static_for<ROWS>([&](auto ii) {
         constexpr int i = decltype(ii)::value;
         typedef float v4f __attribute__((ext_vector_type(4)));
-        const v4f* p = reinterpret_cast<const v4f*>(src + 128 * i);
-        // read once -> non-temporal, except at N = 4096 where both halves are read again
-        const v4f v = C::kSplit ? *p : __builtin_nontemporal_load(p);
+        const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src + 128 * i));
         xr[2 * i] = v.x; xi[2 * i] = v.y; xr[2 * i + 1] = v.z; xi[2 * i + 1] = v.w;
       });
 
@@ -518,37 +523,28 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
       // statistics sweep
       // =====================================================================
       Stats S;
-      static_for<R>([&](auto ii) {
+      static_for<ROWS>([&](auto ii) {
         constexpr int i = decltype(ii)::value;
         float a0, a1;
-        S.template row<i == 0, (!C::kSplit && i == R - 1)>(xr[2 * i], xi[2 * i], xr[2 * i + 1], xi[2 * i + 1],
-                                                          lane, a0, a1);
+        S.template row<i == 0, i == ROWS - 1>(xr[2 * i], xi[2 * i], xr[2 * i + 1], xi[2 * i + 1], lane, a0, a1);
         if constexpr (!C::kSplit) {
           a_lds[(2 * i) * 64] = a0;
           a_lds[(2 * i + 1) * 64] = a1;
         }
       });
-      if constexpr (C::kSplit) {
-        // upper half: streamed through the same sweep while x <- x[n] + x[n+2048]
-        static_for<R>([&](auto ii) {
-          constexpr int i = decltype(ii)::value;
-          const float4 v = *reinterpret_cast<const float4*>(src + 128 * (R + i));
-          float a0, a1;
-          S.template row<false, i == R - 1>(v.x, v.y, v.z, v.w, lane, a0, a1);
-          xr[2 * i] += v.x; xi[2 * i] += v.y; xr[2 * i + 1] += v.z; xi[2 * i + 1] += v.w;
-        });
-      }
       asm volatile("; MARK envelope");
       AMCX_STAMP(0);
       __builtin_amdgcn_sched_barrier(0);
       // envelope second sweep about the exact mean
       const float mu = bcast_l63(wave_sum_l63(S.sa)) * (1.0f / (float)N);
-      if constexpr (!C::kSplit) {
-        static_for<2 * R>([&](auto ee) {
-          constexpr int e = decltype(ee)::value;
+      static_for<2 * ROWS>([&](auto ee) {
+        constexpr int e = decltype(ee)::value;
+        if constexpr (C::kSplit) {
+          S.envelope(__builtin_amdgcn_sqrtf(__builtin_fmaf(xr[e], xr[e], __builtin_fmaf(xi[e], xi[e], kTinyPower))), mu);
+        } else {
           S.envelope(a_lds[e * 64], mu);
-        });
-      }
+        }
+      });
 
       // =====================================================================
       // spectral peak
@@ -556,29 +552,31 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
       asm volatile("; MARK fft1");
       AMCX_STAMP(1);
       __builtin_amdgcn_sched_barrier(0);
-      float peak = fft_peak<R>(xr, xi, la);
-      if constexpr (C::kSplit) {
-        // second visit of both halves: envelope sweep, and the difference branch
-        // x <- (x[n] - x[n+2048]) * W_4096^n,  n = 128 i + 2 l + b,  W^n = W_32^i * W_4096^(2l+b)
+      float peak;
+      if constexpr (!C::kSplit) {
+        peak = fft_peak<R>(xr, xi, la);
+      } else {
+        // radix-2 DIF split: s = x[n] + x[n+2048],  d = (x[n] - x[n+2048]) * W_4096^n,
+        // n = 128 i + 2 l + b,  W_4096^n = W_32^i * W_4096^(2l+b)
         const float4 w4 = *reinterpret_cast<const float4*>(t4 + lane * 16);
+        float sr[2 * R], si[2 * R], dr[2 * R], di[2 * R];
         static_for<R>([&](auto ii) {
           constexpr int i = decltype(ii)::value;
-          const float4 lo = *reinterpret_cast<const float4*>(src + 128 * i);
-          const float4 hi = *reinterpret_cast<const float4*>(src + 128 * (R + i));
-          S.envelope(__builtin_amdgcn_sqrtf(__builtin_fmaf(lo.x, lo.x, lo.y * lo.y)), mu);
-          S.envelope(__builtin_amdgcn_sqrtf(__builtin_fmaf(lo.z, lo.z, lo.w * lo.w)), mu);
-          S.envelope(__builtin_amdgcn_sqrtf(__builtin_fmaf(hi.x, hi.x, hi.y * hi.y)), mu);
-          S.envelope(__builtin_amdgcn_sqrtf(__builtin_fmaf(hi.z, hi.z, hi.w * hi.w)), mu);
-          float d0r = lo.x - hi.x, d0i = lo.y - hi.y, d1r = lo.z - hi.z, d1i = lo.w - hi.w;
+          constexpr int lo = 2 * i, hi = 2 * (R + i);
+          sr[lo] = xr[lo] + xr[hi];             si[lo] = xi[lo] + xi[hi];
+          sr[lo + 1] = xr[lo + 1] + xr[hi + 1]; si[lo + 1] = xi[lo + 1] + xi[hi + 1];
+          float d0r = xr[lo] - xr[hi], d0i = xi[lo] - xi[hi];
+          float d1r = xr[lo + 1] - xr[hi + 1], d1i = xi[lo + 1] - xi[hi + 1];
           mul_w32<i>(d0r, d0i);
           mul_w32<i>(d1r, d1i);
-          xr[2 * i] = __builtin_fmaf(d0r, w4.x, -(d0i * w4.y));
-          xi[2 * i] = __builtin_fmaf(d0r, w4.y, d0i * w4.x);
-          xr[2 * i + 1] = __builtin_fmaf(d1r, w4.z, -(d1i * w4.w));
-          xi[2 * i + 1] = __builtin_fmaf(d1r, w4.w, d1i * w4.z);
+          dr[lo] = __builtin_fmaf(d0r, w4.x, -(d0i * w4.y));
+          di[lo] = __builtin_fmaf(d0r, w4.y, d0i * w4.x);
+          dr[lo + 1] = __builtin_fmaf(d1r, w4.z, -(d1i * w4.w));
+          di[lo + 1] = __builtin_fmaf(d1r, w4.w, d1i * w4.z);
         });
+        peak = fft_peak<R>(sr, si, la);
         __builtin_amdgcn_sched_barrier(0);
-        peak = __builtin_fmaxf(peak, fft_peak<R>(xr, xi, la));
+        peak = __builtin_fmaxf(peak, fft_peak<R>(dr, di, la));
       }
 
       // =====================================================================

@@ -97,13 +97,13 @@ def cpu_baseline(max_procs: int | None = None):
 
 
 # ----------------------------------------------------------------------------
-def _pmc_traffic(frames_per_launch: int):
-    """HBM bytes per launch from a committed PMC summary, if one matches."""
+def _pmc_traffic(frames_per_launch: int, frame_size: int):
+    """HBM bytes per launch from the newest committed PMC summary for this frame size, if any."""
     best = None
     for p in sorted((REPO / "profiles").glob("*pmc*.json")):
         try:
             d = json.loads(p.read_text())
-            if d.get("frame_size") == FRAME_SIZE and d.get("hbm_bytes_per_frame"):
+            if d.get("frame_size") == frame_size and d.get("hbm_bytes_per_frame"):
                 best = d["hbm_bytes_per_frame"] * frames_per_launch
         except Exception:
             continue
@@ -126,6 +126,15 @@ def _valu_note(frames_per_s: float):
         except Exception:
             continue
     return None
+
+
+def _config_label(frame_size, n_frames):
+    """Which BASELINE.json config the chosen shape is (the default run is configs[1])."""
+    if n_frames == N_FRAMES and frame_size == FRAME_SIZE:
+        return "BASELINE configs[1]"
+    if n_frames == N_FRAMES and frame_size == 4096:
+        return "BASELINE configs[2]"
+    return "not a BASELINE config"
 
 
 def main():
@@ -244,7 +253,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {
             "workload": f"{N_MODS} mods x {N_SNR} SNR x {args.frames} frames x {FS} samples "
-                        f"complex64 per GPU (BASELINE configs[1]), resident in HBM; one launch per step",
+                        f"complex64 per GPU ({_config_label(FS, args.frames)}), resident in HBM; one launch per step",
             "frames_per_gpu_per_step": frames_per_launch, "frame_size": FS,
             "kernel": _lib.kernel_name(FS, _lib.VARIANTS[args.variant]),
             "sharding": f"frames x{world}, no collective on the data path",
@@ -252,7 +261,7 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": _pmc_traffic(frames_per_launch) if FS == FRAME_SIZE else None,
+            "traffic": _pmc_traffic(frames_per_launch, FS),
             "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_ms": mean_launch_s * 1e3,
             "measured_read_peak_GBps": read_peak,
             "secondary": _valu_note(value / world) if FS == FRAME_SIZE else None,

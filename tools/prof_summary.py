@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 CSV output (tools/profile.sh) into a short text + JSON summary."""
-import csv, glob, json, os, sys
+import csv, glob, json, os, re, sys
 from collections import defaultdict
 
 out = sys.argv[1]
@@ -41,10 +41,12 @@ frames = int(os.environ.get("AMCX_PROFILE_FRAMES", 6 * 26 * 4096))
 for n, cs in summary["counters_mean_per_dispatch"].items():
     if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
         rd, wr = cs["FETCH_SIZE"] * 1024 * 2, cs["WRITE_SIZE"] * 1024
-        summary["pmc_traffic"] = {"kernel": n, "frame_size": 2048, "frames_per_launch": frames,
+        m = re.search(r"wave_kernel<(\d+)>", n)
+        fs = int(m.group(1)) if m else int(os.environ.get("AMCX_PROFILE_FRAME_SIZE", 2048))
+        summary["pmc_traffic"] = {"kernel": n, "frame_size": fs, "frames_per_launch": frames,
                                   "fetch_bytes_corrected": rd, "write_bytes": wr,
                                   "hbm_bytes_per_frame": (rd + wr) / frames,
-                                  "algorithmic_bytes_per_frame": 8 * 2048 + 72,
+                                  "algorithmic_bytes_per_frame": 8 * fs + 72,
                                   "note": "FETCH_SIZE x2 (gfx950 wide-read undercount), separate --pmc passes"}
 print(json.dumps(summary, indent=1))
 if "pmc_traffic" in summary:
