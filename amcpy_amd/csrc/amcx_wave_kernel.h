@@ -1,5 +1,5 @@
 // AMCX_VARIANT_WAVE: one wavefront (64 lanes) per frame, frame held in registers.
-// Instantiated for frame sizes 1024, 2048 and 4096.
+// Instantiated for the power-of-two frame sizes 128 ... 4096.
 //
 // Why not "one 256-thread workgroup per frame": this path is VALU/power-bound, not
 // HBM-bound (~107 fp32 VALU ops per sample), so the design
@@ -20,10 +20,12 @@
 // Index maps (verified against np.fft.fft with the LDS bank rules in
 // tools/wave_fft_model.py).  A frame is ROWS = N/128 rows of 128 samples:
 //   load     lane l, row i, b in {0,1}  <- x[128 i + 2 l + b]   (global_load_dwordx4, coalesced)
-// Register FFT of NF = 128 R points (R = 16 -> 2048, R = 8 -> 1024), NF = R * 16 * 8:
+// Register FFT of NF = 128 R points (R = 16 -> 2048, 8 -> 1024, 4 -> 512, 2 -> 256, 1 -> 128), NF = R * 16 * 8:
 //   pass 1   R-point DFT over i   -> k1 ; twiddle W_NF^((2l+b) k1)
 //   xchg 1   phases g = k1>>3:  LDS[kk*136 + b*68 + l] (kk = k1&7); reader lane l'
-//            (kk = l'>>3, n3 = l'&7) takes n2 = 0..15 at [kk*136 + (n3&1)*68 + 4 n2 + (n3>>1)]
+//            (kk = l'>>3, n3 = l'&7) takes n2 = 0..15 at [kk*136 + (n3&1)*68 + 4 n2 + (n3>>1)];
+//            for R < 8 only the lanes with kk < R carry bins, the others compute on stale
+//            LDS and are masked out of the peak
 //   pass 2   16-point DFT over n2 -> k2 ; twiddle W_128^(n3 k2)
 //   xchg 2   LDS[k2*65 + 8 kk + n3]; reader lane l'' (kk = l''>>3, k2 = (l''&7) + 8 j)
 //   pass 3   8-point DFT over n3  -> X[k1 + R k2 + 16 R k3]; only max |X|^2 is kept
@@ -54,11 +56,9 @@
 namespace amcx {
 namespace wave {
 
-constexpr int kFramesPerWave = 8;               // frames per wave per batch (finalised together)
 constexpr int kTailChunk = 2;                   // frames per grab over the last stretch of a workgroup's slice
 constexpr int kNumSums = 27;                    // reduced per-lane sums; the spectral peak rides in slot 27
 constexpr int kStashStride = 33;                // 32 floats used per frame; odd -> conflict-free column reads
-constexpr int kStashBytes = kFramesPerWave * kStashStride * 4;
 
 constexpr int kEx1StrideKK = 136, kEx1StrideB = 68;   // complex units (tools/wave_fft_model.py)
 constexpr int kEx2StrideK2 = 65;
@@ -67,8 +67,13 @@ constexpr int kT2Bytes = 15 * 8 * 8;                   // [k2-1][n3] complex
 
 template <int N>
 struct Cfg {
-  static_assert(N == 1024 || N == 2048 || N == 4096, "wave kernel frame sizes");
+  static_assert(N == 128 || N == 256 || N == 512 || N == 1024 || N == 2048 || N == 4096,
+                "wave kernel frame sizes");
   static constexpr bool kSplit = N == 4096;            // radix-2 DIF split in front of a 2048 FFT
+  // frames per wave per batch, finalised together one frame per lane: the fp64 algebra costs
+  // the same per batch whatever N is, so short frames come in larger batches
+  static constexpr int kFramesPerWave = N >= 1024 ? 8 : (N == 512 ? 16 : 32);
+  static constexpr int kStashBytes = kFramesPerWave * kStashStride * 4;
   // waves per workgroup = waves per CU: 3 per SIMD at 161-168 VGPRs, 2 per SIMD when the
   // frame alone takes 128 VGPRs (16 waves at N = 1024, 114 VGPRs, measured no faster: power-bound)
   static constexpr int kWavesPerWG = kSplit ? 8 : 12;
@@ -85,6 +90,7 @@ struct Cfg {
   static_assert(kLdsBytes <= 163840, "one workgroup per CU must fit in 160 KiB of LDS");
   // the envelope's second sweep reads |x| back from the exchange buffer, or, when the frame is too
   // large to park there, takes the square roots again from the registers
+  static_assert(kFramesPerWave <= 64, "one frame per lane in the finaliser");
   static_assert(kSplit || 2 * kRows * 64 * 4 <= kExchangeBytes, "|x| parking must fit the exchange buffer");
 };
 
@@ -316,6 +322,7 @@ struct LaneAddr {
   const char* ex1_r;
   char* ex2_w;
   const char* ex2_r;
+  bool live;          // (lane>>3) < R: this lane ends up with real bins (always true for R >= 8)
 };
 
 // Register FFT of 128*R points held as xr/xi[2*i+b] (see header); returns this
@@ -323,8 +330,9 @@ struct LaneAddr {
 template <int R>
 __device__ __forceinline__ float fft_peak(const float (&xr)[2 * R], const float (&xi)[2 * R],
                                           const LaneAddr& la) {
-  constexpr int LOG2R = R == 16 ? 4 : 3;
-  constexpr int PH = R / 8;
+  constexpr int LOG2R = R == 16 ? 4 : R == 8 ? 3 : R == 4 ? 2 : R == 2 ? 1 : 0;
+  constexpr int PH = R >= 8 ? R / 8 : 1;     // exchange phases of 8 k1 values
+  constexpr int KK = R >= 8 ? 8 : R;         // k1 values per phase
   // pass 1 (both b groups), twiddle T1, exchange 1
   float v0r[R], v0i[R], v1r[R], v1i[R];
   static_for<R>([&](auto ii) {
@@ -348,7 +356,7 @@ __device__ __forceinline__ float fft_peak(const float (&xr)[2 * R], const float 
   static_for<PH>([&](auto gg) {
     constexpr int gph = decltype(gg)::value;
     lds_wave_fence();
-    static_for<8>([&](auto kk_) {
+    static_for<KK>([&](auto kk_) {
       constexpr int kk = decltype(kk_)::value;
       constexpr int p = bitrev(8 * gph + kk, LOG2R);
       *reinterpret_cast<float2*>(la.ex1_w + (kk * kEx1StrideKK) * 8) = make_float2(v0r[p], v0i[p]);
@@ -402,6 +410,7 @@ __device__ __forceinline__ float fft_peak(const float (&xr)[2 * R], const float 
     });
   });
   lds_wave_fence();
+  if constexpr (R < 8) peak = la.live ? peak : 0.f;   // lanes whose k1 = lane>>3 does not exist
   return peak;
 }
 
@@ -413,6 +422,7 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
   using C = Cfg<N>;
   constexpr int R = C::kFftRows, ROWS = C::kRows;
   constexpr int kWavesPerWG = C::kWavesPerWG, kThreads = C::kThreads, kTailFrames = C::kTailFrames;
+  constexpr int kFramesPerWave = C::kFramesPerWave;
   extern __shared__ float4 amcx_wave_smem[];
   char* smem = reinterpret_cast<char*>(amcx_wave_smem);
   const int tid = threadIdx.x;
@@ -473,6 +483,7 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
   la.ex1_r = ex + (kkL * kEx1StrideKK + (n3L & 1) * kEx1StrideB + (n3L >> 1)) * 8;
   la.ex2_w = ex + lane * 8;
   la.ex2_r = ex + (n3L * kEx2StrideK2 + kkL * 8) * 8;   // (lane&7) is k2lo for the reader
+  la.live = kkL < R;
   float* const a_lds = reinterpret_cast<float*>(ex) + lane;   // |x| parked in the wave's LDS: [e][lane]
 
 #ifdef AMCX_WAVE_STAMPS
@@ -693,11 +704,14 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
 }  // namespace wave
 
 inline bool wave_supports(int frame_size) {
-  return frame_size == 1024 || frame_size == 2048 || frame_size == 4096;
+  return frame_size >= 128 && frame_size <= 4096 && (frame_size & (frame_size - 1)) == 0;
 }
 
 inline const char* wave_kernel_name(int frame_size) {
   switch (frame_size) {
+    case 128: return "amcx_features18_wave_kernel<128>";
+    case 256: return "amcx_features18_wave_kernel<256>";
+    case 512: return "amcx_features18_wave_kernel<512>";
     case 1024: return "amcx_features18_wave_kernel<1024>";
     case 2048: return "amcx_features18_wave_kernel<2048>";
     case 4096: return "amcx_features18_wave_kernel<4096>";
@@ -733,6 +747,9 @@ inline hipError_t launch_wave(const float2* iq, int64_t n_frames, int32_t frame_
                               int64_t row_stride, float* out, int64_t out_stride,
                               hipStream_t stream, int cus) {
   switch (frame_size) {
+    case 128: return launch_wave_n<128>(iq, n_frames, row_stride, out, out_stride, stream, cus);
+    case 256: return launch_wave_n<256>(iq, n_frames, row_stride, out, out_stride, stream, cus);
+    case 512: return launch_wave_n<512>(iq, n_frames, row_stride, out, out_stride, stream, cus);
     case 1024: return launch_wave_n<1024>(iq, n_frames, row_stride, out, out_stride, stream, cus);
     case 2048: return launch_wave_n<2048>(iq, n_frames, row_stride, out, out_stride, stream, cus);
     case 4096: return launch_wave_n<4096>(iq, n_frames, row_stride, out, out_stride, stream, cus);

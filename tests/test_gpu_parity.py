@@ -155,6 +155,25 @@ def test_variants_agree():
     assert scaled.max() <= TOL
 
 
+def test_wave_kernel_short_power_of_two_frames():
+    """N = 128, 256, 512: the register-FFT wave kernel with fewer rows per lane (for R < 8 only
+    lanes with lane>>3 < R hold bins) and 16/32-frame finaliser batches; frame counts chosen to
+    leave ragged batches and tail chunks.  Checked against the oracle and the block kernel."""
+    from amcpy_amd import synth, _lib
+    for N, F in ((128, 1531), (256, 777), (512, 403)):
+        assert "wave_kernel" in _lib.kernel_name(N, _lib.VARIANT_AUTO)
+        x = np.concatenate([synth.host_block(m, snr, F // 3 + 1, N, seed=N + i)
+                            for i, (m, snr) in enumerate((("BPSK", 0.0), ("16QAM", 12.0), ("WGN", -10.0)))])[:F]
+        gold = orc.features18_batch(x)
+        got = _run(x, "wave")
+        _assert_parity(got, gold, x, f"wave N={N}")
+        blk = _run(x, "block")
+        S = orc.conditioning_scales(x)
+        _, scaled = orc.parity_errors(got, blk, S)
+        assert scaled.max() <= 2e-5, (N, scaled.max(axis=0))
+        assert np.array_equal(_run(x, "auto"), got)
+
+
 def test_generic_sizes_block_kernel():
     """Frame sizes outside the fast set: non powers of two (direct DFT), tiny
     and odd lengths -- the reference accepts any N (np.fft.fft)."""
