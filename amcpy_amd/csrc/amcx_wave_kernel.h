@@ -74,6 +74,8 @@ struct Cfg {
   // the same per batch whatever N is, so short frames come in larger batches
   static constexpr int kFramesPerWave = N >= 1024 ? 8 : (N == 512 ? 16 : 32);
   static constexpr int kStashBytes = kFramesPerWave * kStashStride * 4;
+  // next frame of the chunk loaded into a second register set while this one is processed
+  static constexpr bool kPrefetch = N <= 1024;
   // waves per workgroup = waves per CU: 3 per SIMD at 161-168 VGPRs, 2 per SIMD when the
   // frame alone takes 128 VGPRs (16 waves at N = 1024, 114 VGPRs, measured no faster: power-bound)
   static constexpr int kWavesPerWG = kSplit ? 8 : 12;
@@ -516,19 +518,21 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
       }
     }
 
-    for (int g = 0; g < n_here; ++g) {
-      asm volatile("; MARK load");
-      AMCX_STAMP(7);
-      // ---- load: kRows x global_load_dwordx4, lane l gets samples 128 i + 2 l + {0,1};
-      // every byte is read once -> non-temporal
-      const float2* src = iq + (f0 + g) * row_stride + 2 * lane;
-      float xr[2 * ROWS], xi[2 * ROWS];
+    // lane l gets samples 128 i + 2 l + {0,1} of each row: kRows x global_load_dwordx4; every
+    // byte is read once -> non-temporal
+    auto load_frame = [&](float (&xr)[2 * ROWS], float (&xi)[2 * ROWS], long long f) {
+      const float2* src = iq + f * row_stride + 2 * lane;
       static_for<ROWS>([&](auto ii) {
         constexpr int i = decltype(ii)::value;
         typedef float v4f __attribute__((ext_vector_type(4)));
         const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src + 128 * i));
         xr[2 * i] = v.x; xi[2 * i] = v.y; xr[2 * i + 1] = v.z; xi[2 * i + 1] = v.w;
       });
+    };
+    // one frame, registers -> stash row g
+    auto frame = [&](const float (&xr)[2 * ROWS], const float (&xi)[2 * ROWS], int g) {
+      asm volatile("; MARK load");
+      AMCX_STAMP(7);
 
       // =====================================================================
       // statistics sweep
@@ -665,6 +669,28 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
           row[kNumSums + 3] = S.Ka;
           row[kNumSums + 4] = S.tie != 0 ? 1.0f : 0.0f;
         }
+      }
+    };
+
+    if constexpr (C::kPrefetch) {
+      // short frames: the load latency at the head of every frame is a large share of the
+      // frame, and there are registers to spare -- ping-pong between two register sets, the
+      // next frame of the chunk in flight while this one is worked on
+      float ar[2 * ROWS], ai[2 * ROWS], br[2 * ROWS], bi[2 * ROWS];
+      load_frame(ar, ai, f0);
+      for (int g = 0; g < n_here; g += 2) {
+        if (g + 1 < n_here) load_frame(br, bi, f0 + g + 1);
+        frame(ar, ai, g);
+        if (g + 1 < n_here) {
+          if (g + 2 < n_here) load_frame(ar, ai, f0 + g + 2);
+          frame(br, bi, g + 1);
+        }
+      }
+    } else {
+      for (int g = 0; g < n_here; ++g) {
+        float xr[2 * ROWS], xi[2 * ROWS];
+        load_frame(xr, xi, f0 + g);
+        frame(xr, xi, g);
       }
     }
 
