@@ -54,11 +54,15 @@ __device__ __forceinline__ float fast_angle(float re, float im, float a) {
 }
 
 // diff(unwrap(theta))[i] from two neighbouring angles: d - 2*pi*rint(d/2pi),
-// half-to-even (v_rndne_f32) reproduces numpy's tie rule since |d| <= 2*pi
+// half-to-even reproduces numpy's tie rule since |d| <= 2*pi
 // (reference features.py:29-30 -> np.unwrap/np.diff).
+// rint is spelled (t + 1.5*2^23) - 1.5*2^23 -- an fma and a subtract on the
+// full-rate fp32 pipe instead of v_rndne_f32, which issues at 2/3 of that rate
+// (profiles/r1_valu_issue_rates.txt); exact for |t| < 2^22, and |t| < 1 here.
 __device__ __forceinline__ float wrapped_step(float th_next, float th) {
+  constexpr float kMagic = 12582912.0f;
   const float d = th_next - th;
-  const float k = __builtin_rintf(d * kInvTwoPi);
+  const float k = __builtin_fmaf(d, kInvTwoPi, kMagic) - kMagic;
   return __builtin_fmaf(-kTwoPi, k, d);
 }
 

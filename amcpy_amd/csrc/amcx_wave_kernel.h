@@ -235,10 +235,9 @@ struct Stats {
   float Kt = 0, Kw = 0, Ka = 0;
   float th_b1_prev = 0;   // angle of sample (i-1, b=1), waiting for its right neighbour
   float rot_prev = 0;     // wave_rol1(angle(i-1, b=0))
-  unsigned long long tie = 0;   // wave-uniform: lanes that saw a step within kTieBand of +-pi
+  float wmax = 0;         // largest |step| this lane saw: > pi - kTieBand flags the frame (kTieBand)
 
   __device__ __forceinline__ void step(float w) {
-    tie |= __builtin_amdgcn_ballot_w64(__builtin_fabsf(w) > kPi - kTieBand);   // v_cmp + s_or
     const float d = w - Kw, d2 = d * d;
     sw1 += d; sw2 += d2;
     sw3 = __builtin_fmaf(d2, d, sw3);
@@ -292,17 +291,24 @@ struct Stats {
       sab1 += e;
       sab2 = __builtin_fmaf(e, e, sab2);
     });
-    step(wrapped_step(th[1], th[0]));                     // sample (i,0) -> (i,1), same lane
+    const float wa = wrapped_step(th[1], th[0]);          // sample (i,0) -> (i,1), same lane
+    step(wa);
     const float rot = dpp<kWaveRol1>(th[0]);              // lane l: angle(i,0) of lane l+1 (63 -> lane 0)
     if constexpr (!FIRST) {
       // right neighbour of (i-1, b=1) is (i-1, b=0) of lane l+1, or (i, b=0) of lane 0 for lane 63
       const float nxt = (lane == 63) ? rot : rot_prev;
-      step(wrapped_step(nxt, th_b1_prev));
+      const float wb = wrapped_step(nxt, th_b1_prev);
+      step(wb);
+      wmax = __builtin_fmaxf(__builtin_fmaxf(wmax, __builtin_fabsf(wa)), __builtin_fabsf(wb));   // one v_max3
+    } else {
+      wmax = __builtin_fabsf(wa);
     }
     if constexpr (LAST) {
       // (last row, b=1): lane 63 holds the frame's last sample, which has no step
       const float w = wrapped_step(rot, th[1]);
-      step(lane == 63 ? Kw : w);
+      const float wc = lane == 63 ? Kw : w;
+      step(wc);
+      wmax = __builtin_fmaxf(wmax, __builtin_fabsf(wc));
     }
     th_b1_prev = th[1];
     rot_prev = rot;
@@ -562,40 +568,8 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
       });
 
       // =====================================================================
-      // spectral peak
-      // =====================================================================
-      asm volatile("; MARK fft1");
-      AMCX_STAMP(1);
-      __builtin_amdgcn_sched_barrier(0);
-      float peak;
-      if constexpr (!C::kSplit) {
-        peak = fft_peak<R>(xr, xi, la);
-      } else {
-        // radix-2 DIF split: s = x[n] + x[n+2048],  d = (x[n] - x[n+2048]) * W_4096^n,
-        // n = 128 i + 2 l + b,  W_4096^n = W_32^i * W_4096^(2l+b)
-        const float4 w4 = *reinterpret_cast<const float4*>(t4 + lane * 16);
-        float sr[2 * R], si[2 * R], dr[2 * R], di[2 * R];
-        static_for<R>([&](auto ii) {
-          constexpr int i = decltype(ii)::value;
-          constexpr int lo = 2 * i, hi = 2 * (R + i);
-          sr[lo] = xr[lo] + xr[hi];             si[lo] = xi[lo] + xi[hi];
-          sr[lo + 1] = xr[lo + 1] + xr[hi + 1]; si[lo + 1] = xi[lo + 1] + xi[hi + 1];
-          float d0r = xr[lo] - xr[hi], d0i = xi[lo] - xi[hi];
-          float d1r = xr[lo + 1] - xr[hi + 1], d1i = xi[lo + 1] - xi[hi + 1];
-          mul_w32<i>(d0r, d0i);
-          mul_w32<i>(d1r, d1i);
-          dr[lo] = __builtin_fmaf(d0r, w4.x, -(d0i * w4.y));
-          di[lo] = __builtin_fmaf(d0r, w4.y, d0i * w4.x);
-          dr[lo + 1] = __builtin_fmaf(d1r, w4.z, -(d1i * w4.w));
-          di[lo + 1] = __builtin_fmaf(d1r, w4.w, d1i * w4.z);
-        });
-        peak = fft_peak<R>(sr, si, la);
-        __builtin_amdgcn_sched_barrier(0);
-        peak = __builtin_fmaxf(peak, fft_peak<R>(dr, di, la));
-      }
-
-      // =====================================================================
-      // wave reduction of the 27 sums + peak -> stash row g
+      // wave reduction of the 27 sums -> stash row g, before the FFT so that the sums'
+      // registers are free while it runs
       // =====================================================================
       asm volatile("; MARK reduce");
       AMCX_STAMP(3);
@@ -651,25 +625,58 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
         v += dpp<kRowMirror>(v);
         r7[j] = v;
       });
-      const float pk = wave_max_l63(peak);
-      {
-        float* row = stash + g * kStashStride;
-        if ((lane & 15) == 0) {                    // one lane per row: rows hold 4j + {0, 2, 1, 3}
-          const int rsel = lane >> 4;
-          float* dst = row + (((rsel & 1) << 1) | (rsel >> 1));
-          static_for<7>([&](auto jj) {
-            constexpr int j = decltype(jj)::value;
-            dst[4 * j] = r7[j];
-          });
-        }
-        if (lane == 63) {
-          row[kNumSums] = pk;                      // overwrites the zero pad slot 27
-          row[kNumSums + 1] = S.Kt;
-          row[kNumSums + 2] = S.Kw;
-          row[kNumSums + 3] = S.Ka;
-          row[kNumSums + 4] = S.tie != 0 ? 1.0f : 0.0f;
-        }
+      const unsigned long long tie = __builtin_amdgcn_ballot_w64(S.wmax > kPi - kTieBand);
+      float* const row = stash + g * kStashStride;
+      if ((lane & 15) == 0) {                    // one lane per row: rows hold 4j + {0, 2, 1, 3}
+        const int rsel = lane >> 4;
+        float* dst = row + (((rsel & 1) << 1) | (rsel >> 1));
+        static_for<7>([&](auto jj) {
+          constexpr int j = decltype(jj)::value;
+          dst[4 * j] = r7[j];
+        });
       }
+      if (lane == 63) {
+        row[kNumSums + 1] = S.Kt;
+        row[kNumSums + 2] = S.Kw;
+        row[kNumSums + 3] = S.Ka;
+        row[kNumSums + 4] = tie != 0 ? 1.0f : 0.0f;
+      }
+
+      // =====================================================================
+      // spectral peak
+      // =====================================================================
+      asm volatile("; MARK fft1");
+      AMCX_STAMP(1);
+      __builtin_amdgcn_sched_barrier(0);
+      float peak;
+      if constexpr (!C::kSplit) {
+        peak = fft_peak<R>(xr, xi, la);
+      } else {
+        // radix-2 DIF split: s = x[n] + x[n+2048],  d = (x[n] - x[n+2048]) * W_4096^n,
+        // n = 128 i + 2 l + b,  W_4096^n = W_32^i * W_4096^(2l+b)
+        const float4 w4 = *reinterpret_cast<const float4*>(t4 + lane * 16);
+        float sr[2 * R], si[2 * R], dr[2 * R], di[2 * R];
+        static_for<R>([&](auto ii) {
+          constexpr int i = decltype(ii)::value;
+          constexpr int lo = 2 * i, hi = 2 * (R + i);
+          sr[lo] = xr[lo] + xr[hi];             si[lo] = xi[lo] + xi[hi];
+          sr[lo + 1] = xr[lo + 1] + xr[hi + 1]; si[lo + 1] = xi[lo + 1] + xi[hi + 1];
+          float d0r = xr[lo] - xr[hi], d0i = xi[lo] - xi[hi];
+          float d1r = xr[lo + 1] - xr[hi + 1], d1i = xi[lo + 1] - xi[hi + 1];
+          mul_w32<i>(d0r, d0i);
+          mul_w32<i>(d1r, d1i);
+          dr[lo] = __builtin_fmaf(d0r, w4.x, -(d0i * w4.y));
+          di[lo] = __builtin_fmaf(d0r, w4.y, d0i * w4.x);
+          dr[lo + 1] = __builtin_fmaf(d1r, w4.z, -(d1i * w4.w));
+          di[lo + 1] = __builtin_fmaf(d1r, w4.w, d1i * w4.z);
+        });
+        peak = fft_peak<R>(sr, si, la);
+        __builtin_amdgcn_sched_barrier(0);
+        peak = __builtin_fmaxf(peak, fft_peak<R>(dr, di, la));
+      }
+
+      const float pk = wave_max_l63(peak);
+      if (lane == 63) row[kNumSums] = pk;        // overwrites the zero pad slot 27 (LDS ops of a wave are in order)
     };
 
     if constexpr (C::kPrefetch) {
