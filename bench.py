@@ -122,6 +122,8 @@ def _valu_note(frames_per_s: float):
                     return {"bound": "valu-issue/power", "valu_instr_per_frame": per_frame,
                             "achieved_Gwaveinstr_per_s": per_frame * frames_per_s / 1e9,
                             "plain_fma_stream_Gwaveinstr_per_s": 890.0,
+                            "board_power": "1370 W of the 1400 W cap, sclk 2.0 of 2.4 GHz while this kernel "
+                                           "loops (profiles/r1e_power_watch.txt)",
                             "source": f"profiles/{p.name}; profiles/r1_valu_issue_rates.txt (3 waves/SIMD)"}
         except Exception:
             continue
