@@ -56,7 +56,6 @@
 namespace amcx {
 namespace wave {
 
-constexpr int kTailChunk = 2;                   // frames per grab over the last stretch of a workgroup's slice
 constexpr int kNumSums = 27;                    // reduced per-lane sums; the spectral peak rides in slot 27
 constexpr int kStashStride = 33;                // 32 floats used per frame; odd -> conflict-free column reads
 
@@ -76,6 +75,12 @@ struct Cfg {
   static constexpr int kStashBytes = kFramesPerWave * kStashStride * 4;
   // next frame of the chunk loaded into a second register set while this one is processed
   static constexpr bool kPrefetch = N <= 1024;
+  // short frames (R < 8 rows) fill only R of the 8 k1 slots of exchange 1, so kGroup = 8/R
+  // consecutive frames share one run of FFT passes 2 and 3: frame j's k1 goes to slot j R + k1,
+  // its bins come out in lanes [8 R j, 8 R (j+1))
+  static constexpr int kGroup = N < 1024 ? 1024 / N : 1;
+  // frames per grab over the last stretch of a workgroup's slice (levels the waves' finish)
+  static constexpr int kTailChunk = kGroup > 2 ? kGroup : 2;
   // waves per workgroup = waves per CU: 3 per SIMD at 161-168 VGPRs, 2 per SIMD when the
   // frame alone takes 128 VGPRs (16 waves at N = 1024, 114 VGPRs, measured no faster: power-bound)
   static constexpr int kWavesPerWG = kSplit ? 8 : 12;
@@ -422,6 +427,88 @@ __device__ __forceinline__ float fft_peak(const float (&xr)[2 * R], const float 
   return peak;
 }
 
+// The same machine in two halves for R < 8 (one exchange phase), so that 8/R frames can share
+// the second half.  fft_front: pass 1 + twiddle + exchange-1 write of one frame into k1 slots
+// [SLOT0, SLOT0 + R).
+template <int R, int SLOT0>
+__device__ __forceinline__ void fft_front(const float (&xr)[2 * R], const float (&xi)[2 * R],
+                                          const LaneAddr& la) {
+  static_assert(R < 8 && SLOT0 + R <= 8, "one exchange phase");
+  constexpr int LOG2R = R == 4 ? 2 : R == 2 ? 1 : 0;
+  float v0r[R], v0i[R], v1r[R], v1i[R];
+  static_for<R>([&](auto ii) {
+    constexpr int i = decltype(ii)::value;
+    v0r[i] = xr[2 * i]; v0i[i] = xi[2 * i]; v1r[i] = xr[2 * i + 1]; v1i[i] = xi[2 * i + 1];
+  });
+  dif<R, 0>(v0r, v0i);
+  dif<R, 0>(v1r, v1i);
+  static_for<R - 1>([&](auto kk1) {
+    constexpr int k1 = decltype(kk1)::value + 1;
+    constexpr int p = bitrev(k1, LOG2R);
+    const float4 t = *reinterpret_cast<const float4*>(la.t1 + (k1 - 1) * 1024);
+    float r = v0r[p], im = v0i[p];
+    v0r[p] = __builtin_fmaf(r, t.x, -(im * t.y));
+    v0i[p] = __builtin_fmaf(r, t.y, im * t.x);
+    r = v1r[p]; im = v1i[p];
+    v1r[p] = __builtin_fmaf(r, t.z, -(im * t.w));
+    v1i[p] = __builtin_fmaf(r, t.w, im * t.z);
+  });
+  static_for<R>([&](auto kk_) {
+    constexpr int k1 = decltype(kk_)::value;
+    constexpr int p = bitrev(k1, LOG2R);
+    constexpr int kk = SLOT0 + k1;
+    *reinterpret_cast<float2*>(la.ex1_w + (kk * kEx1StrideKK) * 8) = make_float2(v0r[p], v0i[p]);
+    *reinterpret_cast<float2*>(la.ex1_w + (kk * kEx1StrideKK + kEx1StrideB) * 8) = make_float2(v1r[p], v1i[p]);
+  });
+}
+
+// fft_back: exchange-1 read, pass 2, exchange 2, pass 3 over all eight k1 slots at once;
+// returns this lane's max |X|^2 over its 16 bins (of the frame that owns slot lane>>3)
+__device__ __forceinline__ float fft_back(const LaneAddr& la) {
+  float zr[16], zi[16];
+  lds_wave_fence();
+  static_for<16>([&](auto nn) {
+    constexpr int n2 = decltype(nn)::value;
+    const float2 v = *reinterpret_cast<const float2*>(la.ex1_r + n2 * 32);
+    zr[n2] = v.x; zi[n2] = v.y;
+  });
+  asm volatile("; MARK fft2");
+  __builtin_amdgcn_sched_barrier(0);
+  dif<16, 0>(zr, zi);
+  static_for<15>([&](auto kk2) {
+    constexpr int k2 = decltype(kk2)::value + 1;
+    constexpr int p = bitrev(k2, 4);
+    const float2 t = *reinterpret_cast<const float2*>(la.t2 + (k2 - 1) * 64);
+    const float r = zr[p], im = zi[p];
+    zr[p] = __builtin_fmaf(r, t.x, -(im * t.y));
+    zi[p] = __builtin_fmaf(r, t.y, im * t.x);
+  });
+  float peak = 0.f;
+  lds_wave_fence();
+  static_for<16>([&](auto kk2) {
+    constexpr int k2 = decltype(kk2)::value;
+    constexpr int p = bitrev(k2, 4);
+    *reinterpret_cast<float2*>(la.ex2_w + (k2 * kEx2StrideK2) * 8) = make_float2(zr[p], zi[p]);
+  });
+  lds_wave_fence();
+  static_for<2>([&](auto jj) {
+    constexpr int j = decltype(jj)::value;
+    float ur[8], ui[8];
+    static_for<8>([&](auto nn) {
+      constexpr int n3 = decltype(nn)::value;
+      const float2 v = *reinterpret_cast<const float2*>(la.ex2_r + (j * 8 * kEx2StrideK2 + n3) * 8);
+      ur[n3] = v.x; ui[n3] = v.y;
+    });
+    dif<8, 0>(ur, ui);
+    static_for<8>([&](auto pp) {
+      constexpr int p = decltype(pp)::value;
+      peak = __builtin_fmaxf(peak, __builtin_fmaf(ur[p], ur[p], ui[p] * ui[p]));
+    });
+  });
+  lds_wave_fence();
+  return peak;
+}
+
 // ---------------------------------------------------------------------------
 template <int N>
 __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amcx_features18_wave_kernel(
@@ -430,7 +517,7 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
   using C = Cfg<N>;
   constexpr int R = C::kFftRows, ROWS = C::kRows;
   constexpr int kWavesPerWG = C::kWavesPerWG, kThreads = C::kThreads, kTailFrames = C::kTailFrames;
-  constexpr int kFramesPerWave = C::kFramesPerWave;
+  constexpr int kFramesPerWave = C::kFramesPerWave, kTailChunk = C::kTailChunk;
   extern __shared__ float4 amcx_wave_smem[];
   char* smem = reinterpret_cast<char*>(amcx_wave_smem);
   const int tid = threadIdx.x;
@@ -536,7 +623,10 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
       });
     };
     // one frame, registers -> stash row g
-    auto frame = [&](const float (&xr)[2 * ROWS], const float (&xi)[2 * ROWS], int g) {
+    // (SLOT: for grouped short frames, which eighth of exchange 1 this frame's FFT front fills)
+    auto frame = [&](const float (&xr)[2 * ROWS], const float (&xi)[2 * ROWS], int g, auto slot_tag) {
+      constexpr int SLOT = decltype(slot_tag)::value;
+      constexpr bool kAInRegs = C::kGroup > 1;   // |x| stays in registers: exchange 1 is shared by the group
       asm volatile("; MARK load");
       AMCX_STAMP(7);
 
@@ -544,11 +634,15 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
       // statistics sweep
       // =====================================================================
       Stats S;
+      float av[kAInRegs ? 2 * ROWS : 1];
       static_for<ROWS>([&](auto ii) {
         constexpr int i = decltype(ii)::value;
         float a0, a1;
         S.template row<i == 0, i == ROWS - 1>(xr[2 * i], xi[2 * i], xr[2 * i + 1], xi[2 * i + 1], lane, a0, a1);
-        if constexpr (!C::kSplit) {
+        if constexpr (kAInRegs) {
+          av[2 * i] = a0;
+          av[2 * i + 1] = a1;
+        } else if constexpr (!C::kSplit) {
           a_lds[(2 * i) * 64] = a0;
           a_lds[(2 * i + 1) * 64] = a1;
         }
@@ -560,7 +654,9 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
       const float mu = bcast_l63(wave_sum_l63(S.sa)) * (1.0f / (float)N);
       static_for<2 * ROWS>([&](auto ee) {
         constexpr int e = decltype(ee)::value;
-        if constexpr (C::kSplit) {
+        if constexpr (kAInRegs) {
+          S.envelope(av[e], mu);
+        } else if constexpr (C::kSplit) {
           S.envelope(__builtin_amdgcn_sqrtf(__builtin_fmaf(xr[e], xr[e], __builtin_fmaf(xi[e], xi[e], kTinyPower))), mu);
         } else {
           S.envelope(a_lds[e * 64], mu);
@@ -649,7 +745,10 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
       AMCX_STAMP(1);
       __builtin_amdgcn_sched_barrier(0);
       float peak;
-      if constexpr (!C::kSplit) {
+      if constexpr (C::kGroup > 1) {
+        fft_front<R, SLOT * R>(xr, xi, la);     // the group's shared back half follows the last frame
+        return;
+      } else if constexpr (!C::kSplit) {
         peak = fft_peak<R>(xr, xi, la);
       } else {
         // radix-2 DIF split: s = x[n] + x[n+2048],  d = (x[n] - x[n+2048]) * W_4096^n,
@@ -679,7 +778,38 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
       if (lane == 63) row[kNumSums] = pk;        // overwrites the zero pad slot 27 (LDS ops of a wave are in order)
     };
 
-    if constexpr (C::kPrefetch) {
+    using Slot0 = std::integral_constant<int, 0>;
+    if constexpr (C::kGroup > 1) {
+      // short frames, ping-pong prefetch as below, kGroup frames per run of FFT passes 2-3
+      constexpr int G = C::kGroup;
+      float ar[2 * ROWS], ai[2 * ROWS], br[2 * ROWS], bi[2 * ROWS];
+      load_frame(ar, ai, f0);
+      for (int g = 0; g < n_here; g += G) {
+        lds_wave_fence();                       // the previous group's exchange reads are done
+        static_for<G / 2>([&](auto jj) {
+          constexpr int j0 = 2 * decltype(jj)::value, j1 = j0 + 1;
+          if (g + j0 < n_here) {
+            if (g + j1 < n_here) load_frame(br, bi, f0 + g + j1);
+            frame(ar, ai, g + j0, std::integral_constant<int, j0>{});
+          }
+          if (g + j1 < n_here) {
+            if (g + j1 + 1 < n_here) load_frame(ar, ai, f0 + g + j1 + 1);
+            frame(br, bi, g + j1, std::integral_constant<int, j1>{});
+          }
+        });
+        // lanes [8 R j, 8 R (j+1)) hold frame j's bins (slots of frames that do not exist hold
+        // stale data and are not written back)
+        float pk = fft_back(la);
+        pk = __builtin_fmaxf(pk, dpp<kQuadXor1>(pk));
+        pk = __builtin_fmaxf(pk, dpp<kQuadXor2>(pk));
+        pk = __builtin_fmaxf(pk, dpp<kRowHalfMirror>(pk));
+        if constexpr (R >= 2) pk = __builtin_fmaxf(pk, dpp<kRowMirror>(pk));
+        if constexpr (R >= 4) pk = __builtin_fmaxf(pk, dpp<kRowBcast15, 0xa, 0xf, false>(pk));
+        const int j = lane / (8 * R);
+        if ((lane & (8 * R - 1)) == 8 * R - 1 && g + j < n_here)
+          stash[(g + j) * kStashStride + kNumSums] = pk;    // over the zero pad slot 27
+      }
+    } else if constexpr (C::kPrefetch) {
       // short frames: the load latency at the head of every frame is a large share of the
       // frame, and there are registers to spare -- ping-pong between two register sets, the
       // next frame of the chunk in flight while this one is worked on
@@ -687,17 +817,17 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
       load_frame(ar, ai, f0);
       for (int g = 0; g < n_here; g += 2) {
         if (g + 1 < n_here) load_frame(br, bi, f0 + g + 1);
-        frame(ar, ai, g);
+        frame(ar, ai, g, Slot0{});
         if (g + 1 < n_here) {
           if (g + 2 < n_here) load_frame(ar, ai, f0 + g + 2);
-          frame(br, bi, g + 1);
+          frame(br, bi, g + 1, Slot0{});
         }
       }
     } else {
       for (int g = 0; g < n_here; ++g) {
         float xr[2 * ROWS], xi[2 * ROWS];
         load_frame(xr, xi, f0 + g);
-        frame(xr, xi, g);
+        frame(xr, xi, g, Slot0{});
       }
     }
 
