@@ -58,7 +58,8 @@ extern "C" {
 #define AMCX_VARIANT_WAVE 2     /* one wavefront per frame, frame held in registers,
                                    register radix-16/8 FFT with LDS exchanges, followed by a
                                    small fix-up launch for frames with a phase step within
-                                   an fp32 ulp of +-pi; frame_size in {1024, 2048, 4096} */
+                                   an fp32 ulp of +-pi; frame_size a power of two,
+                                   128 ... 4096 */
 
 #define AMCX_MIN_FRAME_SIZE 2
 #define AMCX_MAX_FRAME_SIZE 8192
