@@ -20,7 +20,7 @@ SOURCES = [HERE / "amcx.hip"]
 HEADERS = sorted(HERE.glob("*.h")) + [HERE.parents[1] / "include" / "amcx.h"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-         "-ffp-contract=fast", "-fno-math-errno", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function",
+         "-ffp-contract=off", "-fno-math-errno", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function",
          "-Wl,-rpath,/opt/rocm/lib", "-Wl,-soname,libamcx.so"]
 
 

@@ -10,6 +10,8 @@ stored float32); the cancellation-dominated cumulants 10, 12-18 within
 those ids by up to 8.5e-3, so plain relative error is
 reported, not asserted, for them.
 """
+import os
+from pathlib import Path
 import numpy as np
 import pytest
 
@@ -304,6 +306,77 @@ def test_run_extraction_roundtrip_on_gpu(tmp_path):
         x = g[f"in_{m}"][:, :, :fs].reshape(-1, fs)
         _assert_parity(arr.reshape(-1, 18), g[f"out_{m}"].reshape(-1, 18).astype(np.float64), x,
                        f"run_extraction {m}")
+
+
+_RANK_WORKER = """
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["AMCX_REPO"])
+import torch, torch.distributed as dist
+from pathlib import Path
+from amcpy_amd.config import Config, Paths, SignalConfig
+from amcpy_amd.feature_extraction import run_extraction
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)                      # one GPU on the box: both ranks compute on it
+dist.init_process_group("gloo", rank=rank, world_size=world)
+cfg = Config(paths=Paths(root=Path(os.environ["AMCX_ROOT"])),
+             signals=SignalConfig(snr_values={0: "0", 1: "10"}, num_frames=int(os.environ["AMCX_NFRAMES"]),
+                                  frame_size=int(os.environ["AMCX_FS"])))
+run_extraction(cfg, verbose=False)
+dist.barrier()
+dist.destroy_process_group()
+print("RANK_DONE", rank)
+"""
+
+
+def test_two_ranks_run_extraction_sharded(tmp_path):
+    """The N>1 path end to end with the real engine: two processes under torch.distributed
+    (gloo rendezvous -- the box has one GPU, which both ranks compute on), each taking its
+    contiguous half of every modulation's frames; rank 0 gathers and writes the .mat files,
+    which must equal the single-process result bit for bit."""
+    import socket
+    import subprocess
+    import sys
+    import scipy.io
+    from amcpy_amd.config import Config, Paths, SignalConfig
+    from amcpy_amd.feature_extraction import run_extraction
+    g = load_npz("extract_roundtrip.npz")
+    fs, n_frames = int(g["frame_size"]), int(g["n_frames"])
+    mods = [str(m) for m in g["mods"]]
+    roots = {k: tmp_path / k for k in ("single", "sharded")}
+    for root in roots.values():
+        cfg = Config(paths=Paths(root=root),
+                     signals=SignalConfig(snr_values={0: "0", 1: "10"}, num_frames=n_frames, frame_size=fs))
+        cfg.paths.ensure_dirs()
+        scipy.io.savemat(str(cfg.paths.mat_data / cfg.paths.mat_filename),
+                         {cfg.signals.mat_info[m]: g[f"in_{m}"].astype(np.complex128) for m in mods})
+    run_extraction(Config(paths=Paths(root=roots["single"]),
+                          signals=SignalConfig(snr_values={0: "0", 1: "10"}, num_frames=n_frames, frame_size=fs)),
+                   verbose=False)
+    script = tmp_path / "rank_worker.py"
+    script.write_text(_RANK_WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    repo = str(Path(__file__).resolve().parents[1])
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), AMCX_REPO=repo, AMCX_ROOT=str(roots["sharded"]),
+                   AMCX_NFRAMES=str(n_frames), AMCX_FS=str(fs), PYTHONDONTWRITEBYTECODE="1",
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    cfg = Config(paths=Paths(root=roots["single"]))
+    for m in mods:
+        a = scipy.io.loadmat(str(roots["single"] / "calculated-features" / f"{m}_features.mat"))
+        b = scipy.io.loadmat(str(roots["sharded"] / "calculated-features" / f"{m}_features.mat"))
+        key = cfg.signals.mat_info[m]
+        assert a[key].shape == b[key].shape == (2, n_frames, 18)
+        diff = np.argwhere(a[key] != b[key])
+        assert diff.size == 0, (m, diff[:5], a[key][tuple(diff[0])], b[key][tuple(diff[0])])
 
 
 def test_odd_row_stride_and_ragged_counts():

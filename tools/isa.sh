@@ -3,7 +3,7 @@
 set -e
 B=/root/repo/amcpy_amd/csrc/build
 mkdir -p $B && cd $B
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=fast -fno-math-errno -fno-slp-vectorize $EXTRA \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-math-errno -fno-slp-vectorize $EXTRA \
   -save-temps -Rpass-analysis=kernel-resource-usage ../amcx.hip -o $B/libamcx_tmp.so 2> $B/remarks.txt || { grep -E "error" -A5 $B/remarks.txt; exit 1; }
 grep -A14 "wave_kernelILi" $B/remarks.txt | grep -E "Function Name|VGPRs|Scratch|Occupancy|SGPRs:" | sed 's/\[-Rpass.*//'
 for k in $(grep -o "_ZN4amcx4wave27amcx_features18_wave_kernelILi[0-9]*E[A-Za-z0-9_]*" amcx-hip-amdgcn-amd-amdhsa-gfx950.s | sort -u); do

@@ -1,7 +1,7 @@
 // Diagnostic: where does a wave of amcx_features18_wave_kernel spend its cycles?
 // Builds the kernel with in-kernel s_memtime stamps (shares of each section; the
 // stamped build's run time itself is not a benchmark).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast -fno-slp-vectorize tools/wave_stamps.hip -o tools/wave_stamps
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize tools/wave_stamps.hip -o tools/wave_stamps
 #define AMCX_WAVE_STAMPS 1
 #include "../amcpy_amd/csrc/amcx_wave_kernel.h"
 #include <stdio.h>
