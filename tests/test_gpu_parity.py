@@ -174,6 +174,22 @@ def test_wave_kernel_short_power_of_two_frames():
         _, scaled = orc.parity_errors(got, blk, S)
         assert scaled.max() <= 2e-5, (N, scaled.max(axis=0))
         assert np.array_equal(_run(x, "auto"), got)
+        # a frame's 18 floats depend on its samples only, not on which copy of the frame body
+        # (ping-pong register set, exchange slot) or which batch it lands in
+        perm = np.random.default_rng(N).permutation(F)
+        assert np.array_equal(_run(x[perm], "wave"), got[perm]), N
+
+
+def test_results_do_not_depend_on_batch_position():
+    """Same property for the long-frame variants and the block kernel."""
+    from amcpy_amd import synth
+    for N, F in ((1024, 301), (2048, 203), (4096, 101), (100, 57)):
+        x = synth.host_block("64QAM", 8.0, F, N, seed=N)
+        perm = np.random.default_rng(N).permutation(F)
+        for variant in _variants_for(N):
+            a = _run(x, variant)
+            assert np.array_equal(_run(x[perm], variant), a[perm]), (N, variant)
+            assert np.array_equal(_run(x[: F // 3], variant), a[: F // 3]), (N, variant)
 
 
 def test_generic_sizes_block_kernel():
