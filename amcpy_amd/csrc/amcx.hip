@@ -55,11 +55,20 @@ int cu_count() {
   return cus;
 }
 
+// spectral-term variant of the block kernel for this frame size
+int block_mode(int N) {
+  if (is_pow2(N)) return amcx::kBlockPow2;
+  return (N >= amcx::kBluesteinMinN && N <= amcx::kBluesteinMaxN) ? amcx::kBlockBluestein : amcx::kBlockDirect;
+}
+
 int launch_block(const float2* iq, int64_t n_frames, int32_t N, int64_t row_stride, float* out,
                  int64_t out_stride, hipStream_t stream) {
-  const size_t lds = (size_t)16 * N + sizeof(double) * amcx::kBlockWaves * amcx::kMaxReduce;
-  auto kern = is_pow2(N) ? amcx::amcx_features18_block_kernel<true>
-                         : amcx::amcx_features18_block_kernel<false>;
+  const int mode = block_mode(N);
+  const size_t lds = (mode == amcx::kBlockBluestein ? (size_t)16 * amcx::bluestein_length(N) : (size_t)16 * N) +
+                     amcx::kBlockScratchBytes + amcx::kBlockTwiddleBytes;
+  auto kern = mode == amcx::kBlockPow2        ? amcx::amcx_features18_block_kernel<amcx::kBlockPow2>
+              : mode == amcx::kBlockBluestein ? amcx::amcx_features18_block_kernel<amcx::kBlockBluestein>
+                                              : amcx::amcx_features18_block_kernel<amcx::kBlockDirect>;
   if (lds > 64 * 1024)
     AMCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -293,8 +302,9 @@ int amcx_kernel_name(int32_t frame_size, int32_t variant, char* buf, int32_t buf
   const int v = resolve_variant(frame_size, variant);
   if (v < 0) return v;
   const char* name = (v == AMCX_VARIANT_WAVE) ? amcx::wave_kernel_name(frame_size)
-                     : is_pow2(frame_size)    ? "amcx_features18_block_kernel<true>"
-                                              : "amcx_features18_block_kernel<false>";
+                     : block_mode(frame_size) == amcx::kBlockPow2      ? "amcx_features18_block_kernel<1>"
+                     : block_mode(frame_size) == amcx::kBlockBluestein ? "amcx_features18_block_kernel<2>"
+                                                                       : "amcx_features18_block_kernel<0>";
   snprintf(buf, (size_t)buf_len, "%s", name);
   return AMCX_OK;
 }

@@ -5,12 +5,20 @@
 // wavefront-level (shuffle) reduction followed by a 4-wave LDS combine, and
 // the spectral term is a shared-memory radix-2 FFT.  It is the accuracy-first,
 // any-frame-size kernel: sums accumulate in fp64, centred statistics are true
-// two-pass, and a frame size that is not a power of two takes a direct DFT
-// (the reference's np.fft.fft accepts any N; its own known-answer test uses
-// N = 10, features.py:240-255).  The throughput kernel is amcx_wave_kernel.h.
+// two-pass.  The reference's np.fft.fft accepts any N (its own known-answer
+// test uses N = 10, features.py:240-255), so a frame size that is not a power
+// of two takes Bluestein's chirp-z form of the same DFT,
+//   X_k = w_k * sum_n (x_n w_n) conj(w_(k-n)),  w_n = exp(-i pi n^2 / N),
+// as a circular convolution of length M = 2^ceil(log2(2N-1)) through the same
+// LDS FFT (forward DIF, product with the workgroup's precomputed FFT of the
+// chirp, inverse DIT; |w_k| = 1 drops out of the peak), or, for N <= 64 and for
+// 4096 < N < 8192 (M would not fit LDS), a direct O(N^2) DFT in fp64.
+// The throughput kernel is amcx_wave_kernel.h.
 //
-// LDS per workgroup: 16*N bytes (frame + (|x|, angle) stash / DFT twiddles)
-// + 1 KiB of reduction scratch.  Algorithmic HBM bytes per frame: 8*N + 72.
+// LDS per workgroup: 16*N bytes (frame + (|x|, angle) stash / twiddles), or
+// 16*M for Bluestein (chirp spectrum + convolution buffer, which the frame and the
+// stash alias), + 1.5 KiB of reduction scratch and two-level twiddle tables.
+// Algorithmic HBM bytes per frame: 8*N + 72.
 #pragma once
 
 #include "amcx_math.h"
@@ -67,15 +75,95 @@ __device__ __forceinline__ float block_max(float v, double* scratch) {
   return b > 0.f ? __builtin_nanf("") : m;
 }
 
-template <bool POW2>
+constexpr int kBlockDirect = 0, kBlockPow2 = 1, kBlockBluestein = 2;   // spectral-term variants
+constexpr int kBluesteinMinN = 65, kBluesteinMaxN = 4096;
+constexpr int kBlockScratchBytes = (int)sizeof(double) * kBlockWaves * kMaxReduce;   // 512
+constexpr int kBlockTwiddleBytes = 2 * 64 * 8;                                        // T_lo, T_hi
+
+__host__ __device__ inline int bluestein_length(int n) {          // smallest power of two >= 2n - 1
+  int m = 1;
+  while (m < 2 * n - 1) m <<= 1;
+  return m;
+}
+
+// W_M^m = exp(-2 pi i m / M), m < M/2, from two 64-entry tables: T_hi[m >> 6] * T_lo[m & 63]
+__device__ __forceinline__ float2 twiddle2(const float2* tlo, const float2* thi, int m) {
+  const float2 a = thi[m >> 6], b = tlo[m & 63];
+  return make_float2(__builtin_fmaf(a.x, b.x, -(a.y * b.y)), __builtin_fmaf(a.x, b.y, a.y * b.x));
+}
+
+// In-place M-point FFTs over an LDS array by the whole workgroup (trailing barrier included).
+// Forward: decimation in frequency, natural order in, bit-reversed order out.
+__device__ __forceinline__ void lds_fft_dif(float2* v, int M, const float2* tlo, const float2* thi) {
+  const int half_m = M >> 1;
+  for (int half = half_m, step = 1; half >= 1; half >>= 1, step <<= 1) {
+    for (int b = threadIdx.x; b < half_m; b += kBlockThreads) {
+      const int j = b & (half - 1);
+      const int i0 = ((b - j) << 1) + j, i1 = i0 + half;
+      const float2 p = v[i0], q = v[i1];
+      const float2 w = twiddle2(tlo, thi, j * step);
+      const float dr = p.x - q.x, di = p.y - q.y;
+      v[i0] = make_float2(p.x + q.x, p.y + q.y);
+      v[i1] = make_float2(__builtin_fmaf(dr, w.x, -(di * w.y)), __builtin_fmaf(dr, w.y, di * w.x));
+    }
+    __syncthreads();
+  }
+}
+// Inverse (unscaled): decimation in time with conjugate twiddles, bit-reversed in, natural out.
+__device__ __forceinline__ void lds_ifft_dit(float2* v, int M, const float2* tlo, const float2* thi) {
+  const int half_m = M >> 1;
+  for (int half = 1, step = half_m; half <= half_m; half <<= 1, step >>= 1) {
+    for (int b = threadIdx.x; b < half_m; b += kBlockThreads) {
+      const int j = b & (half - 1);
+      const int i0 = ((b - j) << 1) + j, i1 = i0 + half;
+      const float2 p = v[i0], q = v[i1];
+      const float2 w = twiddle2(tlo, thi, j * step);            // conj(w) = (w.x, -w.y)
+      const float tr = __builtin_fmaf(q.x, w.x, q.y * w.y), ti = __builtin_fmaf(q.y, w.x, -(q.x * w.y));
+      v[i0] = make_float2(p.x + tr, p.y + ti);
+      v[i1] = make_float2(p.x - tr, p.y - ti);
+    }
+    __syncthreads();
+  }
+}
+
+// exp(sign * i pi n^2 / N): n^2 mod 2N in integers (n < 4096), then one sincospi
+__device__ __forceinline__ float2 chirp(int n, int N, float sign) {
+  const int r = (n * n) % (2 * N);
+  float sn, cs;
+  sincospif((float)r / (float)N, &sn, &cs);
+  return make_float2(cs, sign * sn);
+}
+
+template <int MODE>
 __global__ __launch_bounds__(kBlockThreads, 2) void amcx_features18_block_kernel(
     const float2* __restrict__ iq, long long n_frames, int N, long long row_stride,
     float* __restrict__ out, long long out_stride) {
   extern __shared__ float4 amcx_block_smem[];
-  float2* xs = reinterpret_cast<float2*>(amcx_block_smem);        // frame, later FFT workspace
-  float2* at = xs + N;                                            // (|x|, angle), later DFT twiddles
-  double* scratch = reinterpret_cast<double*>(at + N);            // kBlockWaves * kMaxReduce doubles
+  float2* const base = reinterpret_cast<float2*>(amcx_block_smem);
+  const int M = MODE == kBlockBluestein ? bluestein_length(N) : 0;
+  float2* bh = base;                                              // Bluestein: FFT of the chirp, M entries
+  float2* xs = base + M;                                          // frame, later FFT workspace (M entries for Bluestein)
+  float2* at = xs + N;                                            // (|x|, angle), later twiddles / workspace
+  double* scratch = reinterpret_cast<double*>(MODE == kBlockBluestein ? xs + M : at + N);   // kBlockWaves * kMaxReduce doubles
+  float2* tlo = reinterpret_cast<float2*>(reinterpret_cast<char*>(scratch) + kBlockScratchBytes);
+  float2* thi = tlo + 64;
   const int tid = threadIdx.x;
+
+  if constexpr (MODE == kBlockBluestein) {
+    // once per workgroup: two-level twiddles of the M-point FFT and the chirp's spectrum
+    if (tid < 128) {
+      const int k = tid & 63;
+      float sn, cs;
+      sincospif((float)(tid < 64 ? k : 64 * k) * (2.0f / (float)M), &sn, &cs);
+      tlo[tid] = make_float2(cs, -sn);                            // tlo[k] = W_M^k, thi[k] = W_M^(64 k)
+    }
+    for (int n = tid; n < M; n += kBlockThreads) {
+      const int d = n < N ? n : (M - n < N ? M - n : -1);         // conj(w) is even in n: wrap it around
+      bh[n] = d >= 0 ? chirp(d, N, 1.0f) : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    lds_fft_dif(bh, M, tlo, thi);
+  }
 
   for (long long f = blockIdx.x; f < n_frames; f += gridDim.x) {
     const float2* src = iq + f * row_stride;
@@ -146,7 +234,30 @@ __global__ __launch_bounds__(kBlockThreads, 2) void amcx_features18_block_kernel
     // (a non-finite sample is caught by the finaliser through the power sum,
     //  so the maximum itself need not carry NaNs)
     float peak = 0.f;
-    if constexpr (POW2) {
+    if constexpr (MODE == kBlockBluestein) {
+      // a_n = x_n w_n in place over the frame, zero padding over the dead (|x|, angle) stash
+      for (int n = tid; n < M; n += kBlockThreads) {
+        float2 a = make_float2(0.f, 0.f);
+        if (n < N) {
+          const float2 x = xs[n], w = chirp(n, N, -1.0f);
+          a = make_float2(__builtin_fmaf(x.x, w.x, -(x.y * w.y)), __builtin_fmaf(x.x, w.y, x.y * w.x));
+        }
+        xs[n] = a;
+      }
+      __syncthreads();
+      lds_fft_dif(xs, M, tlo, thi);
+      for (int n = tid; n < M; n += kBlockThreads) {              // both spectra are in bit-reversed order
+        const float2 a = xs[n], b = bh[n];
+        xs[n] = make_float2(__builtin_fmaf(a.x, b.x, -(a.y * b.y)), __builtin_fmaf(a.x, b.y, a.y * b.x));
+      }
+      __syncthreads();
+      lds_ifft_dit(xs, M, tlo, thi);
+      const float inv_m2 = 1.0f / ((float)M * (float)M);          // the inverse transform is unscaled
+      for (int n = tid; n < N; n += kBlockThreads) {
+        const float2 X = xs[n];
+        peak = __builtin_fmaxf(peak, __builtin_fmaf(X.x, X.x, X.y * X.y) * inv_m2);
+      }
+    } else if constexpr (MODE == kBlockPow2) {
       // in-place radix-2 decimation-in-frequency; output order is bit-reversed,
       // which a maximum does not care about.  Twiddles W_N^m, m < N/2, are tabulated
       // once per frame in the (|x|, angle) stash, which is dead by now: N/512

@@ -53,8 +53,9 @@ extern "C" {
 /* kernel variants (amcx_features18_c64_ex) */
 #define AMCX_VARIANT_AUTO 0     /* fastest kernel that supports frame_size */
 #define AMCX_VARIANT_BLOCK 1    /* one 256-thread workgroup per frame, frame staged in LDS,
-                                   radix-2 LDS FFT (power of two) or direct DFT (any N);
-                                   fp64 accumulation; 2 <= frame_size <= AMCX_MAX_FRAME_SIZE */
+                                   radix-2 LDS FFT (power of two), Bluestein chirp-z FFT
+                                   (65..4096) or direct DFT (any other N); fp64
+                                   accumulation; 2 <= frame_size <= AMCX_MAX_FRAME_SIZE */
 #define AMCX_VARIANT_WAVE 2     /* one wavefront per frame, frame held in registers,
                                    register radix-16/8 FFT with LDS exchanges, followed by a
                                    small fix-up launch for frames with a phase step within

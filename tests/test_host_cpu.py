@@ -48,7 +48,7 @@ def test_argument_validation_needs_no_gpu():
     assert lib.amcx_features18_c64_ex(None, 0, 1000, 1000, None, 18, None, _lib.VARIANT_WAVE) == _lib.ENOTSUP
     assert lib.amcx_features18_c64_ex(None, 0, 2048, 2048, None, 18, None, 7) == _lib.EINVAL
     assert _lib.kernel_name(2048).startswith("amcx_features18_wave_kernel")
-    assert _lib.kernel_name(1000) == "amcx_features18_block_kernel<false>"
+    assert _lib.kernel_name(1000) == "amcx_features18_block_kernel<2>"
     with pytest.raises(ValueError):
         _lib.check(_lib.EINVAL)
     with pytest.raises(_lib.AmcxError):
