@@ -24,8 +24,7 @@
 //   pass 1   R-point DFT over i   -> k1 ; twiddle W_NF^((2l+b) k1)
 //   xchg 1   phases g = k1>>3:  LDS[kk*136 + b*68 + l] (kk = k1&7); reader lane l'
 //            (kk = l'>>3, n3 = l'&7) takes n2 = 0..15 at [kk*136 + (n3&1)*68 + 4 n2 + (n3>>1)];
-//            for R < 8 only the lanes with kk < R carry bins, the others compute on stale
-//            LDS and are masked out of the peak
+//            for R < 8 the eight kk slots are filled by 8/R consecutive frames (slot j R + k1)
 //   pass 2   16-point DFT over n2 -> k2 ; twiddle W_128^(n3 k2)
 //   xchg 2   LDS[k2*65 + 8 kk + n3]; reader lane l'' (kk = l''>>3, k2 = (l''&7) + 8 j)
 //   pass 3   8-point DFT over n3  -> X[k1 + R k2 + 16 R k3]; only max |X|^2 is kept
@@ -40,10 +39,11 @@
 // Every ds_write_b64 / ds_read_b64 / ds_read_b128 of the exchanges and twiddle
 // tables is bank-conflict free and addressed as lane_base + immediate.
 //
-// 768-thread workgroups (N <= 2048): 12 waves = exactly 3 per SIMD, one workgroup per CU.
-// (Two 6-wave workgroups do NOT co-reside: their waves land 2,2,1,1 on the SIMDs
-// and a SIMD holds at most 3 waves of 160 VGPRs -- seen as half the waves'
-// lifetime in SQ_WAVE_CYCLES, profiles/r1a.)  LDS per workgroup at N = 2048:
+// 768-thread workgroups (N <= 2048): 12 waves = exactly 3 per SIMD, one workgroup per CU;
+// LDS, not registers, sets that number (125 VGPRs at N = 2048 since the sums are reduced
+// before the FFT; 16 waves measured no faster, the board is at its power cap).
+// (Two 6-wave workgroups did NOT co-reside at the 160 VGPRs of round 1a: their waves
+// landed 2,2,1,1 on the SIMDs, profiles/r1a.)  LDS per workgroup at N = 2048:
 // twiddles 15 KiB + 960 B, 12 x 8704 B exchange, 12 x 1056 B stash = 133.4 KB.
 // Algorithmic HBM bytes per frame: 8*N read + 72 written.
 #pragma once
@@ -335,7 +335,6 @@ struct LaneAddr {
   const char* ex1_r;
   char* ex2_w;
   const char* ex2_r;
-  bool live;          // (lane>>3) < R: this lane ends up with real bins (always true for R >= 8)
 };
 
 // Register FFT of 128*R points held as xr/xi[2*i+b] (see header); returns this
@@ -343,9 +342,9 @@ struct LaneAddr {
 template <int R>
 __device__ __forceinline__ float fft_peak(const float (&xr)[2 * R], const float (&xi)[2 * R],
                                           const LaneAddr& la) {
-  constexpr int LOG2R = R == 16 ? 4 : R == 8 ? 3 : R == 4 ? 2 : R == 2 ? 1 : 0;
-  constexpr int PH = R >= 8 ? R / 8 : 1;     // exchange phases of 8 k1 values
-  constexpr int KK = R >= 8 ? 8 : R;         // k1 values per phase
+  static_assert(R == 8 || R == 16, "shorter frames go through fft_front / fft_back");
+  constexpr int LOG2R = R == 16 ? 4 : 3;
+  constexpr int PH = R / 8;                  // exchange phases of 8 k1 values
   // pass 1 (both b groups), twiddle T1, exchange 1
   float v0r[R], v0i[R], v1r[R], v1i[R];
   static_for<R>([&](auto ii) {
@@ -369,7 +368,7 @@ __device__ __forceinline__ float fft_peak(const float (&xr)[2 * R], const float 
   static_for<PH>([&](auto gg) {
     constexpr int gph = decltype(gg)::value;
     lds_wave_fence();
-    static_for<KK>([&](auto kk_) {
+    static_for<8>([&](auto kk_) {
       constexpr int kk = decltype(kk_)::value;
       constexpr int p = bitrev(8 * gph + kk, LOG2R);
       *reinterpret_cast<float2*>(la.ex1_w + (kk * kEx1StrideKK) * 8) = make_float2(v0r[p], v0i[p]);
@@ -423,7 +422,6 @@ __device__ __forceinline__ float fft_peak(const float (&xr)[2 * R], const float 
     });
   });
   lds_wave_fence();
-  if constexpr (R < 8) peak = la.live ? peak : 0.f;   // lanes whose k1 = lane>>3 does not exist
   return peak;
 }
 
@@ -578,7 +576,6 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
   la.ex1_r = ex + (kkL * kEx1StrideKK + (n3L & 1) * kEx1StrideB + (n3L >> 1)) * 8;
   la.ex2_w = ex + lane * 8;
   la.ex2_r = ex + (n3L * kEx2StrideK2 + kkL * 8) * 8;   // (lane&7) is k2lo for the reader
-  la.live = kkL < R;
   float* const a_lds = reinterpret_cast<float*>(ex) + lane;   // |x| parked in the wave's LDS: [e][lane]
 
 #ifdef AMCX_WAVE_STAMPS
