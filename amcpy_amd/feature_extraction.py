@@ -24,6 +24,7 @@ What is different underneath:
 from __future__ import annotations
 
 import time
+from pathlib import Path
 from typing import Callable, Dict, Optional
 
 import numpy as np
@@ -67,12 +68,15 @@ def _hip_compute(frame_size: int, device: Optional[int], chunk_bytes: int = 1 <<
         if src.dtype not in (np.complex64, np.complex128):
             src = src.astype(np.complex128)
         per = max(1, chunk_bytes // (frame_size * src.dtype.itemsize))
+        tdtype = torch.complex64 if src.dtype == np.complex64 else torch.complex128
         copy_stream = torch.cuda.Stream(device=dev)
         main = torch.cuda.current_stream(dev)
         pending = None          # (device tensor, event, f0, f1)
         for f0 in range(0, F, per):
             f1 = min(F, f0 + per)
-            host = torch.from_numpy(np.ascontiguousarray(src[f0:f1])).pin_memory()
+            # one copy, source (ndarray view or memmap) -> pinned staging buffer
+            host = torch.empty((f1 - f0, frame_size), dtype=tdtype, pin_memory=True)
+            np.copyto(host.numpy(), src[f0:f1])
             with torch.cuda.stream(copy_stream):
                 xd = host.to(dev, non_blocking=True)
                 ev = torch.cuda.Event()
@@ -113,6 +117,31 @@ def extract_modulation(parsed: np.ndarray, cfg: Config, *, compute=None, device:
     fn = compute or _hip_compute(N, device)
     mat = sharded_features(flat, N, fn, rank, world, group)
     return None if mat is None else mat.reshape(n_snr, n_frames, n_feat)
+
+
+def extract_raw_stream(path, frame_size: int, *, skip_samples: int = 0, max_frames: Optional[int] = None,
+                       compute=None, device: Optional[int] = None) -> np.ndarray:
+    """Features of a raw complex64 sample stream on disk (GNU Radio file sink: interleaved
+    float32 I/Q, no header -- what the reference's legacy reader takes with
+    ``np.fromfile(..., dtype=np.complex64)`` and a fixed number of leading samples dropped,
+    old/read_binary_stream.py:28,48,54-56).  The file is memory-mapped and cut into
+    consecutive ``frame_size``-sample frames (a trailing partial frame is dropped); frames go
+    up chunk by chunk through the same pinned, overlapped path as ``run_extraction``, so
+    the file never has to fit in host memory.  Returns ``(n_frames, 18)`` float32."""
+    if frame_size < 2:
+        raise ValueError("frame_size must be >= 2")
+    if skip_samples < 0:
+        raise ValueError("skip_samples must be >= 0")
+    n_total = Path(path).stat().st_size // 8 - skip_samples
+    n_frames = max(0, n_total // frame_size)
+    if max_frames is not None:
+        n_frames = min(n_frames, int(max_frames))
+    if n_frames == 0:
+        return np.empty((0, 18), dtype=np.float32)
+    frames = np.memmap(path, dtype=np.complex64, mode="r", offset=8 * skip_samples,
+                       shape=(n_frames, frame_size))
+    fn = compute or _hip_compute(frame_size, device)
+    return np.asarray(fn(frames), dtype=np.float32)
 
 
 def run_extraction(cfg: Config, *, compute=None, device: Optional[int] = None, verbose: bool = True) -> None:

@@ -401,6 +401,21 @@ def test_two_ranks_run_extraction_sharded(tmp_path):
         assert diff.size == 0, (m, diff[:5], a[key][tuple(diff[0])], b[key][tuple(diff[0])])
 
 
+def test_raw_complex64_stream_file(tmp_path):
+    """GNU-Radio style raw complex64 file through the real engine: same floats as the frames
+    handed over directly, leading samples skipped, partial last frame dropped."""
+    from amcpy_amd import synth
+    from amcpy_amd.feature_extraction import extract_raw_stream
+    N, F, skip = 1024, 37, 300 * 8
+    x = synth.host_block("8PSK", 6.0, F, N, seed=41)
+    path = tmp_path / "binary_awgn_8PSK(6)"
+    np.concatenate([np.zeros(skip, np.complex64), x.reshape(-1), np.ones(N // 2, np.complex64)]).tofile(path)
+    got = extract_raw_stream(path, N, skip_samples=skip)
+    assert got.shape == (F, 18)
+    assert np.array_equal(got, _run(x, "auto"))
+    _assert_parity(got, orc.features18_batch(x), x, "raw stream")
+
+
 def test_odd_row_stride_and_ragged_counts():
     """Rows that start on 8-byte (not 16-byte) boundaries and frame counts that
     are not a multiple of any chunk size: every frame must still be computed once,

@@ -205,6 +205,30 @@ def test_two_rank_sharding_over_gloo(tmp_path, F):
     assert f"GATHER_OK {F} 2" in outs[0]
 
 
+def test_raw_stream_framing(tmp_path):
+    """extract_raw_stream: headerless complex64 file -> consecutive frames after the skipped
+    samples, trailing partial frame dropped (reference old/read_binary_stream.py:28,54-56);
+    the engine is stubbed, this is the host-side framing."""
+    from amcpy_amd.feature_extraction import extract_raw_stream
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal(1000) + 1j * rng.standard_normal(1000)).astype(np.complex64)
+    path = tmp_path / "binary_awgn_BPSK(10)"
+    x.tofile(path)
+    seen = []
+
+    def compute(block):
+        seen.append(np.array(block))
+        return np.zeros((block.shape[0], 18), dtype=np.float32)
+
+    out = extract_raw_stream(path, 64, skip_samples=100, compute=compute)
+    assert out.shape == (14, 18) and out.dtype == np.float32          # (1000 - 100) // 64
+    assert np.array_equal(seen[0], x[100:100 + 14 * 64].reshape(14, 64))
+    assert extract_raw_stream(path, 64, skip_samples=100, max_frames=3, compute=compute).shape == (3, 18)
+    assert extract_raw_stream(path, 2048, compute=compute).shape == (0, 18)
+    with pytest.raises(ValueError):
+        extract_raw_stream(path, 1, compute=compute)
+
+
 def test_synthetic_generator_statistics():
     from amcpy_amd import synth
     for mod in synth.MODS6[:5]:
