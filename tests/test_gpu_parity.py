@@ -180,6 +180,34 @@ def test_wave_kernel_short_power_of_two_frames():
         assert np.array_equal(_run(x[perm], "wave"), got[perm]), N
 
 
+def test_bad_frames_do_not_leak_into_neighbours():
+    """Grouped short frames share FFT passes 2-3 and a finaliser batch; the ping-pong variants
+    share registers across frames: a NaN / Inf / all-zero frame in the middle of a batch must
+    give NaNs (resp. the all-zero result) for itself only, and leave its neighbours' floats
+    exactly as they are without it."""
+    from amcpy_amd import synth
+    for N in (128, 256, 512, 1024, 2048, 4096, 1000):
+        F = 40
+        x = synth.host_block("16QAM", 10.0, F, N, seed=7 * N)
+        clean = _run(x, "auto")
+        y = x.copy()
+        y[3, N // 2] = np.nan
+        y[12, 5] = complex(np.inf, 0.0)
+        y[21] = 0
+        y[22] = 1.0 + 0.0j
+        got = _run(y, "auto")
+        assert np.isnan(got[3]).all() and np.isnan(got[12]).all(), N
+        keep = np.ones(F, bool)
+        keep[[3, 12, 21, 22]] = False
+        assert np.array_equal(got[keep], clean[keep]), N
+        zero = orc.features18_batch(y[21:23])
+        for row, ref in zip(got[21:23], zero):
+            assert (np.isnan(row) == np.isnan(ref)).all(), (N, row, ref)
+            ok = ~np.isnan(ref)
+            ok[[7, 8]] = False                     # kurtosis of a constant series: rounding noise in the reference too
+            assert np.allclose(row[ok], ref[ok], rtol=2e-5, atol=2e-6), (N, row, ref)
+
+
 def test_results_do_not_depend_on_batch_position():
     """Same property for the long-frame variants and the block kernel."""
     from amcpy_amd import synth
