@@ -175,6 +175,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or "RANK" in os.environ        # launched by torch.distributed.run
+    # stdout carries exactly one JSON line: RCCL prints a version banner to fd 1 when the
+    # communicator comes up, so everything until the final print goes to stderr instead
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -270,7 +275,9 @@ def main():
         },
         "cpu_baseline": cpu,
     }
-    print(json.dumps(rec))
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    print(json.dumps(rec), flush=True)
 
 
 if __name__ == "__main__":
