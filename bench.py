@@ -130,6 +130,21 @@ def _valu_note(frames_per_s: float):
     return None
 
 
+def _ensure_library(local_rank: int):
+    """libamcx.so is a build artefact (not in git): if this checkout lacks it, local rank 0
+    builds it (as __graft_entry__.build() does) and the other ranks wait for the file."""
+    from amcpy_amd.csrc import build as b
+    if b.LIB.exists():
+        return
+    if local_rank == 0:
+        b.build(verbose=False)
+        return
+    deadline = time.time() + 300
+    while not b.LIB.exists() and time.time() < deadline:
+        time.sleep(1.0)
+    time.sleep(2.0)          # let the linker finish writing
+
+
 def _config_label(frame_size, n_frames):
     """Which BASELINE.json config the chosen shape is (the default run is configs[1])."""
     if n_frames == N_FRAMES and frame_size == FRAME_SIZE:
@@ -167,6 +182,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.cpu_procs)            # before the GPU is touched
 
+    _ensure_library(local_rank)
     import torch
     import torch.distributed as dist
     from amcpy_amd import _lib, synth
