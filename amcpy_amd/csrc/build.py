@@ -35,14 +35,20 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = True) -
     if not force and not stale():
         return LIB
     LIB_DIR.mkdir(exist_ok=True)
-    cmd = [HIPCC, *FLAGS, *map(str, SOURCES), "-o", str(LIB)]
+    tmp_lib = LIB.with_name(f"{LIB.name}.{os.getpid()}.tmp")     # linked aside, renamed when complete
+    cmd = [HIPCC, *FLAGS, *map(str, SOURCES), "-o", str(tmp_lib)]
     if save_temps:
         tmp = HERE / "build"
         tmp.mkdir(exist_ok=True)
         cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
     if verbose:
         print("+", " ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True, cwd=str(HERE))
+    try:
+        subprocess.run(cmd, check=True, cwd=str(HERE))
+        os.replace(tmp_lib, LIB)
+    finally:
+        if tmp_lib.exists():
+            tmp_lib.unlink()
     return LIB
 
 

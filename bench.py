@@ -140,9 +140,8 @@ def _ensure_library(local_rank: int):
         b.build(verbose=False)
         return
     deadline = time.time() + 300
-    while not b.LIB.exists() and time.time() < deadline:
+    while not b.LIB.exists() and time.time() < deadline:     # appears atomically (build.py renames)
         time.sleep(1.0)
-    time.sleep(2.0)          # let the linker finish writing
 
 
 def _config_label(frame_size, n_frames):
