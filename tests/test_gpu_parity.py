@@ -550,9 +550,13 @@ def test_iq_pair_layout_is_zero_copy():
         features18_iq_pairs(pairs.transpose(1, 2).contiguous().transpose(1, 2))
 
 
-def test_full_benchmark_shard_properties():
-    """BASELINE configs[1] at full size (6 x 26 x 4096 frames x 2048 samples, 10.5 GB in
-    HBM): too large for the oracle, so size-independent properties --
+@pytest.mark.parametrize("n_mods,N,label", [(6, 2048, "configs[1]"), (6, 4096, "configs[2]"),
+                                            (3, 1024, "configs[4] per-GPU shard")])
+def test_full_benchmark_shard_properties(n_mods, N, label):
+    """BASELINE configs at full size -- configs[1] 6 x 26 x 4096 frames x 2048 samples (10.5 GB
+    in HBM), configs[2] the same at 4096 samples (20.9 GB), and one GPU's eighth of configs[4]
+    (24 x 26 x 4096 x 1024 over 8 GPUs = 3 modulations each, 2.6 GB): too large for the oracle,
+    so size-independent properties --
     every frame is computed exactly once and independently of its position (one launch
     over the whole shard == per-modulation launches == a gathered sample recomputed
     alone, bit for bit), per-block checksums agree, the output is finite, and a sample of
@@ -560,29 +564,31 @@ def test_full_benchmark_shard_properties():
     torch = _torch()
     from amcpy_amd import synth
     from amcpy_amd.features import features18
-    n_snr, n_frames, N = 26, 4096, 2048
-    arena = torch.empty((6, n_snr, n_frames, N), dtype=torch.complex64, device="cuda")
-    for mi, mod in enumerate(synth.MODS6):
+    n_snr, n_frames = 26, 4096
+    arena = torch.empty((n_mods, n_snr, n_frames, N), dtype=torch.complex64, device="cuda")
+    for mi, mod in enumerate(synth.MODS6[:n_mods]):
         synth.device_frames(mod, n_snr, n_frames, N, device="cuda", rank=0, mod_idx=mi, out=arena[mi])
     whole = features18(arena)
-    assert whole.shape == (6, n_snr, n_frames, 18)
+    assert whole.shape == (n_mods, n_snr, n_frames, 18)
     assert torch.isfinite(whole).all()
     # different batching, same bits; block checksums (a checksum of checksums) agree
-    for mi in range(6):
+    for mi in range(n_mods):
         part = features18(arena[mi])
         assert torch.equal(part, whole[mi]), f"modulation {mi}: result depends on the batching"
-    csum_whole = whole.double().sum(dim=2)                        # (6, 26, 18)
-    csum_rev = features18(arena.flip(2).contiguous()).double().sum(dim=2)
+    csum_whole = whole.double().sum(dim=2)                        # (n_mods, 26, 18)
+    rev = arena.flip(2).contiguous()
+    csum_rev = features18(rev).double().sum(dim=2)
+    del rev
     assert torch.allclose(csum_whole, csum_rev, rtol=1e-12, atol=0)
     # a gathered random sample, recomputed alone and checked against the oracle
     g = torch.Generator(device="cpu").manual_seed(5)
-    idx = torch.randint(0, 6 * n_snr * n_frames, (64,), generator=g)
+    idx = torch.randint(0, n_mods * n_snr * n_frames, (64,), generator=g)
     flat = arena.reshape(-1, N)
     sample = flat[idx.cuda()].contiguous()
     alone = features18(sample)
     assert torch.equal(alone, whole.reshape(-1, 18)[idx.cuda()])
     x = sample.cpu().numpy()
-    _assert_parity(alone.cpu().numpy(), orc.features18_batch(x), x, "sample of the full shard")
+    _assert_parity(alone.cpu().numpy(), orc.features18_batch(x), x, f"sample of the full shard, {label}")
     # SNR trend sanity on the signal classes: mean |x| falls towards 1 as noise vanishes
     assert (whole[0, 0, :, 5].mean() > whole[0, -1, :, 5].mean())
 
