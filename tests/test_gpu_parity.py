@@ -211,13 +211,15 @@ def test_bad_frames_do_not_leak_into_neighbours():
 def test_results_do_not_depend_on_batch_position():
     """Same property for the long-frame variants and the block kernel."""
     from amcpy_amd import synth
-    for N, F in ((1024, 301), (2048, 203), (4096, 101), (100, 57)):
+    for N, F in ((128, 517), (512, 333), (1024, 301), (2048, 203), (4096, 101), (100, 57)):
         x = synth.host_block("64QAM", 8.0, F, N, seed=N)
         perm = np.random.default_rng(N).permutation(F)
         for variant in _variants_for(N):
             a = _run(x, variant)
             assert np.array_equal(_run(x[perm], variant), a[perm]), (N, variant)
             assert np.array_equal(_run(x[: F // 3], variant), a[: F // 3]), (N, variant)
+            for tiny in (1, 2, 3, 9):              # fewer frames than waves in a workgroup
+                assert np.array_equal(_run(x[5:5 + tiny], variant), a[5:5 + tiny]), (N, variant, tiny)
 
 
 def test_generic_sizes_block_kernel():
