@@ -1,5 +1,5 @@
 // AMCX_VARIANT_WAVE: one wavefront (64 lanes) per frame, frame held in registers.
-// Instantiated for the power-of-two frame sizes 128 ... 4096.
+// Instantiated for the power-of-two frame sizes 128 ... 8192.
 //
 // Why not "one 256-thread workgroup per frame": this path is VALU/power-bound, not
 // HBM-bound (~107 fp32 VALU ops per sample), so the design
@@ -66,9 +66,10 @@ constexpr int kT2Bytes = 15 * 8 * 8;                   // [k2-1][n3] complex
 
 template <int N>
 struct Cfg {
-  static_assert(N == 128 || N == 256 || N == 512 || N == 1024 || N == 2048 || N == 4096,
+  static_assert(N == 128 || N == 256 || N == 512 || N == 1024 || N == 2048 || N == 4096 || N == 8192,
                 "wave kernel frame sizes");
-  static constexpr bool kSplit = N == 4096;            // radix-2 DIF split in front of a 2048 FFT
+  static constexpr bool kSplit = N >= 4096;            // radix-2 DIF split in front of a 2048 FFT
+  static constexpr bool kSplit2 = N == 8192;           // ... and a second one in front of that
   // frames per wave per batch, finalised together one frame per lane: the fp64 algebra costs
   // the same per batch whatever N is, so short frames come in larger batches
   static constexpr int kFramesPerWave = N >= 1024 ? 8 : (N == 512 ? 16 : 32);
@@ -87,11 +88,13 @@ struct Cfg {
   static constexpr int kThreads = 64 * kWavesPerWG;
   static constexpr int kTailFrames = kWavesPerWG * kFramesPerWave;
   static constexpr int kRows = N / 128;                // rows of 128 samples per frame
+  static constexpr int kHeldRows = kSplit2 ? 32 : kRows;   // rows a wave holds in registers (N = 8192: the lower half)
   static constexpr int kFftRows = kSplit ? 16 : kRows; // R: rows one register FFT holds
   static constexpr int kFftN = 128 * kFftRows;
   static constexpr int kT1Bytes = (kFftRows - 1) * 64 * 16;   // [k1-1][lane][b] complex
   static constexpr int kT4Bytes = kSplit ? 64 * 16 : 0;       // [lane][b] complex: W_4096^(2l+b)
-  static constexpr int kTableBytes = kT1Bytes + kT2Bytes + kT4Bytes;
+  static constexpr int kT8Bytes = kSplit2 ? 64 * 16 : 0;      // [lane][b] complex: W_8192^(2l+b)
+  static constexpr int kTableBytes = kT1Bytes + kT2Bytes + kT4Bytes + kT8Bytes;
   static constexpr int kCounterOffset = kTableBytes + kWavesPerWG * (kExchangeBytes + kStashBytes);
   static constexpr int kLdsBytes = kCounterOffset + 16;       // + the workgroup's two work counters
   static_assert(kLdsBytes <= 163840, "one workgroup per CU must fit in 160 KiB of LDS");
@@ -140,6 +143,26 @@ __device__ __forceinline__ void mul_w32(float& r, float& i) {
     const float t = (i - r) * h; i = (-r - i) * h; r = t;
   } else {
     constexpr float c = kC32[J], s = kS32[J];
+    const float t = __builtin_fmaf(r, c, i * s);
+    i = __builtin_fmaf(i, c, -(r * s));
+    r = t;
+  }
+}
+
+// (r, i) *= W_64^J = exp(-2 pi i J / 64), J = 0..31 (the N = 8192 split)
+constexpr float kCosPi32[17] = {1.f, 0.99518472667219689f, 0.98078528040323043f, 0.95694033573220882f,
+                                0.92387953251128674f, 0.88192126434835503f, 0.83146961230254524f,
+                                0.77301045336273696f, 0.70710678118654752f, 0.63439328416364549f,
+                                0.55557023301960218f, 0.47139673682599764f, 0.38268343236508977f,
+                                0.29028467725446236f, 0.19509032201612825f, 0.09801714032956060f, 0.f};
+template <int J>
+__device__ __forceinline__ void mul_w64(float& r, float& i) {
+  static_assert(J >= 0 && J < 32, "upper half-plane only");
+  if constexpr (J % 2 == 0) {
+    mul_w32<J / 2>(r, i);
+  } else {
+    constexpr float c = J <= 16 ? kCosPi32[J] : -kCosPi32[32 - J];
+    constexpr float s = kCosPi32[J <= 16 ? 16 - J : J - 16];
     const float t = __builtin_fmaf(r, c, i * s);
     i = __builtin_fmaf(i, c, -(r * s));
     r = t;
@@ -513,7 +536,7 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
     const float2* __restrict__ iq, long long n_frames, long long row_stride,
     float* __restrict__ out, long long out_stride AMCX_STAMP_ARG) {
   using C = Cfg<N>;
-  constexpr int R = C::kFftRows, ROWS = C::kRows;
+  constexpr int R = C::kFftRows, ROWS = C::kHeldRows;
   constexpr int kWavesPerWG = C::kWavesPerWG, kThreads = C::kThreads, kTailFrames = C::kTailFrames;
   constexpr int kFramesPerWave = C::kFramesPerWave, kTailChunk = C::kTailChunk;
   extern __shared__ float4 amcx_wave_smem[];
@@ -523,7 +546,8 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   char* t1 = smem;                                        // [R-1][64][2] complex
   char* t2 = smem + C::kT1Bytes;                          // [15][8] complex
-  char* t4 = smem + C::kT1Bytes + kT2Bytes;               // [64][2] complex (N = 4096 only)
+  char* t4 = smem + C::kT1Bytes + kT2Bytes;               // [64][2] complex (N >= 4096 only)
+  char* t8 = t4 + C::kT4Bytes;                            // [64][2] complex (N = 8192 only)
   char* ex = smem + C::kTableBytes + wave * kExchangeBytes;
   float* stash = reinterpret_cast<float*>(smem + C::kTableBytes + kWavesPerWG * kExchangeBytes) +
                  wave * (kFramesPerWave * kStashStride);
@@ -563,6 +587,13 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
       float sn, cs;
       sincospif((float)e * (1.0f / 2048.0f), &sn, &cs);
       reinterpret_cast<float2*>(t4)[e] = make_float2(cs, -sn);
+    }
+  }
+  if constexpr (C::kSplit2) {
+    for (int e = tid; e < 128; e += kThreads) {            // T8[l][b] = W_8192^(2l+b)
+      float sn, cs;
+      sincospif((float)e * (1.0f / 4096.0f), &sn, &cs);
+      reinterpret_cast<float2*>(t8)[e] = make_float2(cs, -sn);
     }
   }
   __syncthreads();
@@ -615,7 +646,8 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
       static_for<ROWS>([&](auto ii) {
         constexpr int i = decltype(ii)::value;
         typedef float v4f __attribute__((ext_vector_type(4)));
-        const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src + 128 * i));
+        const v4f* p = reinterpret_cast<const v4f*>(src + 128 * i);
+        const v4f v = C::kSplit2 ? *p : __builtin_nontemporal_load(p);   // N = 8192 visits a frame twice
         xr[2 * i] = v.x; xi[2 * i] = v.y; xr[2 * i + 1] = v.z; xi[2 * i + 1] = v.w;
       });
     };
@@ -632,33 +664,62 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
       // =====================================================================
       Stats S;
       float av[kAInRegs ? 2 * ROWS : 1];
-      static_for<ROWS>([&](auto ii) {
-        constexpr int i = decltype(ii)::value;
+      const float2* const src2 = iq + (f0 + g) * row_stride + 2 * lane;
+      if constexpr (!C::kSplit2) {
+        static_for<ROWS>([&](auto ii) {
+          constexpr int i = decltype(ii)::value;
+          float a0, a1;
+          S.template row<i == 0, i == ROWS - 1>(xr[2 * i], xi[2 * i], xr[2 * i + 1], xi[2 * i + 1], lane, a0, a1);
+          if constexpr (kAInRegs) {
+            av[2 * i] = a0;
+            av[2 * i + 1] = a1;
+          } else if constexpr (!C::kSplit) {
+            a_lds[(2 * i) * 64] = a0;
+            a_lds[(2 * i + 1) * 64] = a1;
+          }
+        });
+      } else {
+        // N = 8192: 64 rows unrolled would be 60 KB of code and, with the FFTs, overflow the
+        // 64 KB instruction cache (measured: half the issue rate).  The sweep streams the frame
+        // through a rolled loop instead, four rows in flight; the FFT branches re-read it
+        // (L2 / Infinity Cache) into registers afterwards.
+        auto ld = [&](int r) { return *reinterpret_cast<const float4*>(src2 + 128 * r); };
         float a0, a1;
-        S.template row<i == 0, i == ROWS - 1>(xr[2 * i], xi[2 * i], xr[2 * i + 1], xi[2 * i + 1], lane, a0, a1);
-        if constexpr (kAInRegs) {
-          av[2 * i] = a0;
-          av[2 * i + 1] = a1;
-        } else if constexpr (!C::kSplit) {
-          a_lds[(2 * i) * 64] = a0;
-          a_lds[(2 * i + 1) * 64] = a1;
+        float4 ring[4];
+        const float4 first = ld(0);
+        static_for<4>([&](auto kk) { ring[decltype(kk)::value] = ld(1 + decltype(kk)::value); });
+        S.template row<true, false>(first.x, first.y, first.z, first.w, lane, a0, a1);
+#pragma clang loop unroll(disable)
+        for (int i = 1; i < C::kRows - 3; i += 4) {          // rows 1 .. kRows-4
+          static_for<4>([&](auto kk) {
+            constexpr int k = decltype(kk)::value;
+            const float4 cur = ring[k];
+            const int nx = i + 4 + k;
+            ring[k] = ld(nx < C::kRows ? nx : C::kRows - 1);
+            S.template row<false, false>(cur.x, cur.y, cur.z, cur.w, lane, a0, a1);
+          });
         }
-      });
+        S.template row<false, false>(ring[0].x, ring[0].y, ring[0].z, ring[0].w, lane, a0, a1);
+        S.template row<false, false>(ring[1].x, ring[1].y, ring[1].z, ring[1].w, lane, a0, a1);
+        S.template row<false, true>(ring[2].x, ring[2].y, ring[2].z, ring[2].w, lane, a0, a1);
+      }
       asm volatile("; MARK envelope");
       AMCX_STAMP(0);
       __builtin_amdgcn_sched_barrier(0);
-      // envelope second sweep about the exact mean
+      // envelope second sweep about the exact mean (N = 8192: during the second visit below)
       const float mu = bcast_l63(wave_sum_l63(S.sa)) * (1.0f / (float)N);
-      static_for<2 * ROWS>([&](auto ee) {
-        constexpr int e = decltype(ee)::value;
-        if constexpr (kAInRegs) {
-          S.envelope(av[e], mu);
-        } else if constexpr (C::kSplit) {
-          S.envelope(__builtin_amdgcn_sqrtf(__builtin_fmaf(xr[e], xr[e], __builtin_fmaf(xi[e], xi[e], kTinyPower))), mu);
-        } else {
-          S.envelope(a_lds[e * 64], mu);
-        }
-      });
+      if constexpr (!C::kSplit2) {
+        static_for<2 * ROWS>([&](auto ee) {
+          constexpr int e = decltype(ee)::value;
+          if constexpr (kAInRegs) {
+            S.envelope(av[e], mu);
+          } else if constexpr (C::kSplit) {
+            S.envelope(__builtin_amdgcn_sqrtf(__builtin_fmaf(xr[e], xr[e], __builtin_fmaf(xi[e], xi[e], kTinyPower))), mu);
+          } else {
+            S.envelope(a_lds[e * 64], mu);
+          }
+        });
+      }
 
       // =====================================================================
       // wave reduction of the 27 sums -> stash row g, before the FFT so that the sums'
@@ -748,27 +809,70 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
       } else if constexpr (!C::kSplit) {
         peak = fft_peak<R>(xr, xi, la);
       } else {
-        // radix-2 DIF split: s = x[n] + x[n+2048],  d = (x[n] - x[n+2048]) * W_4096^n,
-        // n = 128 i + 2 l + b,  W_4096^n = W_32^i * W_4096^(2l+b)
-        const float4 w4 = *reinterpret_cast<const float4*>(t4 + lane * 16);
-        float sr[2 * R], si[2 * R], dr[2 * R], di[2 * R];
-        static_for<R>([&](auto ii) {
-          constexpr int i = decltype(ii)::value;
-          constexpr int lo = 2 * i, hi = 2 * (R + i);
-          sr[lo] = xr[lo] + xr[hi];             si[lo] = xi[lo] + xi[hi];
-          sr[lo + 1] = xr[lo + 1] + xr[hi + 1]; si[lo + 1] = xi[lo + 1] + xi[hi + 1];
-          float d0r = xr[lo] - xr[hi], d0i = xi[lo] - xi[hi];
-          float d1r = xr[lo + 1] - xr[hi + 1], d1i = xi[lo + 1] - xi[hi + 1];
-          mul_w32<i>(d0r, d0i);
-          mul_w32<i>(d1r, d1i);
-          dr[lo] = __builtin_fmaf(d0r, w4.x, -(d0i * w4.y));
-          di[lo] = __builtin_fmaf(d0r, w4.y, d0i * w4.x);
-          dr[lo + 1] = __builtin_fmaf(d1r, w4.z, -(d1i * w4.w));
-          di[lo + 1] = __builtin_fmaf(d1r, w4.w, d1i * w4.z);
-        });
-        peak = fft_peak<R>(sr, si, la);
-        __builtin_amdgcn_sched_barrier(0);
-        peak = __builtin_fmaxf(peak, fft_peak<R>(dr, di, la));
+        // 4096 points in registers: radix-2 DIF split, s = y[n] + y[n+2048],
+        // d = (y[n] - y[n+2048]) * W_4096^n,  n = 128 i + 2 l + b,  W_4096^n = W_32^i * W_4096^(2l+b)
+        // row_of(ic) yields row i of the 4096-point sequence as (re, im) of b = 0 and b = 1; each
+        // row is asked for exactly once, so a provider may load and accumulate on the way
+        auto fft4096 = [&](auto&& row_of) -> float {
+          const float4 w4 = *reinterpret_cast<const float4*>(t4 + lane * 16);
+          float sr[2 * R], si[2 * R], dr[2 * R], di[2 * R];
+          static_for<R>([&](auto ii) {
+            constexpr int i = decltype(ii)::value;
+            constexpr int lo = 2 * i;
+            const float4 p = row_of(std::integral_constant<int, i>{});
+            const float4 q = row_of(std::integral_constant<int, R + i>{});
+            sr[lo] = p.x + q.x;     si[lo] = p.y + q.y;
+            sr[lo + 1] = p.z + q.z; si[lo + 1] = p.w + q.w;
+            float d0r = p.x - q.x, d0i = p.y - q.y;
+            float d1r = p.z - q.z, d1i = p.w - q.w;
+            mul_w32<i>(d0r, d0i);
+            mul_w32<i>(d1r, d1i);
+            dr[lo] = __builtin_fmaf(d0r, w4.x, -(d0i * w4.y));
+            di[lo] = __builtin_fmaf(d0r, w4.y, d0i * w4.x);
+            dr[lo + 1] = __builtin_fmaf(d1r, w4.z, -(d1i * w4.w));
+            di[lo + 1] = __builtin_fmaf(d1r, w4.w, d1i * w4.z);
+            if constexpr (C::kSplit2 && i % 4 == 3) __builtin_amdgcn_sched_barrier(0);   // 16 loads in flight, not 64
+          });
+          float pk4 = fft_peak<R>(sr, si, la);
+          __builtin_amdgcn_sched_barrier(0);
+          return __builtin_fmaxf(pk4, fft_peak<R>(dr, di, la));
+        };
+        if constexpr (!C::kSplit2) {
+          peak = fft4096([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            return make_float4(xr[2 * i], xi[2 * i], xr[2 * i + 1], xi[2 * i + 1]);
+          });
+        } else {
+          // first re-read (L2 / Infinity Cache): even bins = FFT_4096(x[n] + x[n+4096])
+          peak = fft4096([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const float4 l4 = *reinterpret_cast<const float4*>(src2 + 128 * i);
+            const float4 h4 = *reinterpret_cast<const float4*>(src2 + 128 * (C::kRows / 2 + i));
+            return make_float4(l4.x + h4.x, l4.y + h4.y, l4.z + h4.z, l4.w + h4.w);
+          });
+          __builtin_amdgcn_sched_barrier(0);
+          // second re-read: the envelope's second sweep, and the odd bins =
+          // FFT_4096((x[n] - x[n+4096]) * W_8192^n),  W_8192^n = W_64^i * W_8192^(2l+b)
+          const float4 w8 = *reinterpret_cast<const float4*>(t8 + lane * 16);
+          const float odd = fft4096([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const float4 l4 = *reinterpret_cast<const float4*>(src2 + 128 * i);
+            const float4 h4 = *reinterpret_cast<const float4*>(src2 + 128 * (C::kRows / 2 + i));
+            S.envelope(__builtin_amdgcn_sqrtf(__builtin_fmaf(l4.x, l4.x, __builtin_fmaf(l4.y, l4.y, kTinyPower))), mu);
+            S.envelope(__builtin_amdgcn_sqrtf(__builtin_fmaf(l4.z, l4.z, __builtin_fmaf(l4.w, l4.w, kTinyPower))), mu);
+            S.envelope(__builtin_amdgcn_sqrtf(__builtin_fmaf(h4.x, h4.x, __builtin_fmaf(h4.y, h4.y, kTinyPower))), mu);
+            S.envelope(__builtin_amdgcn_sqrtf(__builtin_fmaf(h4.z, h4.z, __builtin_fmaf(h4.w, h4.w, kTinyPower))), mu);
+            float d0r = l4.x - h4.x, d0i = l4.y - h4.y, d1r = l4.z - h4.z, d1i = l4.w - h4.w;
+            mul_w64<i>(d0r, d0i);
+            mul_w64<i>(d1r, d1i);
+            return make_float4(__builtin_fmaf(d0r, w8.x, -(d0i * w8.y)), __builtin_fmaf(d0r, w8.y, d0i * w8.x),
+                               __builtin_fmaf(d1r, w8.z, -(d1i * w8.w)), __builtin_fmaf(d1r, w8.w, d1i * w8.z));
+          });
+          peak = __builtin_fmaxf(peak, odd);
+          // the three envelope sums join the stash row now (the 24 others went before the FFTs)
+          const float e1 = wave_sum_l63(S.sad1), e2 = wave_sum_l63(S.sad2), e4 = wave_sum_l63(S.sad4);
+          if (lane == 63) { row[16] = e1; row[17] = e2; row[18] = e4; }
+        }
       }
 
       const float pk = wave_max_l63(peak);
@@ -823,7 +927,7 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
     } else {
       for (int g = 0; g < n_here; ++g) {
         float xr[2 * ROWS], xi[2 * ROWS];
-        load_frame(xr, xi, f0 + g);
+        if constexpr (!C::kSplit2) load_frame(xr, xi, f0 + g);   // N = 8192 streams the frame itself
         frame(xr, xi, g, Slot0{});
       }
     }
@@ -864,7 +968,7 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
 }  // namespace wave
 
 inline bool wave_supports(int frame_size) {
-  return frame_size >= 128 && frame_size <= 4096 && (frame_size & (frame_size - 1)) == 0;
+  return frame_size >= 128 && frame_size <= 8192 && (frame_size & (frame_size - 1)) == 0;
 }
 
 inline const char* wave_kernel_name(int frame_size) {
@@ -875,6 +979,7 @@ inline const char* wave_kernel_name(int frame_size) {
     case 1024: return "amcx_features18_wave_kernel<1024>";
     case 2048: return "amcx_features18_wave_kernel<2048>";
     case 4096: return "amcx_features18_wave_kernel<4096>";
+    case 8192: return "amcx_features18_wave_kernel<8192>";
     default: return "";
   }
 }
@@ -913,6 +1018,7 @@ inline hipError_t launch_wave(const float2* iq, int64_t n_frames, int32_t frame_
     case 1024: return launch_wave_n<1024>(iq, n_frames, row_stride, out, out_stride, stream, cus);
     case 2048: return launch_wave_n<2048>(iq, n_frames, row_stride, out, out_stride, stream, cus);
     case 4096: return launch_wave_n<4096>(iq, n_frames, row_stride, out, out_stride, stream, cus);
+    case 8192: return launch_wave_n<8192>(iq, n_frames, row_stride, out, out_stride, stream, cus);
     default: return hipErrorNotSupported;
   }
 }

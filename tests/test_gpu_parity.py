@@ -180,13 +180,35 @@ def test_wave_kernel_short_power_of_two_frames():
         assert np.array_equal(_run(x[perm], "wave"), got[perm]), N
 
 
+def test_wave_kernel_8192():
+    """N = 8192: two radix-2 splits in front of the 2048-point register FFT, lower half in
+    registers, upper half streamed, second visit for the odd bins; against the oracle and the
+    block kernel (LDS radix-2 FFT, fp64 sums)."""
+    from amcpy_amd import synth, _lib
+    N = 8192
+    assert _lib.kernel_name(N, _lib.VARIANT_AUTO) == "amcx_features18_wave_kernel<8192>"
+    x = np.concatenate([synth.host_block(m, snr, 23, N, seed=N + i)
+                        for i, (m, snr) in enumerate((("BPSK", -5.0), ("QPSK", 3.0), ("64QAM", 20.0), ("WGN", 0.0)))])
+    # a pure tone on an odd bin and one on an even bin: both branches of the first split carry the peak
+    n = np.arange(N)
+    x[0] = np.exp(2j * np.pi * 1235 * n / N).astype(np.complex64)
+    x[1] = np.exp(2j * np.pi * 2468 * n / N).astype(np.complex64)
+    gold = orc.features18_batch(x)
+    got = _run(x, "wave")
+    assert abs(got[0, 0] / N - 1.0) < 1e-5 and abs(got[1, 0] / N - 1.0) < 1e-5     # |X|^2 / N = N
+    _assert_parity(got[2:], gold[2:], x[2:], "wave N=8192")
+    blk = _run(x, "block")
+    _, scaled = orc.parity_errors(got, blk, orc.conditioning_scales(x, absolute=True))
+    assert scaled[:, 0].max() <= 2e-5 and scaled[2:].max() <= 2e-5, scaled.max(axis=0)
+
+
 def test_bad_frames_do_not_leak_into_neighbours():
     """Grouped short frames share FFT passes 2-3 and a finaliser batch; the ping-pong variants
     share registers across frames: a NaN / Inf / all-zero frame in the middle of a batch must
     give NaNs (resp. the all-zero result) for itself only, and leave its neighbours' floats
     exactly as they are without it."""
     from amcpy_amd import synth
-    for N in (128, 256, 512, 1024, 2048, 4096, 1000):
+    for N in (128, 256, 512, 1024, 2048, 4096, 8192, 1000):
         F = 40
         x = synth.host_block("16QAM", 10.0, F, N, seed=7 * N)
         clean = _run(x, "auto")
@@ -211,7 +233,7 @@ def test_bad_frames_do_not_leak_into_neighbours():
 def test_results_do_not_depend_on_batch_position():
     """Same property for the long-frame variants and the block kernel."""
     from amcpy_amd import synth
-    for N, F in ((128, 517), (512, 333), (1024, 301), (2048, 203), (4096, 101), (100, 57)):
+    for N, F in ((128, 517), (512, 333), (1024, 301), (2048, 203), (4096, 101), (8192, 67), (100, 57)):
         x = synth.host_block("64QAM", 8.0, F, N, seed=N)
         perm = np.random.default_rng(N).permutation(F)
         for variant in _variants_for(N):
