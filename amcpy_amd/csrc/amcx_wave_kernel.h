@@ -36,6 +36,11 @@
 // branch: L2 holds 4 MiB per XCD against 12 MiB of frames in flight, so the second
 // read came over the fabric -- FETCH_SIZE 2.0x the algorithmic bytes and 23 % of
 // wave-cycles waiting on it, profiles/r1d_n4096_summary.json.)
+// N = 8192 (64 KiB, more than a wave's registers) puts a second split in front of that:
+//   X[2k] = FFT_4096(x[n] + x[n+4096]),  X[2k+1] = FFT_4096((x[n] - x[n+4096]) W_8192^n).
+// The statistics sweep streams the frame through a rolled loop (unrolled it alone would be
+// 60 KB of code against a 64 KB instruction cache) and each branch re-reads the frame from
+// L2 / Infinity Cache straight into the first butterflies of the 4096-point stage.
 // Every ds_write_b64 / ds_read_b64 / ds_read_b128 of the exchanges and twiddle
 // tables is bank-conflict free and addressed as lane_base + immediate.
 //

@@ -60,7 +60,7 @@ extern "C" {
                                    register radix-16/8 FFT with LDS exchanges, followed by a
                                    small fix-up launch for frames with a phase step within
                                    an fp32 ulp of +-pi; frame_size a power of two,
-                                   128 ... 4096 */
+                                   128 ... 8192 */
 
 #define AMCX_MIN_FRAME_SIZE 2
 #define AMCX_MAX_FRAME_SIZE 8192
