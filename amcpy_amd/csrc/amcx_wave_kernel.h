@@ -78,7 +78,11 @@ struct Cfg {
   // frames per wave per batch, finalised together one frame per lane: the fp64 algebra costs
   // the same per batch whatever N is, so short frames come in larger batches
   static constexpr int kFramesPerWave = N >= 1024 ? 8 : (N == 512 ? 16 : 32);
-  static constexpr int kStashBytes = kFramesPerWave * kStashStride * 4;
+  // how many times per frame the per-lane fp32 sums are reduced into the stash and started
+  // afresh (the finaliser adds the rows in fp64): at N = 8192 a lane would otherwise run 128
+  // samples into one accumulator, and C40 reached 1.1e-5 of its conditioning scale
+  static constexpr int kFlushes = N == 8192 ? 4 : 1;
+  static constexpr int kStashBytes = kFramesPerWave * kFlushes * kStashStride * 4;
   // next frame of the chunk loaded into a second register set while this one is processed
   static constexpr bool kPrefetch = N <= 1024;
   // short frames (R < 8 rows) fill only R of the 8 k1 slots of exchange 1, so kGroup = 8/R
@@ -347,6 +351,13 @@ struct Stats {
     rot_prev = rot;
   }
 
+  // start a new stretch of the sums; shifts, neighbour angles and the tie tracker carry on
+  __device__ __forceinline__ void clear_sums() {
+    sA = sBh = sP = sAA = sX4 = sAB = sAP = sBP = 0.f;
+    sAAA = sABB = sAAB = sBBB = sAAP = sX4P = sABP = 0.f;
+    sa = st1 = st2 = sab1 = sab2 = sw1 = sw2 = sw3 = sw4 = 0.f;
+  }
+
   __device__ __forceinline__ void envelope(float a, float mu) {
     const float d = a - mu, d2 = d * d;
     sad1 += __builtin_fabsf(d);
@@ -555,7 +566,7 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
   char* t8 = t4 + C::kT4Bytes;                            // [64][2] complex (N = 8192 only)
   char* ex = smem + C::kTableBytes + wave * kExchangeBytes;
   float* stash = reinterpret_cast<float*>(smem + C::kTableBytes + kWavesPerWG * kExchangeBytes) +
-                 wave * (kFramesPerWave * kStashStride);
+                 wave * (kFramesPerWave * C::kFlushes * kStashStride);
 
   // ---- work distribution ------------------------------------------------------
   // Each workgroup owns a contiguous slice of frames; its waves take chunks of it
@@ -663,11 +674,72 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
       constexpr bool kAInRegs = C::kGroup > 1;   // |x| stays in registers: exchange 1 is shared by the group
       asm volatile("; MARK load");
       AMCX_STAMP(7);
+      // wave reduction of a frame's 27 per-lane sums into one stash row
+      auto reduce_sums = [&](float (&r28)[28], float (&r7)[7]) __attribute__((always_inline)) {
+        // two swap levels (lane bits 5, 4) halve the live values each time --
+        // v_permlane32_swap / v_permlane16_swap exchange half a register pair in one
+        // instruction -- then four DPP steps inside the 16-lane rows.  70 VALU ops
+        // against 162 for 27 independent 6-step butterflies.
+        // (inline asm: hipcc 7.2 folds the two results of __builtin_amdgcn_permlane*_swap
+        //  into one register here -- "v_add v3, v142, v142" -- so the swaps are spelled
+        //  out; one statement per level, opening with the two wait states a VALU
+        //  write -> v_permlane* read needs, which hipcc does not add inside asm.)
+        asm volatile(
+            "s_nop 1\n\t"
+            "v_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\t"
+            "v_permlane32_swap_b32 %4, %5\n\tv_permlane32_swap_b32 %6, %7\n\t"
+            "v_permlane32_swap_b32 %8, %9\n\tv_permlane32_swap_b32 %10, %11\n\t"
+            "v_permlane32_swap_b32 %12, %13\n\tv_permlane32_swap_b32 %14, %15\n\t"
+            "v_permlane32_swap_b32 %16, %17\n\tv_permlane32_swap_b32 %18, %19\n\t"
+            "v_permlane32_swap_b32 %20, %21\n\tv_permlane32_swap_b32 %22, %23\n\t"
+            "v_permlane32_swap_b32 %24, %25\n\tv_permlane32_swap_b32 %26, %27"
+            : "+v"(r28[0]), "+v"(r28[1]), "+v"(r28[2]), "+v"(r28[3]), "+v"(r28[4]), "+v"(r28[5]),
+              "+v"(r28[6]), "+v"(r28[7]), "+v"(r28[8]), "+v"(r28[9]), "+v"(r28[10]), "+v"(r28[11]),
+              "+v"(r28[12]), "+v"(r28[13]), "+v"(r28[14]), "+v"(r28[15]), "+v"(r28[16]), "+v"(r28[17]),
+              "+v"(r28[18]), "+v"(r28[19]), "+v"(r28[20]), "+v"(r28[21]), "+v"(r28[22]), "+v"(r28[23]),
+              "+v"(r28[24]), "+v"(r28[25]), "+v"(r28[26]), "+v"(r28[27]));
+        // lanes 0-31: value 2j summed over lane bit 5; lanes 32-63: value 2j+1
+        float r14[14];
+        static_for<14>([&](auto jj) {
+          constexpr int j = decltype(jj)::value;
+          r14[j] = r28[2 * j] + r28[2 * j + 1];
+        });
+        asm volatile(
+            "s_nop 1\n\t"
+            "v_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\t"
+            "v_permlane16_swap_b32 %4, %5\n\tv_permlane16_swap_b32 %6, %7\n\t"
+            "v_permlane16_swap_b32 %8, %9\n\tv_permlane16_swap_b32 %10, %11\n\t"
+            "v_permlane16_swap_b32 %12, %13"
+            : "+v"(r14[0]), "+v"(r14[1]), "+v"(r14[2]), "+v"(r14[3]), "+v"(r14[4]), "+v"(r14[5]),
+              "+v"(r14[6]), "+v"(r14[7]), "+v"(r14[8]), "+v"(r14[9]), "+v"(r14[10]), "+v"(r14[11]),
+              "+v"(r14[12]), "+v"(r14[13]));
+        // rows 0..3 now hold values 4j+0, 4j+2, 4j+1, 4j+3 summed over lane bits 5 and 4
+        static_for<7>([&](auto jj) {
+          constexpr int j = decltype(jj)::value;
+          float v = r14[2 * j] + r14[2 * j + 1];
+          v += dpp<kQuadXor1>(v);
+          v += dpp<kQuadXor2>(v);
+          v += dpp<kRowHalfMirror>(v);
+          v += dpp<kRowMirror>(v);
+          r7[j] = v;
+        });
+      };
+      auto store_sums = [&](const float (&r7)[7], float* row) __attribute__((always_inline)) {
+        if ((lane & 15) == 0) {                    // one lane per row: rows hold 4j + {0, 2, 1, 3}
+          const int rsel = lane >> 4;
+          float* dst = row + (((rsel & 1) << 1) | (rsel >> 1));
+          static_for<7>([&](auto jj) {
+            constexpr int j = decltype(jj)::value;
+            dst[4 * j] = r7[j];
+          });
+        }
+      };
 
       // =====================================================================
       // statistics sweep
       // =====================================================================
       Stats S;
+      float sa_flushed = 0.f;                    // this lane's sum of |x| over the stretches flushed so far
       float av[kAInRegs ? 2 * ROWS : 1];
       const float2* const src2 = iq + (f0 + g) * row_stride + 2 * lane;
       if constexpr (!C::kSplit2) {
@@ -689,6 +761,7 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
         // through a rolled loop instead, four rows in flight; the FFT branches re-read it
         // (L2 / Infinity Cache) into registers afterwards.
         auto ld = [&](int r) { return *reinterpret_cast<const float4*>(src2 + 128 * r); };
+        static_assert(C::kFlushes == 4 && C::kRows == 64, "flush points of the rolled sweep");
         float a0, a1;
         float4 ring[4];
         const float4 first = ld(0);
@@ -703,6 +776,16 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
             ring[k] = ld(nx < C::kRows ? nx : C::kRows - 1);
             S.template row<false, false>(cur.x, cur.y, cur.z, cur.w, lane, a0, a1);
           });
+          if (i + 3 < C::kRows - 4 && ((i + 3) & 15) == 0) {     // rows 0..16 | ..32 | ..48 | ..63
+            sa_flushed += S.sa;
+            float r28[28] = {S.sA, S.sBh, S.sP, S.sAA, S.sX4, S.sAB, S.sAP, S.sBP, S.sAAA, S.sABB,
+                             S.sAAB, S.sBBB, S.sAAP, S.sX4P, S.sABP, S.sa, 0.f, 0.f, 0.f,
+                             S.st1, S.st2, S.sab1, S.sab2, S.sw1, S.sw2, S.sw3, S.sw4, 0.f};
+            float q7[7];
+            reduce_sums(r28, q7);
+            store_sums(q7, stash + (g * C::kFlushes + ((i + 3) >> 4) - 1) * kStashStride);
+            S.clear_sums();
+          }
         }
         S.template row<false, false>(ring[0].x, ring[0].y, ring[0].z, ring[0].w, lane, a0, a1);
         S.template row<false, false>(ring[1].x, ring[1].y, ring[1].z, ring[1].w, lane, a0, a1);
@@ -712,7 +795,7 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
       AMCX_STAMP(0);
       __builtin_amdgcn_sched_barrier(0);
       // envelope second sweep about the exact mean (N = 8192: during the second visit below)
-      const float mu = bcast_l63(wave_sum_l63(S.sa)) * (1.0f / (float)N);
+      const float mu = bcast_l63(wave_sum_l63(S.sa + sa_flushed)) * (1.0f / (float)N);
       if constexpr (!C::kSplit2) {
         static_for<2 * ROWS>([&](auto ee) {
           constexpr int e = decltype(ee)::value;
@@ -733,67 +816,16 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
       asm volatile("; MARK reduce");
       AMCX_STAMP(3);
       __builtin_amdgcn_sched_barrier(0);
-      // two swap levels (lane bits 5, 4) halve the live values each time --
-      // v_permlane32_swap / v_permlane16_swap exchange half a register pair in one
-      // instruction -- then four DPP steps inside the 16-lane rows.  70 VALU ops
-      // against 162 for 27 independent 6-step butterflies.
-      float r28[28] = {S.sA, S.sBh, S.sP, S.sAA, S.sX4, S.sAB, S.sAP, S.sBP, S.sAAA, S.sABB,
-                       S.sAAB, S.sBBB, S.sAAP, S.sX4P, S.sABP, S.sa, S.sad1, S.sad2, S.sad4,
-                       S.st1, S.st2, S.sab1, S.sab2, S.sw1, S.sw2, S.sw3, S.sw4, 0.f};
-      // (inline asm: hipcc 7.2 folds the two results of __builtin_amdgcn_permlane*_swap
-      //  into one register here -- "v_add v3, v142, v142" -- so the swaps are spelled
-      //  out; one statement per level, opening with the two wait states a VALU
-      //  write -> v_permlane* read needs, which hipcc does not add inside asm.)
-      asm volatile(
-          "s_nop 1\n\t"
-          "v_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\t"
-          "v_permlane32_swap_b32 %4, %5\n\tv_permlane32_swap_b32 %6, %7\n\t"
-          "v_permlane32_swap_b32 %8, %9\n\tv_permlane32_swap_b32 %10, %11\n\t"
-          "v_permlane32_swap_b32 %12, %13\n\tv_permlane32_swap_b32 %14, %15\n\t"
-          "v_permlane32_swap_b32 %16, %17\n\tv_permlane32_swap_b32 %18, %19\n\t"
-          "v_permlane32_swap_b32 %20, %21\n\tv_permlane32_swap_b32 %22, %23\n\t"
-          "v_permlane32_swap_b32 %24, %25\n\tv_permlane32_swap_b32 %26, %27"
-          : "+v"(r28[0]), "+v"(r28[1]), "+v"(r28[2]), "+v"(r28[3]), "+v"(r28[4]), "+v"(r28[5]),
-            "+v"(r28[6]), "+v"(r28[7]), "+v"(r28[8]), "+v"(r28[9]), "+v"(r28[10]), "+v"(r28[11]),
-            "+v"(r28[12]), "+v"(r28[13]), "+v"(r28[14]), "+v"(r28[15]), "+v"(r28[16]), "+v"(r28[17]),
-            "+v"(r28[18]), "+v"(r28[19]), "+v"(r28[20]), "+v"(r28[21]), "+v"(r28[22]), "+v"(r28[23]),
-            "+v"(r28[24]), "+v"(r28[25]), "+v"(r28[26]), "+v"(r28[27]));
-      // lanes 0-31: value 2j summed over lane bit 5; lanes 32-63: value 2j+1
-      float r14[14];
-      static_for<14>([&](auto jj) {
-        constexpr int j = decltype(jj)::value;
-        r14[j] = r28[2 * j] + r28[2 * j + 1];
-      });
-      asm volatile(
-          "s_nop 1\n\t"
-          "v_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\t"
-          "v_permlane16_swap_b32 %4, %5\n\tv_permlane16_swap_b32 %6, %7\n\t"
-          "v_permlane16_swap_b32 %8, %9\n\tv_permlane16_swap_b32 %10, %11\n\t"
-          "v_permlane16_swap_b32 %12, %13"
-          : "+v"(r14[0]), "+v"(r14[1]), "+v"(r14[2]), "+v"(r14[3]), "+v"(r14[4]), "+v"(r14[5]),
-            "+v"(r14[6]), "+v"(r14[7]), "+v"(r14[8]), "+v"(r14[9]), "+v"(r14[10]), "+v"(r14[11]),
-            "+v"(r14[12]), "+v"(r14[13]));
-      // rows 0..3 now hold values 4j+0, 4j+2, 4j+1, 4j+3 summed over lane bits 5 and 4
+      float* const row = stash + (g * C::kFlushes + (C::kFlushes - 1)) * kStashStride;   // the frame's last row
       float r7[7];
-      static_for<7>([&](auto jj) {
-        constexpr int j = decltype(jj)::value;
-        float v = r14[2 * j] + r14[2 * j + 1];
-        v += dpp<kQuadXor1>(v);
-        v += dpp<kQuadXor2>(v);
-        v += dpp<kRowHalfMirror>(v);
-        v += dpp<kRowMirror>(v);
-        r7[j] = v;
-      });
-      const unsigned long long tie = __builtin_amdgcn_ballot_w64(S.wmax > kPi - kTieBand);
-      float* const row = stash + g * kStashStride;
-      if ((lane & 15) == 0) {                    // one lane per row: rows hold 4j + {0, 2, 1, 3}
-        const int rsel = lane >> 4;
-        float* dst = row + (((rsel & 1) << 1) | (rsel >> 1));
-        static_for<7>([&](auto jj) {
-          constexpr int j = decltype(jj)::value;
-          dst[4 * j] = r7[j];
-        });
+      {
+        float r28[28] = {S.sA, S.sBh, S.sP, S.sAA, S.sX4, S.sAB, S.sAP, S.sBP, S.sAAA, S.sABB,
+                         S.sAAB, S.sBBB, S.sAAP, S.sX4P, S.sABP, S.sa, S.sad1, S.sad2, S.sad4,
+                         S.st1, S.st2, S.sab1, S.sab2, S.sw1, S.sw2, S.sw3, S.sw4, 0.f};
+        reduce_sums(r28, r7);
       }
+      const unsigned long long tie = __builtin_amdgcn_ballot_w64(S.wmax > kPi - kTieBand);
+      store_sums(r7, row);                       // (after the ballot: the other order costs 30 VGPRs)
       if (lane == 63) {
         row[kNumSums + 1] = S.Kt;
         row[kNumSums + 2] = S.Kw;
@@ -942,14 +974,22 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
     // ---- batch finalisation: lane g turns frame g's sums into 18 features ----
     lds_wave_fence();
     if (lane < n_here) {
-      const float* row = stash + lane * kStashStride;
+      const float* row = stash + (lane * C::kFlushes + (C::kFlushes - 1)) * kStashStride;   // the frame's last row
+      auto sm = [&](int k) -> double {           // sum k of the frame: its stash rows added in fp64
+        double t = row[k];
+        if constexpr (C::kFlushes > 1) {
+#pragma unroll
+          for (int h = 1; h < C::kFlushes; ++h) t += (double)row[k - h * kStashStride];
+        }
+        return t;
+      };
       FrameSums F;
-      F.sA = row[0]; F.sBh = row[1]; F.sP = row[2]; F.sAA = row[3]; F.sX4 = row[4]; F.sAB = row[5];
-      F.sAP = row[6]; F.sBP = row[7]; F.sAAA = row[8]; F.sABB = row[9]; F.sAAB = row[10];
-      F.sBBB = row[11]; F.sAAP = row[12]; F.sX4P = row[13]; F.sABP = row[14];
-      F.sa = row[15]; F.sad1 = row[16]; F.sad2 = row[17]; F.sad4 = row[18];
-      F.std1 = row[19]; F.std2 = row[20]; F.sab1 = row[21]; F.sab2 = row[22];
-      F.swd1 = row[23]; F.swd2 = row[24]; F.swd3 = row[25]; F.swd4 = row[26];
+      F.sA = sm(0); F.sBh = sm(1); F.sP = sm(2); F.sAA = sm(3); F.sX4 = sm(4); F.sAB = sm(5);
+      F.sAP = sm(6); F.sBP = sm(7); F.sAAA = sm(8); F.sABB = sm(9); F.sAAB = sm(10);
+      F.sBBB = sm(11); F.sAAP = sm(12); F.sX4P = sm(13); F.sABP = sm(14);
+      F.sa = sm(15); F.sad1 = sm(16); F.sad2 = sm(17); F.sad4 = sm(18);
+      F.std1 = sm(19); F.std2 = sm(20); F.sab1 = sm(21); F.sab2 = sm(22);
+      F.swd1 = sm(23); F.swd2 = sm(24); F.swd3 = sm(25); F.swd4 = sm(26);
       F.gmax_raw = row[27]; F.Kt = row[28]; F.Kw = row[29]; F.Ka = row[30];
       F.pi_tie = row[31] != 0.0f;
       float feat[18];

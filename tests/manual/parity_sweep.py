@@ -12,7 +12,7 @@ from amcpy_amd.features import features18
 from oracle import iq_features_oracle as orc
 
 frames_per = int(sys.argv[1]) if len(sys.argv) > 1 else 12
-for N in (128, 256, 512, 1000, 1024, 1536, 2048, 4096):
+for N in (128, 256, 512, 1000, 1024, 1536, 2048, 4096, 8192):
     worst_s = np.zeros(18); worst_p = np.zeros(18); n = 0
     t0 = time.time()
     for mi, mod in enumerate(synth.MODS6):
