@@ -80,6 +80,11 @@ inline hipError_t launch_tie_fix(const float2* iq, int64_t n_frames, int32_t N, 
                                  float* out, int64_t out_stride, hipStream_t stream, int cus) {
   const size_t lds = (size_t)8 * (N + (N & 1)) + sizeof(double) * kBlockWaves * kMaxReduce +
                      sizeof(int) * (kFixListCap + 4);
+  if (lds > 64 * 1024) {   // N = 8192: 68.5 KiB of dynamic LDS needs the attribute (idempotent, no allocation)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(amcx_step_tie_fix_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
   int64_t grid = (int64_t)cus * 16;     // few flagged frames per workgroup: they are handled one at a time
   const int64_t max_grid = (n_frames + 63) / 64;
   if (grid > max_grid) grid = max_grid;
