@@ -6,13 +6,14 @@ Runs ONLY in the build container, where the reference is mounted read-only at
 (``tests/golden/*.npz`` / ``*.json``).  The GPU box has no reference: tests
 there read these fixtures.
 
-    python oracle/capture_golden.py            # regenerate every fixture
+    python oracle/capture_golden.py                      # regenerate every fixture
+    python oracle/capture_golden.py frames 128 512 8192  # only these frames_n{N}.npz
 
 Fixtures:
   kat_n10.json            the reference's own known-answer vector and table
                           (features.py:240-255, 286-305) restated as data
-  frames_n{N}.npz         N in {1024, 2048, 4096}: 6 mods x 3 SNR x 2 frames
-                          complex64 inputs; golden64 (reference on complex128
+  frames_n{N}.npz         N in {128, 512, 1024, 2048, 4096}: 6 mods x 3 SNR x 2 frames
+                          (N = 8192: 6 mods x 1 SNR x 2) complex64 inputs; golden64 (reference on complex128
                           input, float32-stored as feature_extraction.py:35,56
                           does) + its unrounded float64; golden32 (reference on
                           the complex64 input as is); the 11 moments
@@ -93,7 +94,7 @@ def capture_kat(rfeat):
 
 def capture_frames(rfeat, N):
     from amcpy_amd import synth
-    snrs = (-10.0, 4.0, 20.0)
+    snrs = (-10.0, 4.0, 20.0) if N <= 4096 else (4.0,)        # N = 8192: 12 frames keep the fixture under 1 MB
     frames, tags = [], []
     for mi, mod in enumerate(synth.MODS6):
         for si, snr in enumerate(snrs):
@@ -201,8 +202,14 @@ def main():
     os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
     OUT.mkdir(parents=True, exist_ok=True)
     rfeat, rfe, rcfg = _import_reference()
+    if len(sys.argv) > 2 and sys.argv[1] == "frames":
+        for N in map(int, sys.argv[2:]):
+            capture_frames(rfeat, N)
+            p = OUT / f"frames_n{N}.npz"
+            print(f"{p.name:28s} {p.stat().st_size:9d} B")
+        return
     capture_kat(rfeat)
-    for N in (1024, 2048, 4096):
+    for N in (128, 512, 1024, 2048, 4096, 8192):
         capture_frames(rfeat, N)
     for N in (1000, 2048):
         capture_edges(rfeat, N)

@@ -135,7 +135,7 @@ def test_random_frames_against_oracle():
     """Seeded synthetic frames the oracle finishes in seconds, every modulation
     and a wide SNR range, each power-of-two size the fast kernel serves."""
     from amcpy_amd import synth
-    for N in (1024, 2048, 4096):
+    for N in (128, 256, 512, 1024, 2048, 4096, 8192):
         blocks = [synth.host_block(m, snr, 8, N, seed=77 + 13 * i + j)
                   for i, m in enumerate(synth.MODS6) for j, snr in enumerate((-20.0, -6.0, 8.0, 30.0))]
         x = np.concatenate(blocks).astype(np.complex64)
