@@ -81,7 +81,7 @@ struct Cfg {
   // how many times per frame the per-lane fp32 sums are reduced into the stash and started
   // afresh (the finaliser adds the rows in fp64): at N = 8192 a lane would otherwise run 128
   // samples into one accumulator, and C40 reached 1.1e-5 of its conditioning scale
-  static constexpr int kFlushes = N == 8192 ? 4 : 1;
+  static constexpr int kFlushes = N == 8192 ? 4 : (N == 4096 ? 2 : 1);
   static constexpr int kStashBytes = kFramesPerWave * kFlushes * kStashStride * 4;
   // next frame of the chunk loaded into a second register set while this one is processed
   static constexpr bool kPrefetch = N <= 1024;
@@ -753,6 +753,18 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
           } else if constexpr (!C::kSplit) {
             a_lds[(2 * i) * 64] = a0;
             a_lds[(2 * i + 1) * 64] = a1;
+          }
+          if constexpr (C::kFlushes == 2 && i == ROWS / 2 - 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            sa_flushed += S.sa;
+            float r28[28] = {S.sA, S.sBh, S.sP, S.sAA, S.sX4, S.sAB, S.sAP, S.sBP, S.sAAA, S.sABB,
+                             S.sAAB, S.sBBB, S.sAAP, S.sX4P, S.sABP, S.sa, 0.f, 0.f, 0.f,
+                             S.st1, S.st2, S.sab1, S.sab2, S.sw1, S.sw2, S.sw3, S.sw4, 0.f};
+            float q7[7];
+            reduce_sums(r28, q7);
+            store_sums(q7, stash + (g * C::kFlushes) * kStashStride);
+            S.clear_sums();
+            __builtin_amdgcn_sched_barrier(0);
           }
         });
       } else {
