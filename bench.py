@@ -144,12 +144,16 @@ def _ensure_library(local_rank: int):
         time.sleep(1.0)
 
 
-def _config_label(frame_size, n_frames):
-    """Which BASELINE.json config the chosen shape is (the default run is configs[1])."""
-    if n_frames == N_FRAMES and frame_size == FRAME_SIZE:
+def _config_label(frame_size, n_frames, n_mods, world):
+    """Which BASELINE.json config the chosen per-GPU shape is (the default run is configs[1])."""
+    if n_mods == N_MODS and n_frames == N_FRAMES and frame_size == FRAME_SIZE:
         return "BASELINE configs[1]"
-    if n_frames == N_FRAMES and frame_size == 4096:
+    if n_mods == N_MODS and n_frames == N_FRAMES and frame_size == 4096:
         return "BASELINE configs[2]"
+    if n_mods == N_MODS and n_frames * world == 65536 and frame_size == FRAME_SIZE:
+        return f"BASELINE configs[3], frames sharded x{world}"
+    if n_mods * world == 24 and n_frames == N_FRAMES and frame_size == 1024:
+        return f"BASELINE configs[4], modulations sharded x{world}"
     return "not a BASELINE config"
 
 
@@ -159,6 +163,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=N_FRAMES, help="frames per (mod, SNR) block")
+    ap.add_argument("--mods", type=int, default=N_MODS,
+                    help="modulations per GPU (configs[4]: 24 over 8 GPUs = 3 with --frame-size 1024)")
     ap.add_argument("--variant", default="auto", choices=["auto", "block", "wave"])
     ap.add_argument("--frame-size", type=int, default=FRAME_SIZE,
                     help="samples per frame (the BASELINE metric is quoted at 2048; 1024/4096 are the other configs)")
@@ -201,12 +207,13 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # ---- resident shard: (mods, snr, frames, N) complex64 arena in HBM --------
-    arena = torch.empty((N_MODS, N_SNR, args.frames, FS), dtype=torch.complex64, device=dev)
-    for mi, mod in enumerate(synth.MODS6):
-        synth.device_frames(mod, N_SNR, args.frames, FS, device=dev, rank=rank,
+    n_mods = args.mods
+    arena = torch.empty((n_mods, N_SNR, args.frames, FS), dtype=torch.complex64, device=dev)
+    for mi in range(n_mods):
+        synth.device_frames(synth.MODS6[mi % 6], N_SNR, args.frames, FS, device=dev, rank=rank,
                             mod_idx=mi, out=arena[mi])
-    frames_per_launch = N_MODS * N_SNR * args.frames
-    out = torch.empty((N_MODS, N_SNR, args.frames, 18), dtype=torch.float32, device=dev)
+    frames_per_launch = n_mods * N_SNR * args.frames
+    out = torch.empty((n_mods, N_SNR, args.frames, 18), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
 
     def step():
@@ -274,8 +281,9 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": f"{N_MODS} mods x {N_SNR} SNR x {args.frames} frames x {FS} samples "
-                        f"complex64 per GPU ({_config_label(FS, args.frames)}), resident in HBM; one launch per step",
+            "workload": f"{n_mods} mods x {N_SNR} SNR x {args.frames} frames x {FS} samples "
+                        f"complex64 per GPU ({_config_label(FS, args.frames, n_mods, world)}), resident in HBM; "
+                        f"one launch per step",
             "frames_per_gpu_per_step": frames_per_launch, "frame_size": FS,
             "kernel": _lib.kernel_name(FS, _lib.VARIANTS[args.variant]),
             "sharding": f"frames x{world}, no collective on the data path",
