@@ -29,6 +29,10 @@ SIGNATURES = {
     "amcx_features18_c64_ex": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i64, _vp, _i32]),
     "amcx_features18_c64_host": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i64, _i32, _i32]),
     "amcx_features18_c128_host": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i64, _i32, _i32]),
+    "amcx_ctx_create": (C.c_int, [_i32, C.POINTER(_vp)]),
+    "amcx_ctx_destroy": (C.c_int, [_vp]),
+    "amcx_ctx_features18_c64_host": (C.c_int, [_vp, _vp, _i64, _i32, _i64, _vp, _i64, _i32]),
+    "amcx_ctx_features18_c128_host": (C.c_int, [_vp, _vp, _i64, _i32, _i64, _vp, _i64, _i32]),
     "amcx_kernel_name": (C.c_int, [_i32, _i32, C.c_char_p, _i32]),
     "amcx_probe_read_bw": (C.c_int, [_vp, _i64, _vp, _vp]),
     "amcx_group_stats_f32": (C.c_int, [_vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp]),
@@ -85,3 +89,32 @@ def kernel_name(frame_size: int, variant: int = VARIANT_AUTO) -> str:
     buf = C.create_string_buffer(128)
     check(load().amcx_kernel_name(frame_size, variant, buf, len(buf)))
     return buf.value.decode()
+
+
+class HostContext:
+    """Reusable host-buffer context (amcx_ctx_*): a stream and growing device scratch kept
+    across calls.  One per thread and device; freed with the object."""
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        self.device = int(device)
+        check(load().amcx_ctx_create(self.device, C.byref(self._h)))
+
+    def run(self, x2, frame_size: int, out, variant: int) -> None:
+        """x2: C-contiguous (F, L) complex64 / complex128 ndarray; out: (F, >=18) float32."""
+        import numpy as np
+        lib = load()
+        entry = lib.amcx_ctx_features18_c128_host if x2.dtype == np.complex128 else lib.amcx_ctx_features18_c64_host
+        check(entry(self._h, x2.ctypes.data, x2.shape[0], int(frame_size), x2.shape[1],
+                    out.ctypes.data, out.shape[1], int(variant)))
+
+    def close(self) -> None:
+        if self._h:
+            load().amcx_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
+#include <new>
 
 #include "amcx_block_kernel.h"
 #include "amcx_wave_kernel.h"
@@ -69,9 +70,20 @@ int launch_block(const float2* iq, int64_t n_frames, int32_t N, int64_t row_stri
   auto kern = mode == amcx::kBlockPow2        ? amcx::amcx_features18_block_kernel<amcx::kBlockPow2>
               : mode == amcx::kBlockBluestein ? amcx::amcx_features18_block_kernel<amcx::kBlockBluestein>
                                               : amcx::amcx_features18_block_kernel<amcx::kBlockDirect>;
-  if (lds > 64 * 1024)
-    AMCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  // > 64 KiB of dynamic LDS needs the attribute.  It is set once per (kernel, device) to the most any
+  // frame size can ask for, never per launch: two host threads launching different N would otherwise
+  // race between one's attribute and the other's launch.
+  {
+    static bool attr_set[3][64] = {};
+    constexpr int kMaxLds = 16 * AMCX_MAX_FRAME_SIZE + amcx::kBlockScratchBytes + amcx::kBlockTwiddleBytes;
+    int dev = 0;
+    AMCX_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_set[mode][dev]) {
+      AMCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+      if (dev >= 0 && dev < 64) attr_set[mode][dev] = true;   // benign race: idempotent
+    }
+  }
   // enough workgroups to fill every CU at the occupancy LDS allows, grid-stride beyond
   const int per_cu = (int)((160 * 1024) / lds) < 1 ? 1 : (int)((160 * 1024) / lds);
   int64_t grid = (int64_t)cu_count() * (per_cu > 8 ? 8 : per_cu) * 4;
@@ -189,112 +201,174 @@ int amcx_features18_c64(const void* iq_dev, int64_t n_frames, int32_t frame_size
                                 out_row_stride, hip_stream, AMCX_VARIANT_AUTO);
 }
 
-int amcx_features18_c64_host(const void* iq_host, int64_t n_frames, int32_t frame_size,
-                             int64_t row_stride_elems, float* out_host, int64_t out_row_stride,
-                             int32_t device, int32_t variant) {
+// ---- host-buffer entry points over a reusable context --------------------------------------
+// The context owns a stream and device scratch that only ever grows, so a loop of per-frame
+// calls (the reference's usage pattern, features.py:214-232 called once per queue item) pays
+// two small copies and the launches, not hipMalloc/hipFree/stream creation per call.
+struct amcx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  void* d_in = nullptr;   size_t in_cap = 0;     // uploaded rows (complex64 or complex128)
+  void* d_c64 = nullptr;  size_t c64_cap = 0;    // complex128 rows rounded to complex64
+  float* d_out = nullptr; size_t out_cap = 0;
+};
+
+}  // extern "C"
+
+namespace {
+
+int ctx_reserve(void** p, size_t* cap, size_t bytes) {
+  if (*cap >= bytes) return AMCX_OK;
+  if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
+  // grow geometrically so a slowly growing batch size does not reallocate every call
+  size_t want = bytes < (size_t(1) << 20) ? bytes : bytes + bytes / 4;
+  if (hipMalloc(p, want) != hipSuccess) {
+    (void)hipGetLastError();
+    if (want == bytes || hipMalloc(p, bytes) != hipSuccess) { (void)hipGetLastError(); *p = nullptr; return AMCX_ENOMEM; }
+    want = bytes;
+  }
+  *cap = want;
+  return AMCX_OK;
+}
+
+struct DeviceGuard {
+  int prev = -1;
+  hipError_t enter(int dev) {
+    hipError_t e = hipGetDevice(&prev);
+    if (e != hipSuccess) { prev = -1; return e; }
+    return hipSetDevice(dev);
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+int ctx_run(amcx_ctx* c, const void* iq_host, bool is_c128, int64_t n_frames, int32_t frame_size,
+            int64_t row_stride_elems, float* out_host, int64_t out_row_stride, int32_t variant) {
+  if (c == nullptr) return AMCX_EINVAL;
   if (n_frames < 0 || row_stride_elems < frame_size || out_row_stride < AMCX_NUM_FEATURES)
     return AMCX_EINVAL;
   const int v = resolve_variant(frame_size, variant);
   if (v < 0) return v;
   if (n_frames == 0) return AMCX_OK;
   if (iq_host == nullptr || out_host == nullptr) return AMCX_EINVAL;
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
-    return AMCX_ENODEV;
-  int prev = 0;
-  AMCX_HIP(hipGetDevice(&prev));
-  AMCX_HIP(hipSetDevice(device));
-  void* d_iq = nullptr;
-  float* d_out = nullptr;
-  hipStream_t stream = nullptr;
-  int rc = AMCX_OK;
-  const size_t row_bytes = (size_t)frame_size * 8;
-  // frames are packed on the device (row stride == frame_size), so rows longer
-  // than frame_size (feature_extraction.py:68) cost no HBM or PCIe bytes
-  if (hipMalloc(&d_iq, row_bytes * (size_t)n_frames) != hipSuccess ||
-      hipMalloc(reinterpret_cast<void**>(&d_out), sizeof(float) * AMCX_NUM_FEATURES * (size_t)n_frames) != hipSuccess) {
-    (void)hipGetLastError();
-    rc = AMCX_ENOMEM;
-  }
+  DeviceGuard guard;
+  AMCX_HIP(guard.enter(c->device));
+  const size_t elem = is_c128 ? 16 : 8;
+  const size_t row_in = (size_t)frame_size * elem;
+  // rows are packed on the device (row stride == frame_size), so rows longer than frame_size
+  // (feature_extraction.py:68) cost no HBM or PCIe bytes; at most ~512 MiB go up at a time
+  int64_t per = (int64_t)((512ull << 20) / row_in);
+  if (per < 1) per = 1;
+  if (per > n_frames) per = n_frames;
+  int rc = ctx_reserve(&c->d_in, &c->in_cap, row_in * (size_t)per);
+  if (rc == AMCX_OK && is_c128) rc = ctx_reserve(&c->d_c64, &c->c64_cap, (size_t)frame_size * 8 * (size_t)per);
+  if (rc == AMCX_OK)
+    rc = ctx_reserve(reinterpret_cast<void**>(&c->d_out), &c->out_cap,
+                     sizeof(float) * AMCX_NUM_FEATURES * (size_t)per);
+  if (rc != AMCX_OK) return rc;
+  const char* src = static_cast<const char*>(iq_host);
   hipError_t e = hipSuccess;
-  if (rc == AMCX_OK) e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
-  if (rc == AMCX_OK && e == hipSuccess)
-    e = hipMemcpy2DAsync(d_iq, row_bytes, iq_host, (size_t)row_stride_elems * 8, row_bytes,
-                         (size_t)n_frames, hipMemcpyHostToDevice, stream);
-  if (rc == AMCX_OK && e == hipSuccess) {
-    rc = amcx_features18_c64_ex(d_iq, n_frames, frame_size, frame_size, d_out, AMCX_NUM_FEATURES,
-                                stream, v);
-    if (rc == AMCX_OK)
-      e = hipMemcpy2DAsync(out_host, sizeof(float) * (size_t)out_row_stride, d_out,
-                           sizeof(float) * AMCX_NUM_FEATURES, sizeof(float) * AMCX_NUM_FEATURES,
-                           (size_t)n_frames, hipMemcpyDeviceToHost, stream);
-    if (rc == AMCX_OK && e == hipSuccess) e = hipStreamSynchronize(stream);
+  for (int64_t f0 = 0; f0 < n_frames; f0 += per) {
+    const int64_t nf = (n_frames - f0) < per ? (n_frames - f0) : per;
+    e = hipMemcpy2DAsync(c->d_in, row_in, src + (size_t)f0 * (size_t)row_stride_elems * elem,
+                         (size_t)row_stride_elems * elem, row_in, (size_t)nf, hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) break;
+    const void* d_frames = c->d_in;
+    if (is_c128) {
+      hipLaunchKernelGGL(amcx_c128_to_c64_kernel, dim3(2048), dim3(256), 0, c->stream,
+                         static_cast<const double2*>(c->d_in), (long long)nf, (int)frame_size,
+                         (long long)frame_size, static_cast<float2*>(c->d_c64));
+      e = hipGetLastError();
+      if (e != hipSuccess) break;
+      d_frames = c->d_c64;
+    }
+    rc = amcx_features18_c64_ex(d_frames, nf, frame_size, frame_size, c->d_out, AMCX_NUM_FEATURES, c->stream, v);
+    if (rc != AMCX_OK) break;
+    e = hipMemcpy2DAsync(out_host + (size_t)f0 * (size_t)out_row_stride, sizeof(float) * (size_t)out_row_stride,
+                         c->d_out, sizeof(float) * AMCX_NUM_FEATURES, sizeof(float) * AMCX_NUM_FEATURES,
+                         (size_t)nf, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // the scratch is reused by the next chunk / call
+    if (e != hipSuccess) break;
   }
-  if (rc == AMCX_OK && e != hipSuccess) rc = hip_fail(e, "amcx_features18_c64_host");
-  if (stream) (void)hipStreamDestroy(stream);
-  if (d_iq) (void)hipFree(d_iq);
-  if (d_out) (void)hipFree(d_out);
-  (void)hipSetDevice(prev);
+  if (rc == AMCX_OK && e != hipSuccess) rc = hip_fail(e, "amcx_ctx_features18 host entry");
   return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int amcx_ctx_create(int32_t device, amcx_ctx** ctx_out) {
+  if (ctx_out == nullptr) return AMCX_EINVAL;
+  *ctx_out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+    (void)hipGetLastError();
+    return AMCX_ENODEV;
+  }
+  DeviceGuard guard;
+  AMCX_HIP(guard.enter(device));
+  amcx_ctx* c = new (std::nothrow) amcx_ctx();
+  if (c == nullptr) return AMCX_ENOMEM;
+  c->device = device;
+  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreateWithFlags"); }
+  *ctx_out = c;
+  return AMCX_OK;
+}
+
+int amcx_ctx_destroy(amcx_ctx* c) {
+  if (c == nullptr) return AMCX_OK;
+  DeviceGuard guard;
+  (void)guard.enter(c->device);
+  if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+  if (c->d_in) (void)hipFree(c->d_in);
+  if (c->d_c64) (void)hipFree(c->d_c64);
+  if (c->d_out) (void)hipFree(c->d_out);
+  delete c;
+  return AMCX_OK;
+}
+
+int amcx_ctx_features18_c64_host(amcx_ctx* ctx, const void* iq_host, int64_t n_frames, int32_t frame_size,
+                                 int64_t row_stride_elems, float* out_host, int64_t out_row_stride,
+                                 int32_t variant) {
+  return ctx_run(ctx, iq_host, false, n_frames, frame_size, row_stride_elems, out_host, out_row_stride, variant);
+}
+
+int amcx_ctx_features18_c128_host(amcx_ctx* ctx, const void* iq_host, int64_t n_frames, int32_t frame_size,
+                                  int64_t row_stride_elems, float* out_host, int64_t out_row_stride,
+                                  int32_t variant) {
+  return ctx_run(ctx, iq_host, true, n_frames, frame_size, row_stride_elems, out_host, out_row_stride, variant);
+}
+
+// one-shot forms: a context for the duration of the call
+static int one_shot(const void* iq_host, bool is_c128, int64_t n_frames, int32_t frame_size,
+                    int64_t row_stride_elems, float* out_host, int64_t out_row_stride, int32_t device,
+                    int32_t variant) {
+  // argument errors are reported before a device is looked for (tests/test_host_cpu.py runs without one)
+  if (n_frames < 0 || row_stride_elems < frame_size || out_row_stride < AMCX_NUM_FEATURES)
+    return AMCX_EINVAL;
+  const int v = resolve_variant(frame_size, variant);
+  if (v < 0) return v;
+  if (n_frames == 0) return AMCX_OK;
+  if (iq_host == nullptr || out_host == nullptr) return AMCX_EINVAL;
+  amcx_ctx* c = nullptr;
+  int rc = amcx_ctx_create(device, &c);
+  if (rc != AMCX_OK) return rc;
+  rc = ctx_run(c, iq_host, is_c128, n_frames, frame_size, row_stride_elems, out_host, out_row_stride, v);
+  (void)amcx_ctx_destroy(c);
+  return rc;
+}
+
+int amcx_features18_c64_host(const void* iq_host, int64_t n_frames, int32_t frame_size,
+                             int64_t row_stride_elems, float* out_host, int64_t out_row_stride,
+                             int32_t device, int32_t variant) {
+  return one_shot(iq_host, false, n_frames, frame_size, row_stride_elems, out_host, out_row_stride, device, variant);
 }
 
 int amcx_features18_c128_host(const void* iq_host, int64_t n_frames, int32_t frame_size,
                               int64_t row_stride_elems, float* out_host, int64_t out_row_stride,
                               int32_t device, int32_t variant) {
-  if (n_frames < 0 || row_stride_elems < frame_size || out_row_stride < AMCX_NUM_FEATURES)
-    return AMCX_EINVAL;
-  const int v = resolve_variant(frame_size, variant);
-  if (v < 0) return v;
-  if (n_frames == 0) return AMCX_OK;
-  if (iq_host == nullptr || out_host == nullptr) return AMCX_EINVAL;
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
-    return AMCX_ENODEV;
-  int prev = 0;
-  AMCX_HIP(hipGetDevice(&prev));
-  AMCX_HIP(hipSetDevice(device));
-  // chunk: at most ~512 MiB of doubles on the device at a time
-  const size_t row16 = (size_t)frame_size * 16;
-  int64_t per = (int64_t)((512ull << 20) / row16);
-  if (per < 1) per = 1;
-  if (per > n_frames) per = n_frames;
-  void *d_in = nullptr, *d_c64 = nullptr;
-  float* d_out = nullptr;
-  hipStream_t stream = nullptr;
-  int rc = AMCX_OK;
-  hipError_t e = hipSuccess;
-  if (hipMalloc(&d_in, row16 * (size_t)per) != hipSuccess ||
-      hipMalloc(&d_c64, (row16 / 2) * (size_t)per) != hipSuccess ||
-      hipMalloc(reinterpret_cast<void**>(&d_out), sizeof(float) * AMCX_NUM_FEATURES * (size_t)per) != hipSuccess) {
-    (void)hipGetLastError();
-    rc = AMCX_ENOMEM;
-  }
-  if (rc == AMCX_OK) e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
-  const char* src = static_cast<const char*>(iq_host);
-  for (int64_t f0 = 0; rc == AMCX_OK && e == hipSuccess && f0 < n_frames; f0 += per) {
-    const int64_t nf = (n_frames - f0) < per ? (n_frames - f0) : per;
-    e = hipMemcpy2DAsync(d_in, row16, src + (size_t)f0 * (size_t)row_stride_elems * 16,
-                         (size_t)row_stride_elems * 16, row16, (size_t)nf, hipMemcpyHostToDevice, stream);
-    if (e != hipSuccess) break;
-    hipLaunchKernelGGL(amcx_c128_to_c64_kernel, dim3(2048), dim3(256), 0, stream,
-                       static_cast<const double2*>(d_in), (long long)nf, (int)frame_size,
-                       (long long)frame_size, static_cast<float2*>(d_c64));
-    e = hipGetLastError();
-    if (e != hipSuccess) break;
-    rc = amcx_features18_c64_ex(d_c64, nf, frame_size, frame_size, d_out, AMCX_NUM_FEATURES, stream, v);
-    if (rc != AMCX_OK) break;
-    e = hipMemcpy2DAsync(out_host + (size_t)f0 * (size_t)out_row_stride, sizeof(float) * (size_t)out_row_stride,
-                         d_out, sizeof(float) * AMCX_NUM_FEATURES, sizeof(float) * AMCX_NUM_FEATURES,
-                         (size_t)nf, hipMemcpyDeviceToHost, stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);   // d_in / d_out are reused by the next chunk
-  }
-  if (rc == AMCX_OK && e != hipSuccess) rc = hip_fail(e, "amcx_features18_c128_host");
-  if (stream) (void)hipStreamDestroy(stream);
-  if (d_in) (void)hipFree(d_in);
-  if (d_c64) (void)hipFree(d_c64);
-  if (d_out) (void)hipFree(d_out);
-  (void)hipSetDevice(prev);
-  return rc;
+  return one_shot(iq_host, true, n_frames, frame_size, row_stride_elems, out_host, out_row_stride, device, variant);
 }
 
 int amcx_kernel_name(int32_t frame_size, int32_t variant, char* buf, int32_t buf_len) {

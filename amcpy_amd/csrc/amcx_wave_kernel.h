@@ -66,7 +66,7 @@ constexpr int kStashStride = 33;                // 32 floats used per frame; odd
 
 constexpr int kEx1StrideKK = 136, kEx1StrideB = 68;   // complex units (tools/wave_fft_model.py)
 constexpr int kEx2StrideK2 = 65;
-constexpr int kExchangeBytes = 8 * kEx1StrideKK * 8;   // 8704 >= 16*65*8 = 8320
+constexpr int kExchangeBytes = (7 * kEx1StrideKK + kEx1StrideB + 64) * 8;   // 8672: last complex slot exchange 1 touches; >= 16*65*8 = 8320
 constexpr int kT2Bytes = 15 * 8 * 8;                   // [k2-1][n3] complex
 
 template <int N>
@@ -77,7 +77,11 @@ struct Cfg {
   static constexpr bool kSplit2 = N == 8192;           // ... and a second one in front of that
   // frames per wave per batch, finalised together one frame per lane: the fp64 algebra costs
   // the same per batch whatever N is, so short frames come in larger batches
+#ifdef AMCX_EXP_WAVES16   // experiment: 4 waves per SIMD (tools/wave_clock.hip)
+  static constexpr int kFramesPerWave = N == 2048 ? 4 : N >= 1024 ? 8 : (N == 512 ? 16 : 32);
+#else
   static constexpr int kFramesPerWave = N >= 1024 ? 8 : (N == 512 ? 16 : 32);
+#endif
   // how many times per frame the per-lane fp32 sums are reduced into the stash and started
   // afresh (the finaliser adds the rows in fp64): at N = 8192 a lane would otherwise run 128
   // samples into one accumulator, and C40 reached 1.1e-5 of its conditioning scale
@@ -93,7 +97,11 @@ struct Cfg {
   static constexpr int kTailChunk = kGroup > 2 ? kGroup : 2;
   // waves per workgroup = waves per CU: 3 per SIMD at 161-168 VGPRs, 2 per SIMD when the
   // frame alone takes 128 VGPRs (16 waves at N = 1024, 114 VGPRs, measured no faster: power-bound)
+#ifdef AMCX_EXP_WAVES16
+  static constexpr int kWavesPerWG = kSplit ? 8 : 16;
+#else
   static constexpr int kWavesPerWG = kSplit ? 8 : 12;
+#endif
   static constexpr int kThreads = 64 * kWavesPerWG;
   static constexpr int kTailFrames = kWavesPerWG * kFramesPerWave;
   static constexpr int kRows = N / 128;                // rows of 128 samples per frame
@@ -244,8 +252,12 @@ __device__ __forceinline__ void lds_wave_fence() {
 // Diagnostic build only (tools/wave_stamps.hip defines AMCX_WAVE_STAMPS): per-section
 // s_memtime deltas summed per wave into a buffer nothing else reads.  The product
 // build compiles none of this.
+// AMCX_WAVE_STAMPS == 2 (tools/wave_clock.hip): the product instruction stream with ONE
+// s_memtime / s_memrealtime pair around the whole frame loop -- the in-kernel clock the way
+// MI355X_MICROARCH.md "DVFS give-back" (6) prescribes; no per-section stamp executes.
 #ifdef AMCX_WAVE_STAMPS
 #define AMCX_STAMP_ARG , unsigned long long* __restrict__ stamp_out
+#if AMCX_WAVE_STAMPS == 1
 #define AMCX_STAMP(sec)                                                               \
   do {                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                \
@@ -255,6 +267,9 @@ __device__ __forceinline__ void lds_wave_fence() {
     stamp_acc[sec] += t_ - stamp_last;                                                \
     stamp_last = t_;                                                                  \
   } while (0)
+#else
+#define AMCX_STAMP(sec) do { } while (0)
+#endif
 #else
 #define AMCX_STAMP_ARG
 #define AMCX_STAMP(sec) do { } while (0)
@@ -663,7 +678,11 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
         constexpr int i = decltype(ii)::value;
         typedef float v4f __attribute__((ext_vector_type(4)));
         const v4f* p = reinterpret_cast<const v4f*>(src + 128 * i);
+#ifdef AMCX_EXP_PLAIN_LOADS   // experiment (tools/wave_clock.hip): default cache policy instead of nt
+        const v4f v = *p;
+#else
         const v4f v = C::kSplit2 ? *p : __builtin_nontemporal_load(p);   // N = 8192 visits a frame twice
+#endif
         xr[2 * i] = v.x; xi[2 * i] = v.y; xr[2 * i + 1] = v.z; xi[2 * i + 1] = v.w;
       });
     };
@@ -746,7 +765,11 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
         static_for<ROWS>([&](auto ii) {
           constexpr int i = decltype(ii)::value;
           float a0, a1;
+#ifdef AMCX_ABL_NOSTATS   // diagnostic ablation (tools/wave_clock.hip): results are wrong on purpose
+          a0 = xr[2 * i]; a1 = xi[2 * i + 1];
+#else
           S.template row<i == 0, i == ROWS - 1>(xr[2 * i], xi[2 * i], xr[2 * i + 1], xi[2 * i + 1], lane, a0, a1);
+#endif
           if constexpr (kAInRegs) {
             av[2 * i] = a0;
             av[2 * i + 1] = a1;
@@ -856,7 +879,11 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
         fft_front<R, SLOT * R>(xr, xi, la);     // the group's shared back half follows the last frame
         return;
       } else if constexpr (!C::kSplit) {
+#ifdef AMCX_ABL_NOFFT     // diagnostic ablation (tools/wave_clock.hip)
+        peak = xr[0] + xi[2 * ROWS - 1];
+#else
         peak = fft_peak<R>(xr, xi, la);
+#endif
       } else {
         // 4096 points in registers: radix-2 DIF split, s = y[n] + y[n+2048],
         // d = (y[n] - y[n+2048]) * W_4096^n,  n = 128 i + 2 l + b,  W_4096^n = W_32^i * W_4096^(2l+b)
@@ -1017,6 +1044,9 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
   if (lane == 0) {
     const long long w = (long long)blockIdx.x * kWavesPerWG + wave;
     stamp_acc[6] = __builtin_amdgcn_s_memrealtime() - real0;   // wave lifetime, 100 MHz ticks
+#if AMCX_WAVE_STAMPS != 1
+    stamp_acc[0] = __builtin_amdgcn_s_memtime() - stamp_last;  // the same span in shader cycles
+#endif
     for (int k = 0; k < kStampSections; ++k) stamp_out[w * kStampSections + k] = stamp_acc[k];
   }
 #endif

@@ -16,6 +16,7 @@ Feature ids (reference config.py:118-137): 1 gamma_max, 2 sigma_ap,
 """
 from __future__ import annotations
 
+import threading
 from typing import Iterable, List
 
 import numpy as np
@@ -94,6 +95,21 @@ def features18_iq_pairs(iq_pairs, **kw):
     return features18(torch.view_as_complex(iq_pairs), **kw)
 
 
+_tls = threading.local()
+
+
+def _host_context(device: int) -> "_lib.HostContext":
+    """This thread's reusable context for `device` (amcx_ctx_*: stream + device scratch kept
+    across calls, so calculate_features in a loop is not allocation-bound)."""
+    cache = getattr(_tls, "ctx", None)
+    if cache is None:
+        cache = _tls.ctx = {}
+    ctx = cache.get(device)
+    if ctx is None:
+        ctx = cache[device] = _lib.HostContext(device)
+    return ctx
+
+
 def features18_host(frames: np.ndarray, *, frame_size: int | None = None, device: int = 0,
                     variant="auto") -> np.ndarray:
     """numpy (..., L) complex -> numpy (..., 18) float32 via the GPU.
@@ -108,17 +124,13 @@ def features18_host(frames: np.ndarray, *, frame_size: int | None = None, device
     if N > L:
         raise ValueError(f"frame_size {N} exceeds row length {L}")
     lead = x.shape[:-1]
-    lib = _lib.load()
     if x.dtype == np.complex128:
         # MATLAB doubles: uploaded as they are, rounded to complex64 on the GPU
         x2 = np.ascontiguousarray(x.reshape(-1, L))
-        entry = lib.amcx_features18_c128_host
     else:
         x2 = np.ascontiguousarray(x.reshape(-1, L), dtype=np.complex64)
-        entry = lib.amcx_features18_c64_host
     out = np.empty((x2.shape[0], _lib.NUM_FEATURES), dtype=np.float32)
-    _lib.check(entry(x2.ctypes.data, x2.shape[0], N, L, out.ctypes.data, _lib.NUM_FEATURES,
-                     int(device), _variant(variant)))
+    _host_context(int(device)).run(x2, N, out, _variant(variant))
     return out.reshape(lead + (_lib.NUM_FEATURES,))
 
 

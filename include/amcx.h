@@ -116,6 +116,26 @@ int amcx_features18_c128_host(const void* iq_host, int64_t n_frames, int32_t fra
                               int32_t device, int32_t variant);
 
 /*
+ * The same two host-buffer entry points over a reusable context: the context owns a
+ * HIP stream and device scratch that only grows, so calling per frame in a loop -- the
+ * reference's own usage pattern, calculate_features once per queue item
+ * (feature_extraction.py:30-39) -- costs two small copies and the launches instead of
+ * hipMalloc / hipFree / stream creation per call.  A context belongs to one device and
+ * must not be used by two threads at once (one context per thread).  amcx_ctx_destroy
+ * accepts NULL.  The one-shot entry points above are these with a context that lives
+ * for the duration of the call.
+ */
+typedef struct amcx_ctx amcx_ctx;
+int amcx_ctx_create(int32_t device, amcx_ctx** ctx_out);
+int amcx_ctx_destroy(amcx_ctx* ctx);
+int amcx_ctx_features18_c64_host(amcx_ctx* ctx, const void* iq_host, int64_t n_frames,
+                                 int32_t frame_size, int64_t row_stride_elems, float* out_host,
+                                 int64_t out_row_stride, int32_t variant);
+int amcx_ctx_features18_c128_host(amcx_ctx* ctx, const void* iq_host, int64_t n_frames,
+                                  int32_t frame_size, int64_t row_stride_elems, float* out_host,
+                                  int64_t out_row_stride, int32_t variant);
+
+/*
  * Name of the kernel `variant` resolves to for this frame_size (as it shows in
  * rocprofv3 kernel traces), written NUL-terminated into buf.  Returns 0, or
  * AMCX_ENOTSUP / AMCX_EINVAL.

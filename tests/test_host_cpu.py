@@ -271,3 +271,100 @@ def test_config_mirror_equals_reference_defaults():
     assert cfg.features.used_names == ref["features"]["used_names"]
     assert cfg.features.num_used == ref["features"]["num_used"]
     assert cfg.training.feature_files == ref["training"]["feature_files"]
+
+
+def test_frame_rows_gathers_fortran_ordered_containers():
+    """loadmat returns Fortran-ordered arrays; FrameRows must deliver the snr-major flattening of
+    parsed[:n_snr, :n_frames, :N] chunk by chunk without a full reshape copy."""
+    from amcpy_amd.feature_extraction import FrameRows, _gather_parallel
+    rng = np.random.default_rng(3)
+    full = (rng.standard_normal((3, 300, 40)) + 1j * rng.standard_normal((3, 300, 40)))
+    parsed = np.asfortranarray(full)                      # (n_snr+1, n_frames+..., L) as loadmat gives it
+    n_snr, n_frames, N = 2, 260, 32
+    want = full[:n_snr, :n_frames].reshape(n_snr * n_frames, 40)
+    rows = FrameRows(parsed, n_snr, n_frames)
+    assert rows.shape == (n_snr * n_frames, 40) and np.array_equal(rows.to_array(), want)
+    for (g0, g1) in [(0, 1), (255, 265), (100, 520), (0, 520)]:      # chunks that straddle an snr row
+        dst = np.empty((g1 - g0, N), dtype=np.complex128)
+        _gather_parallel(rows, dst, g0, g1, N, threads=4)
+        assert np.array_equal(dst, want[g0:g1, :N])
+    part = rows.slice(250, 400)                           # a rank's contiguous range
+    dst = np.empty((150, N), dtype=np.complex64)          # narrowing cast on the way is allowed
+    part.gather(dst, 0, 150, N)
+    assert np.array_equal(dst, want[250:400, :N].astype(np.complex64))
+
+
+_EXTRACT_WORKER = textwrap.dedent('''
+    import os, sys
+    import numpy as np
+    import torch.distributed as dist
+    sys.path.insert(0, os.environ["AMCX_REPO"])
+    from pathlib import Path
+    from amcpy_amd.config import Config, Paths, SignalConfig
+    from amcpy_amd import feature_extraction as fe
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    loads = []
+    real_load = fe._load_variable
+    def counting_load(path, key):
+        loads.append(key)
+        return real_load(path, key)
+    fe._load_variable = counting_load
+    seen = []
+    def compute(block):                       # stand-in engine: per-row checksum
+        seen.append(block.shape)
+        base = np.abs(np.asarray(block)[:, :16]).sum(axis=1, dtype=np.float64)
+        return (base[:, None] * np.arange(1, 19)[None, :]).astype(np.float32)
+    cfg = Config(paths=Paths(root=Path(os.environ["AMCX_ROOT"])),
+                 signals=SignalConfig(snr_values={0: "0", 1: "10", 2: "20"}, num_frames=7, frame_size=16))
+    fe.run_extraction(cfg, compute=compute, verbose=False)
+    # rank 0 alone decodes the container; every rank computes only its contiguous share
+    assert (len(loads) == 6) == (rank == 0), (rank, loads)
+    assert all(s[1] == 16 for s in seen) and sum(s[0] for s in seen) in (6 * 11, 6 * 10), seen
+    print("EXTRACT_OK", rank, len(loads), sum(s[0] for s in seen))
+    dist.destroy_process_group()
+''')
+
+
+def test_two_rank_run_extraction_rank0_decodes_and_publishes(tmp_path):
+    """run_extraction with two ranks over gloo: rank 0 loads the .mat (once per variable) and
+    publishes packed frames through shared memory, both ranks compute their shard, rank 0 writes
+    files equal to the single-process result; the shared files are removed afterwards."""
+    import glob
+    import scipy.io
+    from amcpy_amd.config import Config, Paths, SignalConfig
+    from amcpy_amd import feature_extraction as fe
+    rng = np.random.default_rng(11)
+    cfg = Config(paths=Paths(root=tmp_path / "two"),
+                 signals=SignalConfig(snr_values={0: "0", 1: "10", 2: "20"}, num_frames=7, frame_size=16))
+    cfg1 = Config(paths=Paths(root=tmp_path / "one"), signals=cfg.signals)
+    container = {cfg.signals.mat_info[m]: (rng.standard_normal((3, 9, 20)) + 1j * rng.standard_normal((3, 9, 20)))
+                 for m in cfg.signals.modulations_with_noise}
+    for c in (cfg, cfg1):
+        c.paths.ensure_dirs()
+        scipy.io.savemat(str(c.paths.mat_data / c.paths.mat_filename), container)
+
+    def compute(block):
+        base = np.abs(np.asarray(block)[:, :16]).sum(axis=1, dtype=np.float64)
+        return (base[:, None] * np.arange(1, 19)[None, :]).astype(np.float32)
+
+    fe.run_extraction(cfg1, compute=compute, verbose=False)
+    before = set(glob.glob(str(fe._shared_dir() / "amcx_frames_*")))
+    script = tmp_path / "extract_worker.py"
+    script.write_text(_EXTRACT_WORKER)
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   AMCX_REPO=str(REPO), AMCX_ROOT=str(tmp_path / "two"), PYTHONDONTWRITEBYTECODE="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "EXTRACT_OK 0 6 66" in outs[0] and "EXTRACT_OK 1 0 60" in outs[1], outs
+    assert set(glob.glob(str(fe._shared_dir() / "amcx_frames_*"))) == before, "shared frame files left behind"
+    for m in cfg.signals.modulations_with_noise:
+        a = scipy.io.loadmat(str(cfg1.paths.calculated_features / f"{m}_features.mat"))
+        b = scipy.io.loadmat(str(cfg.paths.calculated_features / f"{m}_features.mat"))
+        key = cfg.signals.mat_info[m]
+        assert b[key].shape == (3, 7, 18) and np.array_equal(a[key], b[key])
