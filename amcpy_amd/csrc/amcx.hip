@@ -9,7 +9,7 @@
 
 #include "amcx_block_kernel.h"
 #include "amcx_wave_kernel.h"
-#include "amcx_tie_fix_kernel.h"
+#include "amcx_fixup_kernel.h"
 #include "amcx_post_kernels.h"
 
 namespace {
@@ -185,10 +185,11 @@ int amcx_features18_c64_ex(const void* iq_dev, int64_t n_frames, int32_t frame_s
     hipError_t e = amcx::launch_wave(iq, n_frames, frame_size, row_stride_elems, out_dev,
                                      out_row_stride, stream, cu_count());
     if (e != hipSuccess) return hip_fail(e, "wave kernel launch");
-    // frames with a phase step within one angle rounding of +-pi: exact f5/f9 (amcx_tie_fix_kernel.h)
-    e = amcx::launch_tie_fix(iq, n_frames, frame_size, row_stride_elems, out_dev, out_row_stride, stream,
-                             cu_count());
-    if (e != hipSuccess) return hip_fail(e, "tie-fix kernel launch");
+    // frames the fp32 kernel flagged: a phase step within an angle rounding of +-pi (exact f5/f9), or
+    // out of its fp32 range (all 18 recomputed with fp64 sums): amcx_fixup_kernel.h
+    e = amcx::launch_fixup(iq, n_frames, frame_size, row_stride_elems, out_dev, out_row_stride, stream,
+                           cu_count());
+    if (e != hipSuccess) return hip_fail(e, "fix-up kernel launch");
     return AMCX_OK;
   }
   return launch_block(iq, n_frames, frame_size, row_stride_elems, out_dev, out_row_stride, stream);

@@ -134,39 +134,30 @@ __device__ __forceinline__ float2 chirp(int n, int N, float sign) {
   return make_float2(cs, sign * sn);
 }
 
+// LDS regions of one workgroup (see the kernel below for how they are laid out)
+struct BlockLds {
+  float2* bh;        // Bluestein: FFT of the chirp, M entries
+  float2* xs;        // frame, later FFT workspace (M entries for Bluestein)
+  float2* at;        // (|x|, angle), later twiddles / workspace
+  double* scratch;   // kBlockWaves * kMaxReduce doubles
+  float2* tlo;       // two-level twiddle tables (Bluestein only)
+  float2* thi;
+};
+
+// All 18 features of ONE frame by the whole 256-thread workgroup; out_row gets the 18 floats.
+// Also the slow path behind the wave kernel for frames outside its fp32 range (amcx_fixup_kernel.h).
 template <int MODE>
-__global__ __launch_bounds__(kBlockThreads, 2) void amcx_features18_block_kernel(
-    const float2* __restrict__ iq, long long n_frames, int N, long long row_stride,
-    float* __restrict__ out, long long out_stride) {
-  extern __shared__ float4 amcx_block_smem[];
-  float2* const base = reinterpret_cast<float2*>(amcx_block_smem);
-  const int M = MODE == kBlockBluestein ? bluestein_length(N) : 0;
-  float2* bh = base;                                              // Bluestein: FFT of the chirp, M entries
-  float2* xs = base + M;                                          // frame, later FFT workspace (M entries for Bluestein)
-  float2* at = xs + N;                                            // (|x|, angle), later twiddles / workspace
-  double* scratch = reinterpret_cast<double*>(MODE == kBlockBluestein ? xs + M : at + N);   // kBlockWaves * kMaxReduce doubles
-  float2* tlo = reinterpret_cast<float2*>(reinterpret_cast<char*>(scratch) + kBlockScratchBytes);
-  float2* thi = tlo + 64;
+__device__ __forceinline__ void block_frame(const float2* __restrict__ src, int N, int M, const BlockLds& L,
+                                            float* __restrict__ out_row) {
+  float2* const bh = L.bh;
+  float2* const xs = L.xs;
+  float2* const at = L.at;
+  double* const scratch = L.scratch;
+  const float2* const tlo = L.tlo;
+  const float2* const thi = L.thi;
   const int tid = threadIdx.x;
-
-  if constexpr (MODE == kBlockBluestein) {
-    // once per workgroup: two-level twiddles of the M-point FFT and the chirp's spectrum
-    if (tid < 128) {
-      const int k = tid & 63;
-      float sn, cs;
-      sincospif((float)(tid < 64 ? k : 64 * k) * (2.0f / (float)M), &sn, &cs);
-      tlo[tid] = make_float2(cs, -sn);                            // tlo[k] = W_M^k, thi[k] = W_M^(64 k)
-    }
-    for (int n = tid; n < M; n += kBlockThreads) {
-      const int d = n < N ? n : (M - n < N ? M - n : -1);         // conj(w) is even in n: wrap it around
-      bh[n] = d >= 0 ? chirp(d, N, 1.0f) : make_float2(0.f, 0.f);
-    }
-    __syncthreads();
-    lds_fft_dif(bh, M, tlo, thi);
-  }
-
-  for (long long f = blockIdx.x; f < n_frames; f += gridDim.x) {
-    const float2* src = iq + f * row_stride;
+  (void)bh; (void)tlo; (void)thi; (void)M;
+  {
     for (int n = tid; n < N; n += kBlockThreads) xs[n] = src[n];
     __syncthreads();
 
@@ -309,8 +300,44 @@ __global__ __launch_bounds__(kBlockThreads, 2) void amcx_features18_block_kernel
     }
     peak = block_max(peak, scratch);   // barriers inside: LDS free for the next frame
     S.gmax_raw = peak;
-    if (tid == 0) finalize_features(S, N, out + f * out_stride);
+    if (tid == 0) finalize_features(S, N, out_row);
   }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kBlockThreads, 2) void amcx_features18_block_kernel(
+    const float2* __restrict__ iq, long long n_frames, int N, long long row_stride,
+    float* __restrict__ out, long long out_stride) {
+  extern __shared__ float4 amcx_block_smem[];
+  float2* const base = reinterpret_cast<float2*>(amcx_block_smem);
+  const int M = MODE == kBlockBluestein ? bluestein_length(N) : 0;
+  float2* bh = base;                                              // Bluestein: FFT of the chirp, M entries
+  float2* xs = base + M;                                          // frame, later FFT workspace (M entries for Bluestein)
+  float2* at = xs + N;                                            // (|x|, angle), later twiddles / workspace
+  double* scratch = reinterpret_cast<double*>(MODE == kBlockBluestein ? xs + M : at + N);   // kBlockWaves * kMaxReduce doubles
+  float2* tlo = reinterpret_cast<float2*>(reinterpret_cast<char*>(scratch) + kBlockScratchBytes);
+  float2* thi = tlo + 64;
+  const int tid = threadIdx.x;
+
+  if constexpr (MODE == kBlockBluestein) {
+    // once per workgroup: two-level twiddles of the M-point FFT and the chirp's spectrum
+    if (tid < 128) {
+      const int k = tid & 63;
+      float sn, cs;
+      sincospif((float)(tid < 64 ? k : 64 * k) * (2.0f / (float)M), &sn, &cs);
+      tlo[tid] = make_float2(cs, -sn);                            // tlo[k] = W_M^k, thi[k] = W_M^(64 k)
+    }
+    for (int n = tid; n < M; n += kBlockThreads) {
+      const int d = n < N ? n : (M - n < N ? M - n : -1);         // conj(w) is even in n: wrap it around
+      bh[n] = d >= 0 ? chirp(d, N, 1.0f) : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    lds_fft_dif(bh, M, tlo, thi);
+  }
+
+  BlockLds L{bh, xs, at, scratch, tlo, thi};
+  for (long long f = blockIdx.x; f < n_frames; f += gridDim.x)
+    block_frame<MODE>(iq + f * row_stride, N, M, L, out + f * out_stride);
 }
 
 }  // namespace amcx

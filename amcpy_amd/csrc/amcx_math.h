@@ -69,7 +69,7 @@ __device__ __forceinline__ float wrapped_step(float th_next, float th) {
 // |step| > pi - kTieBand: rounding of the two fp32 angles (<= 1e-6 together) may
 // have decided the sign of the wrapped step.  The fp64 reference resolves such a
 // step from the 17th digit; the throughput kernel only FLAGS the frame (it stores
-// -f5, and f5 >= 0) and amcx_step_tie_fix_kernel recomputes f5/f9 of flagged frames
+// -f5, and f5 >= 0) and amcx_fixup_kernel recomputes f5/f9 of flagged frames
 // with exact_step below.  About 1 frame in 400 is flagged at low SNR; every frame
 // of noiseless axis-aligned data is.
 constexpr float kTieBand = 2.0e-6f;
@@ -114,6 +114,31 @@ struct FrameSums {
   bool pi_tie = false;           // some step within kTieBand of +-pi: f5 is stored negated as the flag
   double gmax_raw;               // max_k |X_k|^2 (unnormalised FFT)
 };
+
+// Range in which the throughput kernel's fp32 sums are trusted, as the frame's mean power
+// sum|x|^2 / N: sixth-order products of a frame at 1e10 stay below 3.4e38 unless one sample
+// holds most of its energy (then a sum overflows and is_outside_fp32_range sees the inf), and at
+// 1e-10 they are still 8 orders above the smallest normal float.  Frames outside -- and frames
+// any of whose sums is not finite -- are flagged (f5 = -inf) and recomputed with fp64 sums by
+// amcx_fixup_kernel: the reference evaluates in complex128 (features.py:46-58) and is finite
+// over the whole complex64 range, overflowing only in its float32 store.
+constexpr double kRangeLoPower = 1.0e-10, kRangeHiPower = 1.0e10;
+
+__device__ inline bool is_outside_fp32_range(const FrameSums& s, int N) {
+  if (!(s.sP == s.sP)) return false;            // a NaN sample: 18 NaNs on either path
+  double z = 0.0;                               // 0 * x is NaN for x = +-inf or NaN
+  z = __builtin_fma(s.sA, 0.0, z);   z = __builtin_fma(s.sBh, 0.0, z);  z = __builtin_fma(s.sP, 0.0, z);
+  z = __builtin_fma(s.sAA, 0.0, z);  z = __builtin_fma(s.sX4, 0.0, z);  z = __builtin_fma(s.sAB, 0.0, z);
+  z = __builtin_fma(s.sAP, 0.0, z);  z = __builtin_fma(s.sBP, 0.0, z);  z = __builtin_fma(s.sAAA, 0.0, z);
+  z = __builtin_fma(s.sABB, 0.0, z); z = __builtin_fma(s.sAAB, 0.0, z); z = __builtin_fma(s.sBBB, 0.0, z);
+  z = __builtin_fma(s.sAAP, 0.0, z); z = __builtin_fma(s.sX4P, 0.0, z); z = __builtin_fma(s.sABP, 0.0, z);
+  z = __builtin_fma(s.sa, 0.0, z);   z = __builtin_fma(s.sad2, 0.0, z); z = __builtin_fma(s.sad4, 0.0, z);
+  z = __builtin_fma(s.gmax_raw, 0.0, z);
+  const double n = (double)N;
+  const bool zero_frame = s.sP <= 2.0 * n * (double)kTinyPower;
+  const double pbar = s.sP / n;
+  return (z != z) || (!zero_frame && !(pbar >= kRangeLoPower && pbar <= kRangeHiPower));
+}
 
 // The finaliser's results are stored as float32, so its square roots and quotients
 // need ~1e-7, not 1e-16: the raw v_sqrt_f64 / v_rcp_f64 (accurate to about float
@@ -188,7 +213,7 @@ __device__ inline void finalize_features(const FrameSums& s, int N, float* __res
   // ---- frequency phi = w / 2pi over N-1 values: f5, f9
   frequency_features(s.Kw, s.swd1, s.swd2, s.swd3, s.swd4, N, out[4], out[8]);
 
-  if (s.pi_tie) out[4] = -out[4];   // picked up by amcx_step_tie_fix_kernel
+  if (s.pi_tie) out[4] = -out[4];   // picked up by amcx_fixup_kernel
 
   // ---- mixed moments (complex as (re, im) pairs)
   if (zero_frame) {   // the guard's kTinyPower must not leak into |C20| ... |C63| of a zero frame

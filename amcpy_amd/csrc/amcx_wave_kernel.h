@@ -1033,6 +1033,7 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
       F.pi_tie = row[31] != 0.0f;
       float feat[18];
       finalize_features(F, N, feat);
+      if (is_outside_fp32_range(F, N)) feat[4] = -__builtin_inff();   // all 18 redone by amcx_fixup_kernel
       float* dst = out + (f0 + lane) * out_stride;
 #pragma unroll
       for (int j = 0; j < 18; ++j) dst[j] = feat[j];

@@ -1,4 +1,4 @@
-"""`python -m amcpy_amd extract [--root DIR] [--frame-size N] [--num-frames F] [--device D]`
+"""`python -m amcpy_amd extract [--root DIR] [--frame-size N] [--num-frames F] [--snr-values L ...] [--device D]`
 
 The `extract` sub-command of the reference's CLI (src/amcpy/main.py:32,85-87,
 160-175), and only that one: plot/train/eval/quantize are outside the hot path
@@ -23,6 +23,8 @@ def build_parser() -> argparse.ArgumentParser:
     ex.add_argument("--root", type=Path, default=None, help="project root (default: cwd)")
     ex.add_argument("--frame-size", type=int, default=None)
     ex.add_argument("--num-frames", type=int, default=None)
+    ex.add_argument("--snr-values", nargs="+", default=None, metavar="LABEL",
+                    help="SNR labels of the container's first axis, in order (default: the 16 of SignalConfig)")
     ex.add_argument("--device", type=int, default=None, help="GPU index (default: current device)")
     return ap
 
@@ -35,6 +37,8 @@ def main(argv=None) -> int:
         sig = replace(sig, frame_size=args.frame_size)
     if args.num_frames is not None:
         sig = replace(sig, num_frames=args.num_frames)
+    if args.snr_values is not None:
+        sig = replace(sig, snr_values={i: str(v) for i, v in enumerate(args.snr_values)})
     cfg = replace(cfg, signals=sig)
     if args.command == "extract":
         from .feature_extraction import run_extraction

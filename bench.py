@@ -42,75 +42,211 @@ CPU_SAMPLE = (6, 2, 500, 2048)  # BASELINE configs[0]
 
 
 # ----------------------------------------------------------------------------
-# CPU baseline (oracle, reference-shaped) -- runs before any GPU initialisation
+# CPU baselines (the oracle, reference-shaped) -- run before any GPU initialisation
 # ----------------------------------------------------------------------------
-def _cpu_worker(job):
+_BLOCK = None
+
+
+def _cpu_init(jobs_by_slot, counter):
+    """Pool initialiser: import numpy + the oracle and build this worker's block once, outside
+    the timed region (fork/import used to be most of a 1.6 s measurement)."""
+    global _BLOCK
     import numpy as np
     from amcpy_amd import synth
     from oracle import iq_features_oracle as orc
-    mod, mi, si, snr, n_frames, N = job
-    blk = synth.host_block(mod, snr, n_frames, N, seed=1000 + 10 * mi + si).astype(np.complex128)
+    with counter.get_lock():
+        slot = counter.value
+        counter.value += 1
+    mod, mi, si, snr, n_frames, N = jobs_by_slot[slot % len(jobs_by_slot)]
+    _BLOCK = synth.host_block(mod, snr, n_frames, N, seed=1000 + 10 * mi + si).astype(np.complex128)
+    orc.calculate_features(range(1, 19), _BLOCK[0])            # warm every code path
+
+
+def _cpu_spin(seconds):
+    """Cycle over this worker's block for `seconds`; returns (frames, elapsed)."""
+    from oracle import iq_features_oracle as orc
+    n = _BLOCK.shape[0]
     t0 = time.perf_counter()
+    done = 0
     acc = 0.0
-    for f in range(n_frames):
-        row = orc.calculate_features(range(1, 19), blk[f])
+    while True:
+        row = orc.calculate_features(range(1, 19), _BLOCK[done % n])
         acc += row[5]
-    return n_frames, time.perf_counter() - t0, acc
+        done += 1
+        if (done & 7) == 0 and time.perf_counter() - t0 >= seconds:
+            break
+    return done, time.perf_counter() - t0, acc
 
 
-def cpu_baseline(max_procs: int | None = None):
-    """Frames/s of the oracle's per-frame, per-feature evaluator (same
-    redundancy class as the reference: 9x moments, 4x instantaneous values per
-    frame) over worker processes on the host cores."""
-    import multiprocessing as mp
-    from amcpy_amd import synth
-    n_mods, n_snr, n_frames, N = CPU_SAMPLE
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _host_cores():
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    procs = max(1, min(cores, max_procs or cores))
+    return cores
+
+
+def cpu_baseline(max_procs: int | None = None, seconds: float = 10.0):
+    """Frames/s of the oracle's per-frame, per-feature evaluator (same redundancy class as the
+    reference: 9x moments, 4x instantaneous values per frame): one worker process per host core,
+    each cycling over its own (modulation, SNR) block of the configs[0] shape for `seconds` of
+    wall time AFTER the pool is up and warm."""
+    import multiprocessing as mp
+    from amcpy_amd import synth
+    n_mods, n_snr, n_frames, N = CPU_SAMPLE
+    procs = max(1, min(_host_cores(), max_procs or _host_cores()))
     grid = synth.snr_grid(n_snr)
-    # split every (mod, snr) block into chunks so all workers stay busy
-    per = max(1, n_frames // max(1, procs // (n_mods * n_snr) + 1))
-    jobs = []
-    for mi, mod in enumerate(synth.MODS6[:n_mods]):
-        for si in range(n_snr):
-            left = n_frames
-            while left > 0:
-                c = min(per, left)
-                jobs.append((mod, mi, si, float(grid[si]), c, N))
-                left -= c
+    jobs = [(mod, mi, si, float(grid[si]), min(n_frames, 64), N)
+            for mi, mod in enumerate(synth.MODS6[:n_mods]) for si in range(n_snr)]
+    ctx = mp.get_context("fork")
+    counter = ctx.Value("i", 0)
+    with ctx.Pool(procs, initializer=_cpu_init, initargs=(jobs, counter)) as pool:
+        pool.map(_cpu_spin, [0.05] * procs, chunksize=1)           # every worker up and warm
+        t0 = time.perf_counter()
+        res = pool.map(_cpu_spin, [seconds] * procs, chunksize=1)
+        wall = time.perf_counter() - t0
+    frames = sum(r[0] for r in res)
+    value = frames / wall
+    return {
+        "value": value, "unit": "frames/s", "cores": procs, "kind": "port", "cpu_model": _cpu_model(),
+        "sample": f"{procs} worker processes, each cycling over 64 frames of one (modulation, SNR) block of the "
+                  f"BASELINE configs[0] shape ({n_mods} mods x {n_snr} SNR x {n_frames} x {N}, complex128 input, "
+                  f"oracle.calculate_features per frame) for {wall:.1f} s after pool warm-up: {frames} frames",
+        "extrapolated_configs1_seconds": N_MODS * N_SNR * N_FRAMES / value,
+    }
+
+
+def _ref_shaped_child(job):
+    """One modulation the way the reference's _modulation_process runs it (feature_extraction.py:42-82):
+    a Queue of (signal, snr, frame) items, num_threads daemon worker threads each storing
+    calculate_features(1..18) into a shared float32 matrix, queue.join()."""
+    import queue
+    import threading
+    import numpy as np
+    from amcpy_amd import synth
+    from oracle import iq_features_oracle as orc
+    mod, mi, n_snr, n_frames, N, n_threads = job
+    grid = synth.snr_grid(n_snr)
+    parsed = np.stack([synth.host_block(mod, float(grid[si]), n_frames, N, seed=1000 + 10 * mi + si)
+                       for si in range(n_snr)]).astype(np.complex128)
+    mat = np.zeros((n_snr, n_frames, 18), dtype=np.float32)
+    q = queue.Queue()
+
+    def worker():
+        while True:
+            sig, si, fi = q.get()
+            try:
+                mat[si, fi, :] = orc.calculate_features(range(1, 19), sig)
+            finally:
+                q.task_done()
+
+    t0 = time.perf_counter()
+    for _ in range(n_threads):
+        threading.Thread(target=worker, daemon=True).start()
+    for si in range(n_snr):
+        for fi in range(n_frames):
+            q.put((parsed[si, fi, 0:N], si, fi))
+    q.join()
+    return n_snr * n_frames, time.perf_counter() - t0, float(mat[0, 0, 5])
+
+
+def cpu_baseline_reference_shaped(n_threads: int = 8):
+    """The reference's own process/thread structure (feature_extraction.py:58-61,89-97;
+    config.py:98): one process per modulation x num_threads=8 GIL-bound threads, on the whole
+    BASELINE configs[0] container (6 000 frames).  Uses at most 6 cores however many the host has."""
+    import multiprocessing as mp
+    from amcpy_amd import synth
+    n_mods, n_snr, n_frames, N = CPU_SAMPLE
+    jobs = [(mod, mi, n_snr, n_frames, N, n_threads) for mi, mod in enumerate(synth.MODS6[:n_mods])]
     ctx = mp.get_context("fork")
     t0 = time.perf_counter()
-    with ctx.Pool(procs) as pool:
-        res = pool.map(_cpu_worker, jobs, chunksize=1)
+    with ctx.Pool(n_mods) as pool:
+        res = pool.map(_ref_shaped_child, jobs, chunksize=1)
     wall = time.perf_counter() - t0
     frames = sum(r[0] for r in res)
+    compute_wall = max(r[1] for r in res)
+    value = frames / compute_wall
     return {
-        "value": frames / wall, "unit": "frames/s", "cores": procs, "kind": "port",
-        "sample": f"{n_mods} mods x {n_snr} SNR x {n_frames} frames x {N} samples (BASELINE configs[0]), "
-                  f"complex128 input, oracle.calculate_features per frame, {procs} worker processes, "
-                  f"{wall:.1f} s wall",
+        "value": value, "unit": "frames/s", "cores": min(n_mods, _host_cores()), "kind": "reference-shaped",
+        "cpu_model": _cpu_model(),
+        "sample": f"BASELINE configs[0] whole ({n_mods} mods x {n_snr} SNR x {n_frames} x {N}, complex128): "
+                  f"{n_mods} processes x {n_threads} threads fed by a Queue, as feature_extraction.py:58-61,89-97; "
+                  f"slowest process {compute_wall:.1f} s (pool wall {wall:.1f} s incl. data generation)",
+        "extrapolated_configs1_seconds": N_MODS * N_SNR * N_FRAMES / value,
     }
 
 
 # ----------------------------------------------------------------------------
 def _pmc_traffic(frames_per_launch: int, frame_size: int):
-    """HBM bytes per launch from the newest committed PMC summary for this frame size, if any."""
-    best = None
-    for p in sorted((REPO / "profiles").glob("*pmc*.json")):
+    """(HBM bytes per launch, source file) from the newest committed PMC summary for this frame
+    size, if any -- replayed from profiles/, not measured in this run."""
+    best, src = None, None
+    for p in sorted((REPO / "profiles").glob("*pmc*.json"), key=lambda q: (q.name[:2] != "r2", q.name)):
         try:
             d = json.loads(p.read_text())
             if d.get("frame_size") == frame_size and d.get("hbm_bytes_per_frame"):
-                best = d["hbm_bytes_per_frame"] * frames_per_launch
+                best, src = d["hbm_bytes_per_frame"] * frames_per_launch, f"profiles/{p.name}"
         except Exception:
             continue
-    return best
+    for p in sorted((REPO / "profiles").glob("r2*pmc*.json")):          # this round's files win
+        try:
+            d = json.loads(p.read_text())
+            if d.get("frame_size") == frame_size and d.get("hbm_bytes_per_frame"):
+                best, src = d["hbm_bytes_per_frame"] * frames_per_launch, f"profiles/{p.name}"
+        except Exception:
+            continue
+    return best, src
 
 
-def _valu_note(frames_per_s: float):
+def _committed_json(name: str):
+    p = REPO / "profiles" / name
+    try:
+        return json.loads(p.read_text())
+    except Exception:
+        return None
+
+
+def h2d_path(dev, frame_size: int = FRAME_SIZE):
+    """The real-data upload path (run_extraction's engine) on a configs[0]-shaped complex128
+    container held the way scipy.io.loadmat returns it (Fortran order): gather -> pinned ->
+    HBM -> round to complex64 -> kernel -> D2H of the (F x 18) result.  Reported beside the
+    headline, never as `value`."""
+    import numpy as np
+    import torch
+    from amcpy_amd.feature_extraction import FrameRows, HipEngine
+    n_mods, n_snr, n_frames, N = CPU_SAMPLE[0], CPU_SAMPLE[1], CPU_SAMPLE[2], frame_size
+    rng = np.random.default_rng(7)
+    parsed = np.asfortranarray((rng.standard_normal((n_snr, n_frames, N)) +
+                                1j * rng.standard_normal((n_snr, n_frames, N))))
+    eng = HipEngine(N, dev.index, chunk_bytes=64 << 20)
+    rows = FrameRows(parsed, n_snr, n_frames)
+    eng(rows)                                             # warm: pinned + device slots, kernels
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(n_mods):                               # six modulations, as run_extraction loops
+        eng(rows)
+    wall = time.perf_counter() - t0
+    frames = n_mods * n_snr * n_frames
+    nbytes = frames * N * 16
+    return {"GBps": nbytes / wall / 1e9, "frames_per_s": frames / wall, "seconds": wall,
+            "what": f"HipEngine on {n_mods} x ({n_snr}, {n_frames}, {N}) complex128 Fortran-ordered arrays "
+                    f"(BASELINE configs[0] as loadmat returns it): threaded gather -> pinned -> H2D -> round to "
+                    f"complex64 on the GPU -> kernel -> D2H; {eng.stats.get('gather_threads')} gather threads, "
+                    f"{eng.stats.get('chunks')} chunk(s) per modulation; loadmat/savemat not included"}
+
+
+def _valu_note_r1(frames_per_s: float):
     """Secondary bound from the committed PMC summary: the kernel is VALU/power-bound
     (DESIGN.md section 4.3), so report the issue rate next to the HBM fraction."""
     for p in sorted((REPO / "profiles").glob("*final_summary.json"), reverse=True):
@@ -130,14 +266,33 @@ def _valu_note(frames_per_s: float):
     return None
 
 
+def _valu_note(frames_per_s: float):
+    """Secondary bounds of the N = 2048 kernel from this round's committed budget
+    (profiles/r2_wave_budget.json: in-kernel clock, issue slots, ablations -- DESIGN.md 4.3)."""
+    b = _committed_json("r2_wave_budget.json")
+    if b is None:
+        return _valu_note_r1(frames_per_s)
+    per_frame = b.get("valu_instr_per_frame")
+    out = {"bound": b.get("bound", "board power, then VALU issue"), "valu_instr_per_frame": per_frame,
+           "source": "profiles/r2_wave_budget.json"}
+    if per_frame:
+        out["achieved_Gwaveinstr_per_s"] = per_frame * frames_per_s / 1e9
+    for k in ("in_kernel_clock_GHz", "in_kernel_clock_zeros_GHz", "simd_cycles_per_frame",
+              "valu_issue_slot_use", "frames_per_s_on_zero_data", "frames_per_s_L2_resident"):
+        if k in b:
+            out[k] = b[k]
+    return out
+
+
 def _ensure_library(local_rank: int):
     """libamcx.so is a build artefact (not in git): if this checkout lacks it, local rank 0
     builds it (as __graft_entry__.build() does) and the other ranks wait for the file."""
     from amcpy_amd.csrc import build as b
-    if b.LIB.exists():
-        return
     if local_rank == 0:
-        b.build(verbose=False)
+        if Path(b.HIPCC).exists():
+            b.build(force=False, verbose=False)          # rebuilds only if sources are newer (build.stale)
+        elif not b.LIB.exists():
+            raise SystemExit("libamcx.so is missing and hipcc is not available")
         return
     deadline = time.time() + 300
     while not b.LIB.exists() and time.time() < deadline:     # appears atomically (build.py renames)
@@ -168,9 +323,13 @@ def main():
     ap.add_argument("--variant", default="auto", choices=["auto", "block", "wave"])
     ap.add_argument("--frame-size", type=int, default=FRAME_SIZE,
                     help="samples per frame (the BASELINE metric is quoted at 2048; 1024/4096 are the other configs)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="label only: 'strong' when --frames / --mods were divided by the GPU count (tools/scale.sh)")
     ap.add_argument("--no-cpu-baseline", action="store_true",
                     help="skip the host baseline (use under rocprofv3: no worker processes)")
     ap.add_argument("--cpu-procs", type=int, default=None)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="timed CPU work per worker after warm-up")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the real-data upload-path measurement")
     args = ap.parse_args()
     FS = args.frame_size
 
@@ -183,9 +342,10 @@ def main():
                              "python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N")
         world, rank, local_rank = 1, 0, 0
 
-    cpu = None
+    cpu = cpu_ref_shaped = None
     if world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.cpu_procs)            # before the GPU is touched
+        cpu = cpu_baseline(args.cpu_procs, args.cpu_seconds)      # before the GPU is touched
+        cpu_ref_shaped = cpu_baseline_reference_shaped()
 
     _ensure_library(local_rank)
     import torch
@@ -243,6 +403,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
 
+    # the same step with the (F x 18) result brought to the host: launch + kernels + D2H, wall clock
+    host_out = torch.empty(out.shape, dtype=torch.float32, pin_memory=True)
+    step(); host_out.copy_(out); torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        host_out.copy_(out, non_blocking=True)
+    torch.cuda.synchronize()
+    wall_d2h_ms = (time.perf_counter() - t1) / args.steps * 1e3
+
     # sanity: the timed output is finite
     assert torch.isfinite(out[0, N_SNR // 2, :64]).all(), "non-finite features in the timed output"
 
@@ -263,6 +433,10 @@ def main():
         torch.cuda.synchronize()
         read_peak = nbytes * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
+    h2d = None
+    if rank == 0 and world == 1 and not args.no_h2d:
+        h2d = h2d_path(dev)
+
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -273,12 +447,13 @@ def main():
     value = total_frames / wall
     mean_launch_s = sum(launch_ms) / len(launch_ms) * 1e-3
     alg_bytes = (8 * FS + 72) * frames_per_launch
+    traffic, traffic_src = _pmc_traffic(frames_per_launch, FS)
     achieved = alg_bytes / mean_launch_s / 1e9
     rec = {
         "metric": f"IQ frames/sec (18 features, {FS}-sample complex64)",
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {
             "workload": f"{n_mods} mods x {N_SNR} SNR x {args.frames} frames x {FS} samples "
@@ -291,12 +466,16 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": _pmc_traffic(frames_per_launch, FS),
+            "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_ms": mean_launch_s * 1e3,
             "measured_read_peak_GBps": read_peak,
             "secondary": _valu_note(value / world) if FS == FRAME_SIZE else None,
         },
+        "wall_incl_d2h_ms": wall_d2h_ms,
+        "h2d": h2d,
+        "parity": _committed_json("r2_parity_summary.json"),
         "cpu_baseline": cpu,
+        "cpu_baseline_reference_shaped": cpu_ref_shaped,
     }
     sys.stdout.flush()
     os.dup2(real_stdout, 1)

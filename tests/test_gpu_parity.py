@@ -51,15 +51,34 @@ def _variants_for(N):
     return out
 
 
-def _assert_parity(got, golden_f64, frames, what):
+SUM_FLOOR = 2e-3      # see _assert_parity(large_sample=True)
+
+
+def _assert_parity(got, golden_f64, frames, what, large_sample=False):
+    """The tolerance of the module docstring.  ``large_sample`` (thousands of frames): among
+    thousands of noise-like frames a few have a cumulant whose every term is ~1000x below the
+    size of the summands it is averaged from (|mean x^6| = 0.003 where mean |x|^6 = 7: pure
+    chance), so S itself collapses; fp32 accumulation is good to ~1e-8 of the SUMMAND scale, not
+    of such an S.  There the scale is floored at SUM_FLOOR x (S evaluated with every moment
+    replaced by the mean of its summands' magnitudes), i.e. an absolute 2e-8 of the summand
+    scale -- and at least 99.9 % of the frames must meet the unfloored criterion."""
     S = orc.conditioning_scales(frames)
     plain, scaled = orc.parity_errors(got, golden_f64.astype(np.float32), S)
     worst = scaled.max(axis=0)
     print(f"\n[{what}] worst scaled rel per feature:", " ".join(f"{v:.1e}" for v in worst))
     print(f"[{what}] worst plain  rel per feature:", " ".join(f"{v:.1e}" for v in plain.max(axis=0)))
-    assert worst.max() <= TOL, f"{what}: feature {int(worst.argmax()) + 1} off by {worst.max():.3e}"
     strict = [i for i in range(18) if i < 9 or i == 10]
     assert plain[:, strict].max() <= TOL
+    if not large_sample:
+        assert worst.max() <= TOL, f"{what}: feature {int(worst.argmax()) + 1} off by {worst.max():.3e}"
+        return
+    over = (scaled > TOL).any(axis=1)
+    print(f"[{what}] frames beyond the unfloored criterion: {int(over.sum())} of {len(over)}"
+          f" (worst {scaled.max():.2e})")
+    assert over.mean() <= 1e-3, f"{what}: {int(over.sum())} of {len(over)} frames beyond 1e-5 of max(|value|, S)"
+    S_floor = np.maximum(S, SUM_FLOOR * orc.conditioning_scales(frames, absolute=True))
+    _, scaled_f = orc.parity_errors(got, golden_f64.astype(np.float32), S_floor)
+    assert scaled_f.max() <= TOL, f"{what}: feature {int(scaled_f.max(axis=0).argmax()) + 1} off by {scaled_f.max():.3e}"
 
 
 def test_library_loads_and_sees_gpu():
@@ -574,12 +593,15 @@ def test_iq_pair_layout_is_zero_copy():
         features18_iq_pairs(pairs.transpose(1, 2).contiguous().transpose(1, 2))
 
 
-@pytest.mark.parametrize("n_mods,N,label", [(6, 2048, "configs[1]"), (6, 4096, "configs[2]"),
-                                            (3, 1024, "configs[4] per-GPU shard")])
-def test_full_benchmark_shard_properties(n_mods, N, label):
+@pytest.mark.parametrize("n_mods,N,n_frames,label",
+                         [(6, 2048, 4096, "configs[1]"), (6, 4096, 4096, "configs[2]"),
+                          (6, 2048, 8192, "configs[3] per-GPU shard"), (3, 1024, 4096, "configs[4] per-GPU shard")])
+def test_full_benchmark_shard_properties(n_mods, N, n_frames, label):
     """BASELINE configs at full size -- configs[1] 6 x 26 x 4096 frames x 2048 samples (10.5 GB
     in HBM), configs[2] the same at 4096 samples (20.9 GB), and one GPU's eighth of configs[4]
-    (24 x 26 x 4096 x 1024 over 8 GPUs = 3 modulations each, 2.6 GB): too large for the oracle,
+    (24 x 26 x 4096 x 1024 over 8 GPUs = 3 modulations each, 2.6 GB) and of configs[3]
+    (6 x 26 x 65536 x 2048 frame-sharded over 8 GPUs = 8192 frames per (mod, SNR), 20.9 GB):
+    too large for the oracle,
     so size-independent properties --
     every frame is computed exactly once and independently of its position (one launch
     over the whole shard == per-modulation launches == a gathered sample recomputed
@@ -588,7 +610,7 @@ def test_full_benchmark_shard_properties(n_mods, N, label):
     torch = _torch()
     from amcpy_amd import synth
     from amcpy_amd.features import features18
-    n_snr, n_frames = 26, 4096
+    n_snr = 26
     arena = torch.empty((n_mods, n_snr, n_frames, N), dtype=torch.complex64, device="cuda")
     for mi, mod in enumerate(synth.MODS6[:n_mods]):
         synth.device_frames(mod, n_snr, n_frames, N, device="cuda", rank=0, mod_idx=mi, out=arena[mi])
@@ -653,3 +675,126 @@ def test_launch_is_graph_capturable():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, want)
+
+
+def test_dynamic_range_matches_the_float32_stored_reference():
+    """Frames of ordinary shape at scales 1e-12 ... 1e12, one whose halves differ by ten orders
+    of magnitude and one with a single 5e7 sample (tests/golden/range_n2048.npz, captured from
+    the reference).  The reference evaluates in complex128 and stores float32
+    (features.py:46-58, feature_extraction.py:35,56): its sixth-order cumulants are inf above
+    |x| ~ 2.6e6 and 0 below ~ 3e-8 while everything else stays finite.  Both variants must
+    reproduce that pattern exactly and every finite value within the usual tolerance -- the wave
+    kernel by flagging what its fp32 sums cannot hold for the fp64-sum fix-up."""
+    g = load_npz("range_n2048.npz")
+    x, names = g["iq"], [str(n) for n in g["names"]]
+    gold32, gold64 = g["golden64"], g["golden64_f64"]
+    S = orc.conditioning_scales(x.astype(np.complex128))
+    with np.errstate(all="ignore"):
+        stored = gold64.astype(np.float32)
+    assert np.array_equal(stored, gold32, equal_nan=True)
+    strict = [i for i in range(18) if i < 9 or i == 10]
+    for variant in VARIANTS_POW2:
+        got = _run(x, variant)
+        special = ~np.isfinite(gold32) | (gold32 == 0)
+        bad = np.argwhere(special & (got != gold32))
+        assert bad.size == 0, (variant, [(names[i], j + 1, got[i, j], gold32[i, j]) for i, j in bad[:6]])
+        assert np.isfinite(got[~special]).all(), variant
+        with np.errstate(all="ignore"):
+            diff = np.abs(got.astype(np.float64) - gold32.astype(np.float64))
+            # float32 denormals of the reference's store carry fewer bits: allow their quantum
+            quantum = np.where(np.abs(gold32) < 1.2e-38, 1.5e-45, 0.0)
+            scaled = (diff - quantum).clip(min=0) / np.maximum(np.abs(gold32.astype(np.float64)), S)
+            plain = (diff - quantum).clip(min=0) / np.abs(gold32.astype(np.float64))
+        scaled[special] = 0.0
+        plain[special] = 0.0
+        worst = scaled.max(axis=0)
+        print(f"\n[range {variant}] worst scaled rel per feature:", " ".join(f"{v:.1e}" for v in worst))
+        i, j = np.unravel_index(scaled.argmax(), scaled.shape)
+        assert worst.max() <= TOL, (variant, names[i], j + 1, got[i, j], gold32[i, j])
+        assert plain[:, strict].max() <= TOL, variant
+
+
+def test_run_extraction_on_a_container_of_genuine_doubles(tmp_path):
+    """The reference evaluates MATLAB doubles in complex128 (feature_extraction.py:46-48,68);
+    the engine rounds them to complex64 on the GPU first.  Fixture: a container whose samples
+    are NOT float32-representable and the six files the reference's own run_extraction wrote
+    for it (tests/golden/extract_roundtrip_f64.npz).  The rounding must stay inside the
+    tolerance of SURVEY.md section 8c."""
+    import scipy.io
+    from amcpy_amd.config import Config, Paths, SignalConfig
+    from amcpy_amd.feature_extraction import run_extraction
+    g = load_npz("extract_roundtrip_f64.npz")
+    fs, n_frames = int(g["frame_size"]), int(g["n_frames"])
+    mods = [str(m) for m in g["mods"]]
+    cfg = Config(paths=Paths(root=tmp_path),
+                 signals=SignalConfig(snr_values={0: "0", 1: "10"}, num_frames=n_frames, frame_size=fs))
+    cfg.paths.ensure_dirs()
+    container = {cfg.signals.mat_info[m]: g[f"in_{m}"] for m in mods}
+    assert all(v.dtype == np.complex128 and not np.array_equal(v, v.astype(np.complex64)) for v in container.values())
+    scipy.io.savemat(str(cfg.paths.mat_data / cfg.paths.mat_filename), container)
+    run_extraction(cfg, verbose=False)
+    for m in mods:
+        d = scipy.io.loadmat(str(cfg.paths.calculated_features / f"{m}_features.mat"))
+        arr = d[cfg.signals.mat_info[m]]
+        assert arr.dtype == np.float32 and arr.shape == (2, n_frames, 18)
+        x = g[f"in_{m}"][:, :, :fs].reshape(-1, fs)                 # complex128: the scales of the true input
+        _assert_parity(arr.reshape(-1, 18), g[f"out_{m}"].reshape(-1, 18).astype(np.float64), x,
+                       f"genuine doubles {m}")
+
+
+def test_extract_cli_on_the_configs0_shape(tmp_path):
+    """`python -m amcpy_amd extract` as a subprocess on BASELINE configs[0]: 6 modulations x 2 SNR
+    x 500 frames x 2048 samples in mat-data/all_modulations.mat -> six {mod}_features.mat, checked
+    against the oracle (reference CLI: main.py:32,85-87,160-175)."""
+    import subprocess
+    import sys
+    import scipy.io
+    from amcpy_amd import synth
+    from amcpy_amd.config import Config, Paths, SignalConfig
+    n_snr, n_frames, fs = 2, 500, 2048
+    cfg = Config(paths=Paths(root=tmp_path),
+                 signals=SignalConfig(snr_values={0: "0", 1: "10"}, num_frames=n_frames, frame_size=fs))
+    cfg.paths.ensure_dirs()
+    blocks = synth.host_frames(synth.MODS6, n_snr, n_frames, fs)             # complex64, seeds of SURVEY 8d
+    scipy.io.savemat(str(cfg.paths.mat_data / cfg.paths.mat_filename),
+                     {cfg.signals.mat_info[m]: blocks[m] for m in synth.MODS6})
+    repo = str(Path(__file__).resolve().parents[1])
+    env = dict(os.environ, PYTHONPATH=repo + os.pathsep + os.environ.get("PYTHONPATH", ""),
+               PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, "-m", "amcpy_amd", "extract", "--root", str(tmp_path),
+                        "--num-frames", str(n_frames), "--frame-size", str(fs), "--snr-values", "0", "10"],
+                       env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "All feature calculations complete!" in r.stdout
+    for m in synth.MODS6:
+        d = scipy.io.loadmat(str(cfg.paths.calculated_features / f"{m}_features.mat"))
+        assert sorted(k for k in d if not k.startswith("__")) == sorted(["Modulation", cfg.signals.mat_info[m]])
+        arr = d[cfg.signals.mat_info[m]]
+        assert arr.dtype == np.float32 and arr.shape == (n_snr, n_frames, 18)
+        x = blocks[m].reshape(-1, fs)
+        _assert_parity(arr.reshape(-1, 18), orc.features18_batch(x), x, f"CLI extract {m}", large_sample=True)
+    bad = subprocess.run([sys.executable, "-m", "amcpy_amd", "extract", "--root", str(tmp_path / "nowhere")],
+                         env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0                                                # a missing container is an error
+
+
+def test_calculate_features_in_a_loop_reuses_its_context():
+    """The reference's usage pattern -- calculate_features once per frame (feature_extraction.py:30-39)
+    -- must not pay allocation per call: the per-thread context (amcx_ctx_*) keeps stream and
+    scratch.  Same values as the batch entry, and a loop of 200 calls stays under 50 ms each."""
+    import time
+    from amcpy_amd import synth
+    from amcpy_amd.features import calculate_features, features18_host
+    x = synth.host_block("16QAM", 8.0, 8, 2048, seed=77)
+    batch = features18_host(x)
+    calculate_features(range(1, 19), x[0])                                    # warm: context + kernels
+    t0 = time.perf_counter()
+    for k in range(200):
+        row = calculate_features(range(1, 19), x[k % 8])
+        assert np.array_equal(np.float32(row), batch[k % 8])
+    per_call = (time.perf_counter() - t0) / 200
+    print(f"\ncalculate_features per call: {per_call * 1e6:.0f} us")
+    assert per_call < 50e-3
+    # complex128 frames take the double entry of the same context
+    row = calculate_features([6, 11], x[0].astype(np.complex128) * (1 + 1e-9))
+    assert np.allclose(row, [batch[0][5], batch[0][10]], rtol=1e-6)
