@@ -67,7 +67,10 @@ constexpr int kStashStride = 33;                // 32 floats used per frame; odd
 constexpr int kEx1StrideKK = 136, kEx1StrideB = 68;   // complex units (tools/wave_fft_model.py)
 constexpr int kEx2StrideK2 = 65;
 constexpr int kExchangeBytes = (7 * kEx1StrideKK + kEx1StrideB + 64) * 8;   // 8672: last complex slot exchange 1 touches; >= 16*65*8 = 8320
-constexpr int kT2Bytes = 15 * 8 * 8;                   // [k2-1][n3] complex
+// twiddles of the twisted decimation-in-time passes (see fft_peak): stage s of a LEN-point pass
+// holds 2^s factors, flat index 2^s - 1 + k
+constexpr int kTw2Stride = 15 * 8;                     // pass 2: 15 complex per k1 slot (bytes)
+constexpr int kTw3Row = 64 * 8;                        // pass 3: [phase][j][7][lane] complex, one row per factor
 
 template <int N>
 struct Cfg {
@@ -108,10 +111,12 @@ struct Cfg {
   static constexpr int kHeldRows = kSplit2 ? 32 : kRows;   // rows a wave holds in registers (N = 8192: the lower half)
   static constexpr int kFftRows = kSplit ? 16 : kRows; // R: rows one register FFT holds
   static constexpr int kFftN = 128 * kFftRows;
-  static constexpr int kT1Bytes = (kFftRows - 1) * 64 * 16;   // [k1-1][lane][b] complex
+  static constexpr int kPhases = kFftRows >= 8 ? kFftRows / 8 : 1;   // exchange phases of 8 k1 slots
+  static constexpr int kT2Bytes = 8 * kPhases * kTw2Stride;          // [k1 slot][15] complex
+  static constexpr int kT3Bytes = kPhases * 2 * 7 * kTw3Row;         // [phase][j][7][lane] complex
   static constexpr int kT4Bytes = kSplit ? 64 * 16 : 0;       // [lane][b] complex: W_4096^(2l+b)
   static constexpr int kT8Bytes = kSplit2 ? 64 * 16 : 0;      // [lane][b] complex: W_8192^(2l+b)
-  static constexpr int kTableBytes = kT1Bytes + kT2Bytes + kT4Bytes + kT8Bytes;
+  static constexpr int kTableBytes = kT2Bytes + kT3Bytes + kT4Bytes + kT8Bytes;
   static constexpr int kCounterOffset = kTableBytes + kWavesPerWG * (kExchangeBytes + kStashBytes);
   static constexpr int kLdsBytes = kCounterOffset + 16;       // + the workgroup's two work counters
   static_assert(kLdsBytes <= 163840, "one workgroup per CU must fit in 160 KiB of LDS");
@@ -383,13 +388,51 @@ struct Stats {
 
 // LDS addresses that depend only on the lane (bytes)
 struct LaneAddr {
-  const char* t1;     // T1 + lane*16
-  const char* t2;     // T2 + (lane&7)*8
+  const char* tw2;    // pass-2 twiddles of this lane's k1 slot: T2 + (lane>>3)*kTw2Stride
+  const char* tw3;    // pass-3 twiddles: T3 + lane*8
   char* ex1_w;        // exchange + lane*8
   const char* ex1_r;
   char* ex2_w;
   const char* ex2_r;
 };
+
+// (a, b) <- (a + t b, a - t b) in 6 FMAs: the second output is 2a - (a + t b)
+__device__ __forceinline__ void bfly6(float& ar, float& ai, float& br, float& bi, const float2 t) {
+  const float yr = __builtin_fmaf(-t.y, bi, __builtin_fmaf(t.x, br, ar));
+  const float yi = __builtin_fmaf(t.y, br, __builtin_fmaf(t.x, bi, ai));
+  br = __builtin_fmaf(2.0f, ar, -yr);
+  bi = __builtin_fmaf(2.0f, ai, -yi);
+  ar = yr;
+  ai = yi;
+}
+
+// LEN-point DFT of x[m] * w^m, radix-2 decimation in time with the twist folded into every
+// butterfly's factor: Y = E + (w W_LEN^k) O, E / O the (w^2-twisted) transforms of the even / odd
+// samples.  In place on natural-order storage; frequency k ends at position bitrev(k).
+// tw(i) returns factor i of the flat list [stage s: 2^s factors w^(LEN/2^(s+1)) W_(2^(s+1))^k].
+// This is how the inter-pass twiddles of the 16 x 16 x 8 decomposition are applied: 6 FMAs per
+// butterfly instead of a 4-op complex multiplication per point plus 4 add/sub per butterfly
+// (tools/wave_fft_model.py: model_fused).
+template <int LEN, class TW>
+__device__ __forceinline__ void twisted_dit(float (&re)[LEN], float (&im)[LEN], TW&& tw) {
+  constexpr int LOG = LEN == 16 ? 4 : 3;
+  static_assert(LEN == 16 || LEN == 8, "pass lengths");
+  static_for<LOG>([&](auto ss) {
+    constexpr int sidx = decltype(ss)::value;
+    constexpr int half = 1 << sidx;             // factors in this stage = L/2
+    constexpr int d = LEN / (2 * half);         // distance between the two inputs
+    float2 t[half];                             // fetched per stage: all LEN-1 at once cost registers
+    static_for<half>([&](auto kk) { t[decltype(kk)::value] = tw(std::integral_constant<int, half - 1 + decltype(kk)::value>{}); });
+    static_for<d>([&](auto mm) {
+      constexpr int m = decltype(mm)::value;
+      static_for<half>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        constexpr int p = m + 2 * d * bitrev(k, sidx);
+        bfly6(re[p], im[p], re[p + d], im[p + d], t[k]);
+      });
+    });
+  });
+}
 
 // Register FFT of 128*R points held as xr/xi[2*i+b] (see header); returns this
 // lane's max |X|^2 over the 2R bins it ends up with.
@@ -399,7 +442,7 @@ __device__ __forceinline__ float fft_peak(const float (&xr)[2 * R], const float 
   static_assert(R == 8 || R == 16, "shorter frames go through fft_front / fft_back");
   constexpr int LOG2R = R == 16 ? 4 : 3;
   constexpr int PH = R / 8;                  // exchange phases of 8 k1 values
-  // pass 1 (both b groups), twiddle T1, exchange 1
+  // pass 1 (both b groups): plain DFT over the rows, no twiddle (it rides pass 2 and pass 3)
   float v0r[R], v0i[R], v1r[R], v1i[R];
   static_for<R>([&](auto ii) {
     constexpr int i = decltype(ii)::value;
@@ -407,17 +450,6 @@ __device__ __forceinline__ float fft_peak(const float (&xr)[2 * R], const float 
   });
   dif<R, 0>(v0r, v0i);
   dif<R, 0>(v1r, v1i);
-  static_for<R - 1>([&](auto kk1) {
-    constexpr int k1 = decltype(kk1)::value + 1;
-    constexpr int p = bitrev(k1, LOG2R);
-    const float4 t = *reinterpret_cast<const float4*>(la.t1 + (k1 - 1) * 1024);
-    float r = v0r[p], im = v0i[p];
-    v0r[p] = __builtin_fmaf(r, t.x, -(im * t.y));
-    v0i[p] = __builtin_fmaf(r, t.y, im * t.x);
-    r = v1r[p]; im = v1i[p];
-    v1r[p] = __builtin_fmaf(r, t.z, -(im * t.w));
-    v1i[p] = __builtin_fmaf(r, t.w, im * t.z);
-  });
   float zr[PH][16], zi[PH][16];
   static_for<PH>([&](auto gg) {
     constexpr int gph = decltype(gg)::value;
@@ -437,17 +469,11 @@ __device__ __forceinline__ float fft_peak(const float (&xr)[2 * R], const float 
   });
   asm volatile("; MARK fft2");
   __builtin_amdgcn_sched_barrier(0);
-  // pass 2, twiddle T2, exchange 2, pass 3
-  static_for<PH>([&](auto gg) { dif<16, 0>(zr[decltype(gg)::value], zi[decltype(gg)::value]); });
-  static_for<15>([&](auto kk2) {
-    constexpr int k2 = decltype(kk2)::value + 1;
-    constexpr int p = bitrev(k2, 4);
-    const float2 t = *reinterpret_cast<const float2*>(la.t2 + (k2 - 1) * 64);
-    static_for<PH>([&](auto gg) {
-      constexpr int gph = decltype(gg)::value;
-      const float r = zr[gph][p], im = zi[gph][p];
-      zr[gph][p] = __builtin_fmaf(r, t.x, -(im * t.y));
-      zi[gph][p] = __builtin_fmaf(r, t.y, im * t.x);
+  // pass 2 over n2, twist (W_(NF/8)^k1)^n2; exchange 2; pass 3 over n3, twist (W_NF^(R k2 + k1))^n3
+  static_for<PH>([&](auto gg) {
+    constexpr int gph = decltype(gg)::value;
+    twisted_dit<16>(zr[gph], zi[gph], [&](auto ii) {
+      return *reinterpret_cast<const float2*>(la.tw2 + gph * 8 * kTw2Stride + decltype(ii)::value * 8);
     });
   });
   float peak = 0.f;
@@ -468,10 +494,13 @@ __device__ __forceinline__ float fft_peak(const float (&xr)[2 * R], const float 
         const float2 v = *reinterpret_cast<const float2*>(la.ex2_r + (j * 8 * kEx2StrideK2 + n3) * 8);
         ur[n3] = v.x; ui[n3] = v.y;
       });
-      dif<8, 0>(ur, ui);
-      static_for<8>([&](auto pp) {
-        constexpr int p = decltype(pp)::value;
-        peak = __builtin_fmaxf(peak, __builtin_fmaf(ur[p], ur[p], ui[p] * ui[p]));
+      twisted_dit<8>(ur, ui, [&](auto ii) {
+        return *reinterpret_cast<const float2*>(la.tw3 + ((gph * 2 + j) * 7 + decltype(ii)::value) * kTw3Row);
+      });
+      static_for<4>([&](auto pp) {
+        constexpr int p = 2 * decltype(pp)::value;
+        peak = __builtin_fmaxf(__builtin_fmaxf(peak, __builtin_fmaf(ur[p], ur[p], ui[p] * ui[p])),
+                               __builtin_fmaf(ur[p + 1], ur[p + 1], ui[p + 1] * ui[p + 1]));   // v_max3
       });
     });
   });
@@ -480,7 +509,7 @@ __device__ __forceinline__ float fft_peak(const float (&xr)[2 * R], const float 
 }
 
 // The same machine in two halves for R < 8 (one exchange phase), so that 8/R frames can share
-// the second half.  fft_front: pass 1 + twiddle + exchange-1 write of one frame into k1 slots
+// the second half.  fft_front: pass 1 + exchange-1 write of one frame into k1 slots
 // [SLOT0, SLOT0 + R).
 template <int R, int SLOT0>
 __device__ __forceinline__ void fft_front(const float (&xr)[2 * R], const float (&xi)[2 * R],
@@ -494,17 +523,6 @@ __device__ __forceinline__ void fft_front(const float (&xr)[2 * R], const float 
   });
   dif<R, 0>(v0r, v0i);
   dif<R, 0>(v1r, v1i);
-  static_for<R - 1>([&](auto kk1) {
-    constexpr int k1 = decltype(kk1)::value + 1;
-    constexpr int p = bitrev(k1, LOG2R);
-    const float4 t = *reinterpret_cast<const float4*>(la.t1 + (k1 - 1) * 1024);
-    float r = v0r[p], im = v0i[p];
-    v0r[p] = __builtin_fmaf(r, t.x, -(im * t.y));
-    v0i[p] = __builtin_fmaf(r, t.y, im * t.x);
-    r = v1r[p]; im = v1i[p];
-    v1r[p] = __builtin_fmaf(r, t.z, -(im * t.w));
-    v1i[p] = __builtin_fmaf(r, t.w, im * t.z);
-  });
   static_for<R>([&](auto kk_) {
     constexpr int k1 = decltype(kk_)::value;
     constexpr int p = bitrev(k1, LOG2R);
@@ -514,8 +532,9 @@ __device__ __forceinline__ void fft_front(const float (&xr)[2 * R], const float 
   });
 }
 
-// fft_back: exchange-1 read, pass 2, exchange 2, pass 3 over all eight k1 slots at once;
-// returns this lane's max |X|^2 over its 16 bins (of the frame that owns slot lane>>3)
+// fft_back: exchange-1 read, pass 2, exchange 2, pass 3 over all eight k1 slots at once (the
+// twiddle tables know which frame-local k1 a slot holds); returns this lane's max |X|^2 over its
+// 16 bins (of the frame that owns slot lane>>3)
 __device__ __forceinline__ float fft_back(const LaneAddr& la) {
   float zr[16], zi[16];
   lds_wave_fence();
@@ -526,14 +545,8 @@ __device__ __forceinline__ float fft_back(const LaneAddr& la) {
   });
   asm volatile("; MARK fft2");
   __builtin_amdgcn_sched_barrier(0);
-  dif<16, 0>(zr, zi);
-  static_for<15>([&](auto kk2) {
-    constexpr int k2 = decltype(kk2)::value + 1;
-    constexpr int p = bitrev(k2, 4);
-    const float2 t = *reinterpret_cast<const float2*>(la.t2 + (k2 - 1) * 64);
-    const float r = zr[p], im = zi[p];
-    zr[p] = __builtin_fmaf(r, t.x, -(im * t.y));
-    zi[p] = __builtin_fmaf(r, t.y, im * t.x);
+  twisted_dit<16>(zr, zi, [&](auto ii) {
+    return *reinterpret_cast<const float2*>(la.tw2 + decltype(ii)::value * 8);
   });
   float peak = 0.f;
   lds_wave_fence();
@@ -551,10 +564,13 @@ __device__ __forceinline__ float fft_back(const LaneAddr& la) {
       const float2 v = *reinterpret_cast<const float2*>(la.ex2_r + (j * 8 * kEx2StrideK2 + n3) * 8);
       ur[n3] = v.x; ui[n3] = v.y;
     });
-    dif<8, 0>(ur, ui);
-    static_for<8>([&](auto pp) {
-      constexpr int p = decltype(pp)::value;
-      peak = __builtin_fmaxf(peak, __builtin_fmaf(ur[p], ur[p], ui[p] * ui[p]));
+    twisted_dit<8>(ur, ui, [&](auto ii) {
+      return *reinterpret_cast<const float2*>(la.tw3 + (j * 7 + decltype(ii)::value) * kTw3Row);
+    });
+    static_for<4>([&](auto pp) {
+      constexpr int p = 2 * decltype(pp)::value;
+      peak = __builtin_fmaxf(__builtin_fmaxf(peak, __builtin_fmaf(ur[p], ur[p], ui[p] * ui[p])),
+                             __builtin_fmaf(ur[p + 1], ur[p + 1], ui[p + 1] * ui[p + 1]));
     });
   });
   lds_wave_fence();
@@ -575,9 +591,9 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  char* t1 = smem;                                        // [R-1][64][2] complex
-  char* t2 = smem + C::kT1Bytes;                          // [15][8] complex
-  char* t4 = smem + C::kT1Bytes + kT2Bytes;               // [64][2] complex (N >= 4096 only)
+  char* t2 = smem;                                        // pass-2 twiddles [k1 slot][15] complex
+  char* t3 = smem + C::kT2Bytes;                          // pass-3 twiddles [phase][j][7][lane] complex
+  char* t4 = smem + C::kT2Bytes + C::kT3Bytes;            // [64][2] complex (N >= 4096 only)
   char* t8 = t4 + C::kT4Bytes;                            // [64][2] complex (N = 8192 only)
   char* ex = smem + C::kTableBytes + wave * kExchangeBytes;
   float* stash = reinterpret_cast<float*>(smem + C::kTableBytes + kWavesPerWG * kExchangeBytes) +
@@ -601,17 +617,29 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
   const long long body_len = slice_len - tail_len;          // grabbed kFramesPerWave at a time
 
   // ---- twiddle tables, once per workgroup -----------------------------------
-  for (int e = tid; e < (R - 1) * 128; e += kThreads) {    // T1[k1-1][l][b] = W_NF^((2l+b) k1)
-    const int k1 = e / 128 + 1, lb = e % 128;
+  // W_NF^e = exp(-2 pi i e / NF) with an integer exponent: exact argument reduction
+  auto w_nf = [](int e) {
     float sn, cs;
-    sincospif((float)(lb * k1) * (2.0f / (float)C::kFftN), &sn, &cs);
-    reinterpret_cast<float2*>(t1)[e] = make_float2(cs, -sn);
+    sincospif((float)(e & (C::kFftN - 1)) * (2.0f / (float)C::kFftN), &sn, &cs);
+    return make_float2(cs, -sn);
+  };
+  // pass 2 (16 points over n2, slot k1' = 8 g + kk holding frame-local k1 = k1' mod R): factor i of
+  // stage s (L = 2^(s+1), d = 16 / L):  (W_(NF/8)^k1)^d W_L^k  =  W_NF^(8 k1 d + k NF / L)
+  for (int e = tid; e < 8 * C::kPhases * 15; e += kThreads) {
+    const int slot = e / 15, i = e % 15;
+    const int k1 = slot % R;
+    const int sidx = i < 1 ? 0 : i < 3 ? 1 : i < 7 ? 2 : 3;
+    const int k = i - ((1 << sidx) - 1), Lp = 2 << sidx, d = 16 / Lp;
+    reinterpret_cast<float2*>(t2)[e] = w_nf(8 * k1 * d + k * (C::kFftN / Lp));
   }
-  for (int e = tid; e < 15 * 8; e += kThreads) {           // T2[k2-1][n3] = W_128^(n3 k2)
-    const int k2 = e / 8 + 1, n3 = e % 8;
-    float sn, cs;
-    sincospif((float)(n3 * k2) * (1.0f / 64.0f), &sn, &cs);
-    reinterpret_cast<float2*>(t2)[e] = make_float2(cs, -sn);
+  // pass 3 (8 points over n3; lane = (kk, k2 low), combination c = 2 g + j: k2 = (lane & 7) + 8 j):
+  // (W_NF^(R k2 + k1))^d W_L^k = W_NF^((R k2 + k1) d + k NF / L), L = 2^(s+1), d = 8 / L
+  for (int e = tid; e < C::kPhases * 2 * 7 * 64; e += kThreads) {
+    const int ln = e & 63, i = (e >> 6) % 7, c = e / (7 * 64);
+    const int k1 = (8 * (c >> 1) + (ln >> 3)) % R, k2 = (ln & 7) + 8 * (c & 1);
+    const int sidx = i < 1 ? 0 : i < 3 ? 1 : 2;
+    const int k = i - ((1 << sidx) - 1), Lp = 2 << sidx, d = 8 / Lp;
+    reinterpret_cast<float2*>(t3)[e] = w_nf((R * k2 + k1) * d + k * (C::kFftN / Lp));
   }
   if constexpr (C::kSplit) {
     for (int e = tid; e < 128; e += kThreads) {            // T4[l][b] = W_4096^(2l+b)
@@ -632,8 +660,8 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
   // lane-constant LDS byte addresses
   const int kkL = lane >> 3, n3L = lane & 7;
   LaneAddr la;
-  la.t1 = t1 + lane * 16;
-  la.t2 = t2 + n3L * 8;
+  la.tw2 = t2 + kkL * kTw2Stride;
+  la.tw3 = t3 + lane * 8;
   la.ex1_w = ex + lane * 8;
   la.ex1_r = ex + (kkL * kEx1StrideKK + (n3L & 1) * kEx1StrideB + (n3L >> 1)) * 8;
   la.ex2_w = ex + lane * 8;
@@ -690,7 +718,11 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
     // (SLOT: for grouped short frames, which eighth of exchange 1 this frame's FFT front fills)
     auto frame = [&](const float (&xr)[2 * ROWS], const float (&xi)[2 * ROWS], int g, auto slot_tag) {
       constexpr int SLOT = decltype(slot_tag)::value;
+#ifdef AMCX_EXP_A_IN_REGS   // experiment: N = 2048 keeps |x| in 32 VGPRs instead of parking it in LDS
+      constexpr bool kAInRegs = C::kGroup > 1 || N == 2048;
+#else
       constexpr bool kAInRegs = C::kGroup > 1;   // |x| stays in registers: exchange 1 is shared by the group
+#endif
       asm volatile("; MARK load");
       AMCX_STAMP(7);
       // wave reduction of a frame's 27 per-lane sums into one stash row

@@ -25,6 +25,19 @@
  *   - every function returns 0 or a negative AMCX_E* code and never throws.
  *     NaN/Inf in the data are not errors: a frame holding a non-finite sample
  *     yields 18 NaNs, as numpy's arithmetic does for the reference.
+ *   - amplitude range: samples are exact zeros or 1e-15 <~ |x| <~ 1e15.  Inside
+ *     1e-5 <~ rms|x| <~ 1e5 the throughput kernel's fp32 sums hold; outside it (and whenever
+ *     one of its sums overflows: a single 1e7 sample among unit ones) the frame is
+ *     recomputed with fp64 sums by the fix-up launch, so results match the reference --
+ *     which evaluates in complex128 (features.py:46-58) -- including the inf / 0 its
+ *     float32 store produces for |x|^6 beyond float32 (feature_extraction.py:35,56).
+ *     Such frames run at the block kernel's rate (~1/10 of the fast path).
+ *   - AMCX_VARIANT_WAVE / AUTO on a power-of-two frame size is TWO launches on the stream:
+ *     the throughput kernel marks the frames it cannot finish exactly in band -- feature 5
+ *     (a standard deviation, >= 0 or NaN) stored negative: finite = a phase step within an
+ *     fp32 ulp of +-pi, -inf = outside the fp32 range -- and amcx_fixup_kernel rewrites
+ *     them.  A consumer on ANOTHER stream that reads `out_dev` between the two launches
+ *     sees those marks; order it after the whole call (event / stream sync), as usual.
  *   - re-entrant and thread-safe; launches are asynchronous on `hip_stream`
  *     (a hipStream_t, NULL = default stream); completion = caller's stream sync.
  *     The device entry points allocate nothing and never synchronise, so after one
@@ -54,7 +67,10 @@ extern "C" {
 #define AMCX_VARIANT_AUTO 0     /* fastest kernel that supports frame_size */
 #define AMCX_VARIANT_BLOCK 1    /* one 256-thread workgroup per frame, frame staged in LDS,
                                    radix-2 LDS FFT (power of two), Bluestein chirp-z FFT
-                                   (65..4096) or direct DFT (any other N); fp64
+                                   (65..4096) or direct O(N^2) fp64 DFT (N <= 64, and the
+                                   non-powers of two 4097..8191, whose chirp would need 256 KB
+                                   of LDS: ~100x slower per frame than Bluestein at 4096 --
+                                   zero-pad such frames to 8192 if that is acceptable); fp64
                                    accumulation; 2 <= frame_size <= AMCX_MAX_FRAME_SIZE */
 #define AMCX_VARIANT_WAVE 2     /* one wavefront per frame, frame held in registers,
                                    register radix-16/8 FFT with LDS exchanges, followed by a

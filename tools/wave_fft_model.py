@@ -100,3 +100,115 @@ if __name__ == "__main__":
         print(f"N = {N:5d} (R = {R1:2d}): max rel err vs np.fft.fft: {err:.2e}")
         assert err < 1e-12
     print("all exchange instructions conflict-free; index maps OK")
+
+
+# ---------------------------------------------------------------------------------------------
+# Round 2: the inter-pass twiddles ride the NEXT pass's butterflies ("twisted" decimation in time).
+#   pass 1 leaves  y[k1; n_low],  n_low = 8 n2 + n3, untwiddled.  T1 = W_NF^(n_low k1) factors as
+#   W_NF^(n3 k1) * (W_(NF/8)^k1)^n2 : the second factor is a geometric twist of pass 2's input,
+#   the first moves into pass 3's twist,  W_128^(n3 k2) W_NF^(n3 k1) = (W_NF^(R k2 + k1))^n3.
+#   A LEN-point DFT of x[m] w^m by radix-2 DIT:  Y = E + (w W_LEN^k) O  with E, O the twisted DFTs
+#   (twist w^2) of the even / odd samples -- every butterfly a + t b, a - t b = 2a - (a + t b):
+#   6 FMAs, no separate twiddle multiplication.  In place on natural-order storage, result for
+#   frequency k at position bitrev(k) (never un-reversed: only max |X|^2 is kept).
+def bitrev(v, bits):
+    r = 0
+    for i in range(bits):
+        r |= ((v >> i) & 1) << (bits - 1 - i)
+    return r
+
+
+def dit_twiddles(w, LEN):
+    """[stage][k]: stage s joins sub-transforms of length L/2 -> L = 2^(s+1), distance d = LEN/L."""
+    out = []
+    L = 2
+    while L <= LEN:
+        d = LEN // L
+        out.append([w ** d * W(L, k) for k in range(L // 2)])
+        L *= 2
+    return out
+
+
+def twisted_dit(v, tw):
+    """v: (LEN, lanes) array, tw[stage][k]: (lanes,) arrays.  Returns v with Y[k] at bitrev(k)."""
+    LEN = v.shape[0]
+    v = v.copy()
+    L, s = 2, 0
+    while L <= LEN:
+        d = LEN // L
+        bits = s            # log2(L/2)
+        for m in range(d):
+            for k in range(L // 2):
+                p = m + 2 * d * bitrev(k, bits)
+                a, b, t = v[p], v[p + d], tw[s][k]
+                y = a + t * b
+                v[p], v[p + d] = y, 2 * a - y
+        L *= 2
+        s += 1
+    return v
+
+
+def model_fused(x, R1):
+    """Same lane/register/LDS maps as model(); T1 / T2 folded into passes 2 / 3."""
+    N = 128 * R1
+    PH = max(1, R1 // 8)
+    lane = np.arange(L)
+    reg = np.zeros((L, R1, 2), complex)
+    for i in range(R1):
+        for b in range(2):
+            reg[:, i, b] = x[128 * i + 2 * lane + b]
+    y1 = np.zeros_like(reg)          # pass 1, NO twiddle
+    for k1 in range(R1):
+        for b in range(2):
+            y1[:, k1, b] = sum(reg[:, i, b] * W(R1, i * k1) for i in range(R1))
+    z = np.zeros((L, PH, 16), complex)
+    n2w, qw = lane >> 2, lane & 3
+    for g in range(PH):
+        lds = np.full(1088, 0j, complex)
+        for kk in range(min(8, R1)):
+            for b in range(2):
+                lds[ex1_addr(kk, n2w, 2 * qw + b)] = y1[:, 8 * g + kk, b]
+        for n2 in range(16):
+            z[:, g, n2] = lds[ex1_addr(lane >> 3, n2, lane & 7)]
+    # pass 2: twist w = W_(N/8)^k1, k1 = 8g + (lane>>3): the table depends on k1 only (16 x 15 entries)
+    y2 = np.zeros((L, PH, 16), complex)  # position p holds k2 = bitrev(p)
+    for g in range(PH):
+        k1 = 8 * g + (lane >> 3)
+        w = W(N // 8, 1) ** k1
+        y2[:, g, :] = twisted_dit(z[:, g, :].T, dit_twiddles(w, 16)).T
+    u = np.zeros((L, PH, 2, 8), complex)
+    for g in range(PH):
+        lds = np.full(1040, 0j, complex)
+        for k2 in range(16):
+            lds[ex2_addr(lane >> 3, k2, lane & 7)] = y2[:, g, bitrev(k2, 4)]
+        for j in range(2):
+            for n3 in range(8):
+                u[:, g, j, n3] = lds[ex2_addr(lane >> 3, (lane & 7) + 8 * j, n3)]
+    # pass 3: twist w3 = W_N^(R k2 + k1), fully lane-dependent: table [g][j][7][lane]
+    X = np.zeros(N, complex)
+    for g in range(PH):
+        for j in range(2):
+            k1 = 8 * g + (lane >> 3)
+            k2 = (lane & 7) + 8 * j
+            w3 = W(N, 1) ** (R1 * k2 + k1)
+            out = twisted_dit(u[:, g, j, :].T, dit_twiddles(w3, 8))
+            ok = k1 < R1
+            for k3 in range(8):
+                X[(k1 + R1 * k2 + 16 * R1 * k3)[ok]] = out[bitrev(k3, 3)][ok]
+    return X
+
+
+def check_fused():
+    rng = np.random.default_rng(1)
+    for R1 in (8, 16):
+        N = 128 * R1
+        x = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+        X = model_fused(x, R1)
+        ref = np.fft.fft(x)
+        err = np.abs(X - ref).max() / np.abs(ref).max()
+        print(f"fused twiddles, N = {N:5d}: max rel err vs np.fft.fft: {err:.2e}")
+        assert err < 1e-12
+
+
+if __name__ == "__main__":
+    check_fused()
