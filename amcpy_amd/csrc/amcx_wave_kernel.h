@@ -102,6 +102,8 @@ struct Cfg {
   // frame alone takes 128 VGPRs (16 waves at N = 1024, 114 VGPRs, measured no faster: power-bound)
 #ifdef AMCX_EXP_WAVES16
   static constexpr int kWavesPerWG = kSplit ? 8 : 16;
+#elif defined(AMCX_EXP_8192_W4)
+  static constexpr int kWavesPerWG = kSplit2 ? 4 : kSplit ? 8 : 12;
 #else
   static constexpr int kWavesPerWG = kSplit ? 8 : 12;
 #endif
@@ -116,7 +118,13 @@ struct Cfg {
   static constexpr int kT3Bytes = kPhases * 2 * 7 * kTw3Row;         // [phase][j][7][lane] complex
   static constexpr int kT4Bytes = kSplit ? 64 * 16 : 0;       // [lane][b] complex: W_4096^(2l+b)
   static constexpr int kT8Bytes = kSplit2 ? 64 * 16 : 0;      // [lane][b] complex: W_8192^(2l+b)
-  static constexpr int kTableBytes = kT2Bytes + kT3Bytes + kT4Bytes + kT8Bytes;
+  // N = 8192 keeps the classic form of passes 2 / 3 (separate twiddle multiplications, fft_peak_classic):
+  // its FFTs run next to 64 live registers of the other branch, and the fused butterflies' extra
+  // operands turned 66 spilled registers into 360 there (28.6 -> 17 M frames/s)
+  static constexpr bool kClassicFft = kSplit2;
+  static constexpr int kT1cBytes = kClassicFft ? 15 * 64 * 16 : 0;   // classic T1 [k1-1][lane][b] complex
+  static constexpr int kT2cBytes = kClassicFft ? 15 * 8 * 8 : 0;     // classic T2 [k2-1][n3] complex
+  static constexpr int kTableBytes = (kClassicFft ? kT1cBytes + kT2cBytes : kT2Bytes + kT3Bytes) + kT4Bytes + kT8Bytes;
   static constexpr int kCounterOffset = kTableBytes + kWavesPerWG * (kExchangeBytes + kStashBytes);
   static constexpr int kLdsBytes = kCounterOffset + 16;       // + the workgroup's two work counters
   static_assert(kLdsBytes <= 163840, "one workgroup per CU must fit in 160 KiB of LDS");
@@ -210,6 +218,23 @@ __device__ __forceinline__ void dif(float (&re)[R], float (&im)[R]) {
     dif<H, OFF, R>(re, im);
     dif<H, OFF + H, R>(re, im);
   }
+}
+
+// first stage only of dif<LEN, OFF>: afterwards [OFF, OFF+LEN/2) and [OFF+LEN/2, OFF+LEN) are two
+// independent half-length problems (even / odd output frequencies)
+template <int LEN, int OFF, int R>
+__device__ __forceinline__ void dif_stage(float (&re)[R], float (&im)[R]) {
+  constexpr int H = LEN / 2;
+  static_for<H>([&](auto jj) {
+    constexpr int j = decltype(jj)::value;
+    const float ar = re[OFF + j], ai = im[OFF + j], br = re[OFF + j + H], bi = im[OFF + j + H];
+    re[OFF + j] = ar + br;
+    im[OFF + j] = ai + bi;
+    float dr = ar - br, di = ai - bi;
+    mul_w32<j * (32 / LEN)>(dr, di);
+    re[OFF + j + H] = dr;
+    im[OFF + j + H] = di;
+  });
 }
 
 // ---- DPP helpers -------------------------------------------------------------
@@ -388,6 +413,8 @@ struct Stats {
 
 // LDS addresses that depend only on the lane (bytes)
 struct LaneAddr {
+  const char* t1c;    // classic tables (N = 8192 only): T1 + lane*16, T2 + (lane&7)*8
+  const char* t2c;
   const char* tw2;    // pass-2 twiddles of this lane's k1 slot: T2 + (lane>>3)*kTw2Stride
   const char* tw3;    // pass-3 twiddles: T3 + lane*8
   char* ex1_w;        // exchange + lane*8
@@ -421,14 +448,13 @@ __device__ __forceinline__ void twisted_dit(float (&re)[LEN], float (&im)[LEN], 
     constexpr int sidx = decltype(ss)::value;
     constexpr int half = 1 << sidx;             // factors in this stage = L/2
     constexpr int d = LEN / (2 * half);         // distance between the two inputs
-    float2 t[half];                             // fetched per stage: all LEN-1 at once cost registers
-    static_for<half>([&](auto kk) { t[decltype(kk)::value] = tw(std::integral_constant<int, half - 1 + decltype(kk)::value>{}); });
-    static_for<d>([&](auto mm) {
-      constexpr int m = decltype(mm)::value;
-      static_for<half>([&](auto kk) {
-        constexpr int k = decltype(kk)::value;
+    static_for<half>([&](auto kk) {
+      constexpr int k = decltype(kk)::value;
+      const float2 t = tw(std::integral_constant<int, half - 1 + k>{});   // one factor serves d butterflies
+      static_for<d>([&](auto mm) {
+        constexpr int m = decltype(mm)::value;
         constexpr int p = m + 2 * d * bitrev(k, sidx);
-        bfly6(re[p], im[p], re[p + d], im[p + d], t[k]);
+        bfly6(re[p], im[p], re[p + d], im[p + d], t);
       });
     });
   });
@@ -440,9 +466,89 @@ template <int R>
 __device__ __forceinline__ float fft_peak(const float (&xr)[2 * R], const float (&xi)[2 * R],
                                           const LaneAddr& la) {
   static_assert(R == 8 || R == 16, "shorter frames go through fft_front / fft_back");
+  constexpr int PH = R / 8;                  // exchange phases of 8 k1 values
+  // pass 1 (both b groups): plain DFT over the rows, no twiddle (it rides pass 2 and pass 3).
+  // With two exchange phases (R = 16) phase g takes the k1 of parity g: after the first
+  // decimation-in-frequency stage those are the two independent halves of the register set, so
+  // the odd half waits as 8 + 8 complex values while the even half goes through exchange 1,
+  // pass 2, exchange 2 and pass 3 -- 32 registers fewer in flight than with both phases' pass-2
+  // inputs read before either is processed.
+  float v0r[R], v0i[R], v1r[R], v1i[R];
+  static_for<R>([&](auto ii) {
+    constexpr int i = decltype(ii)::value;
+    v0r[i] = xr[2 * i]; v0i[i] = xi[2 * i]; v1r[i] = xr[2 * i + 1]; v1i[i] = xi[2 * i + 1];
+  });
+  if constexpr (PH == 2) {
+    dif_stage<R, 0>(v0r, v0i);
+    dif_stage<R, 0>(v1r, v1i);
+  }
+  float peak = 0.f;
+  static_for<PH>([&](auto gg) {
+    constexpr int gph = decltype(gg)::value;
+    dif<8, 8 * gph>(v0r, v0i);
+    dif<8, 8 * gph>(v1r, v1i);
+    float zr[16], zi[16];
+    lds_wave_fence();
+    static_for<8>([&](auto kk_) {
+      constexpr int kk = decltype(kk_)::value;
+      constexpr int p = 8 * gph + bitrev(kk, 3);        // R = 16: k1 = 2 kk + gph; R = 8: k1 = kk
+      *reinterpret_cast<float2*>(la.ex1_w + (kk * kEx1StrideKK) * 8) = make_float2(v0r[p], v0i[p]);
+      *reinterpret_cast<float2*>(la.ex1_w + (kk * kEx1StrideKK + kEx1StrideB) * 8) = make_float2(v1r[p], v1i[p]);
+    });
+    lds_wave_fence();
+    static_for<16>([&](auto nn) {
+      constexpr int n2 = decltype(nn)::value;
+      const float2 v = *reinterpret_cast<const float2*>(la.ex1_r + n2 * 32);
+      zr[n2] = v.x; zi[n2] = v.y;
+    });
+    if constexpr (gph == 0) asm volatile("; MARK fft2");
+    __builtin_amdgcn_sched_barrier(0);
+    // pass 2 over n2, twist (W_(NF/8)^k1)^n2; exchange 2; pass 3 over n3, twist (W_NF^(R k2 + k1))^n3
+    const char* const tw2 = la.tw2;
+    twisted_dit<16>(zr, zi, [&](auto ii) {
+      return *reinterpret_cast<const float2*>(tw2 + gph * 8 * kTw2Stride + decltype(ii)::value * 8);
+    });
+    lds_wave_fence();
+    static_for<16>([&](auto kk2) {
+      constexpr int k2 = decltype(kk2)::value;
+      constexpr int p = bitrev(k2, 4);
+      *reinterpret_cast<float2*>(la.ex2_w + (k2 * kEx2StrideK2) * 8) = make_float2(zr[p], zi[p]);
+    });
+    lds_wave_fence();
+    const char* const tw3 = la.tw3;
+    static_for<2>([&](auto jj) {
+      constexpr int j = decltype(jj)::value;
+      float ur[8], ui[8];
+      static_for<8>([&](auto nn) {
+        constexpr int n3 = decltype(nn)::value;
+        const float2 v = *reinterpret_cast<const float2*>(la.ex2_r + (j * 8 * kEx2StrideK2 + n3) * 8);
+        ur[n3] = v.x; ui[n3] = v.y;
+      });
+      twisted_dit<8>(ur, ui, [&](auto ii) {
+        return *reinterpret_cast<const float2*>(tw3 + ((gph * 2 + j) * 7 + decltype(ii)::value) * kTw3Row);
+      });
+      static_for<4>([&](auto pp) {
+        constexpr int p = 2 * decltype(pp)::value;
+        peak = __builtin_fmaxf(__builtin_fmaxf(peak, __builtin_fmaf(ur[p], ur[p], ui[p] * ui[p])),
+                               __builtin_fmaf(ur[p + 1], ur[p + 1], ui[p + 1] * ui[p + 1]));   // v_max3
+      });
+    });
+    if constexpr (gph + 1 < PH) __builtin_amdgcn_sched_barrier(0);   // the other half starts only now
+  });
+  lds_wave_fence();
+  return peak;
+}
+
+// Round-1 form of the same transform, kept for N = 8192 (Cfg::kClassicFft): pass 1, T1 =
+// W_2048^((2l+b) k1) as a separate complex multiplication, exchange 1 (phase g = k1 >> 3), pass 2
+// (decimation in frequency), T2 = W_128^(n3 k2), exchange 2, pass 3.
+template <int R>
+__device__ __forceinline__ float fft_peak_classic(const float (&xr)[2 * R], const float (&xi)[2 * R],
+                                          const LaneAddr& la) {
+  static_assert(R == 16, "N = 8192 only");
   constexpr int LOG2R = R == 16 ? 4 : 3;
   constexpr int PH = R / 8;                  // exchange phases of 8 k1 values
-  // pass 1 (both b groups): plain DFT over the rows, no twiddle (it rides pass 2 and pass 3)
+  // pass 1 (both b groups), twiddle T1, exchange 1
   float v0r[R], v0i[R], v1r[R], v1i[R];
   static_for<R>([&](auto ii) {
     constexpr int i = decltype(ii)::value;
@@ -450,6 +556,17 @@ __device__ __forceinline__ float fft_peak(const float (&xr)[2 * R], const float 
   });
   dif<R, 0>(v0r, v0i);
   dif<R, 0>(v1r, v1i);
+  static_for<R - 1>([&](auto kk1) {
+    constexpr int k1 = decltype(kk1)::value + 1;
+    constexpr int p = bitrev(k1, LOG2R);
+    const float4 t = *reinterpret_cast<const float4*>(la.t1c + (k1 - 1) * 1024);
+    float r = v0r[p], im = v0i[p];
+    v0r[p] = __builtin_fmaf(r, t.x, -(im * t.y));
+    v0i[p] = __builtin_fmaf(r, t.y, im * t.x);
+    r = v1r[p]; im = v1i[p];
+    v1r[p] = __builtin_fmaf(r, t.z, -(im * t.w));
+    v1i[p] = __builtin_fmaf(r, t.w, im * t.z);
+  });
   float zr[PH][16], zi[PH][16];
   static_for<PH>([&](auto gg) {
     constexpr int gph = decltype(gg)::value;
@@ -467,13 +584,19 @@ __device__ __forceinline__ float fft_peak(const float (&xr)[2 * R], const float 
       zr[gph][n2] = v.x; zi[gph][n2] = v.y;
     });
   });
-  asm volatile("; MARK fft2");
-  __builtin_amdgcn_sched_barrier(0);
-  // pass 2 over n2, twist (W_(NF/8)^k1)^n2; exchange 2; pass 3 over n3, twist (W_NF^(R k2 + k1))^n3
-  static_for<PH>([&](auto gg) {
-    constexpr int gph = decltype(gg)::value;
-    twisted_dit<16>(zr[gph], zi[gph], [&](auto ii) {
-      return *reinterpret_cast<const float2*>(la.tw2 + gph * 8 * kTw2Stride + decltype(ii)::value * 8);
+  asm volatile("; MARK fft2");   // not only a marker for tools/isa.sh: without this asm statement the scheduler
+  __builtin_amdgcn_sched_barrier(0);   // merges the two halves and the N = 8192 kernel spills 374 registers instead of 66
+  // pass 2, twiddle T2, exchange 2, pass 3
+  static_for<PH>([&](auto gg) { dif<16, 0>(zr[decltype(gg)::value], zi[decltype(gg)::value]); });
+  static_for<15>([&](auto kk2) {
+    constexpr int k2 = decltype(kk2)::value + 1;
+    constexpr int p = bitrev(k2, 4);
+    const float2 t = *reinterpret_cast<const float2*>(la.t2c + (k2 - 1) * 64);
+    static_for<PH>([&](auto gg) {
+      constexpr int gph = decltype(gg)::value;
+      const float r = zr[gph][p], im = zi[gph][p];
+      zr[gph][p] = __builtin_fmaf(r, t.x, -(im * t.y));
+      zi[gph][p] = __builtin_fmaf(r, t.y, im * t.x);
     });
   });
   float peak = 0.f;
@@ -494,13 +617,10 @@ __device__ __forceinline__ float fft_peak(const float (&xr)[2 * R], const float 
         const float2 v = *reinterpret_cast<const float2*>(la.ex2_r + (j * 8 * kEx2StrideK2 + n3) * 8);
         ur[n3] = v.x; ui[n3] = v.y;
       });
-      twisted_dit<8>(ur, ui, [&](auto ii) {
-        return *reinterpret_cast<const float2*>(la.tw3 + ((gph * 2 + j) * 7 + decltype(ii)::value) * kTw3Row);
-      });
-      static_for<4>([&](auto pp) {
-        constexpr int p = 2 * decltype(pp)::value;
-        peak = __builtin_fmaxf(__builtin_fmaxf(peak, __builtin_fmaf(ur[p], ur[p], ui[p] * ui[p])),
-                               __builtin_fmaf(ur[p + 1], ur[p + 1], ui[p + 1] * ui[p + 1]));   // v_max3
+      dif<8, 0>(ur, ui);
+      static_for<8>([&](auto pp) {
+        constexpr int p = decltype(pp)::value;
+        peak = __builtin_fmaxf(peak, __builtin_fmaf(ur[p], ur[p], ui[p] * ui[p]));
       });
     });
   });
@@ -545,8 +665,9 @@ __device__ __forceinline__ float fft_back(const LaneAddr& la) {
   });
   asm volatile("; MARK fft2");
   __builtin_amdgcn_sched_barrier(0);
+  const char* const tw2 = la.tw2;
   twisted_dit<16>(zr, zi, [&](auto ii) {
-    return *reinterpret_cast<const float2*>(la.tw2 + decltype(ii)::value * 8);
+    return *reinterpret_cast<const float2*>(tw2 + decltype(ii)::value * 8);
   });
   float peak = 0.f;
   lds_wave_fence();
@@ -556,6 +677,7 @@ __device__ __forceinline__ float fft_back(const LaneAddr& la) {
     *reinterpret_cast<float2*>(la.ex2_w + (k2 * kEx2StrideK2) * 8) = make_float2(zr[p], zi[p]);
   });
   lds_wave_fence();
+  const char* const tw3 = la.tw3;
   static_for<2>([&](auto jj) {
     constexpr int j = decltype(jj)::value;
     float ur[8], ui[8];
@@ -565,7 +687,7 @@ __device__ __forceinline__ float fft_back(const LaneAddr& la) {
       ur[n3] = v.x; ui[n3] = v.y;
     });
     twisted_dit<8>(ur, ui, [&](auto ii) {
-      return *reinterpret_cast<const float2*>(la.tw3 + (j * 7 + decltype(ii)::value) * kTw3Row);
+      return *reinterpret_cast<const float2*>(tw3 + (j * 7 + decltype(ii)::value) * kTw3Row);
     });
     static_for<4>([&](auto pp) {
       constexpr int p = 2 * decltype(pp)::value;
@@ -579,7 +701,7 @@ __device__ __forceinline__ float fft_back(const LaneAddr& la) {
 
 // ---------------------------------------------------------------------------
 template <int N>
-__global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amcx_features18_wave_kernel(
+__global__ __launch_bounds__(Cfg<N>::kThreads, (Cfg<N>::kWavesPerWG + 3) / 4) void amcx_features18_wave_kernel(
     const float2* __restrict__ iq, long long n_frames, long long row_stride,
     float* __restrict__ out, long long out_stride AMCX_STAMP_ARG) {
   using C = Cfg<N>;
@@ -593,7 +715,9 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   char* t2 = smem;                                        // pass-2 twiddles [k1 slot][15] complex
   char* t3 = smem + C::kT2Bytes;                          // pass-3 twiddles [phase][j][7][lane] complex
-  char* t4 = smem + C::kT2Bytes + C::kT3Bytes;            // [64][2] complex (N >= 4096 only)
+  char* t1c = smem;                                       // classic tables instead (N = 8192)
+  char* t2c = smem + C::kT1cBytes;
+  char* t4 = smem + C::kTableBytes - C::kT4Bytes - C::kT8Bytes;   // [64][2] complex (N >= 4096 only)
   char* t8 = t4 + C::kT4Bytes;                            // [64][2] complex (N = 8192 only)
   char* ex = smem + C::kTableBytes + wave * kExchangeBytes;
   float* stash = reinterpret_cast<float*>(smem + C::kTableBytes + kWavesPerWG * kExchangeBytes) +
@@ -623,20 +747,30 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
     sincospif((float)(e & (C::kFftN - 1)) * (2.0f / (float)C::kFftN), &sn, &cs);
     return make_float2(cs, -sn);
   };
+  if constexpr (C::kClassicFft) {
+    for (int e = tid; e < 15 * 128; e += kThreads) {       // T1[k1-1][l][b] = W_NF^((2l+b) k1)
+      const int k1 = e / 128 + 1, lb = e % 128;
+      reinterpret_cast<float2*>(t1c)[e] = w_nf(lb * k1);
+    }
+    for (int e = tid; e < 15 * 8; e += kThreads) {         // T2[k2-1][n3] = W_128^(n3 k2) = W_NF^(16 n3 k2)
+      const int k2 = e / 8 + 1, n3 = e % 8;
+      reinterpret_cast<float2*>(t2c)[e] = w_nf(n3 * k2 * (C::kFftN / 128));
+    }
+  }
   // pass 2 (16 points over n2, slot k1' = 8 g + kk holding frame-local k1 = k1' mod R): factor i of
   // stage s (L = 2^(s+1), d = 16 / L):  (W_(NF/8)^k1)^d W_L^k  =  W_NF^(8 k1 d + k NF / L)
-  for (int e = tid; e < 8 * C::kPhases * 15; e += kThreads) {
+  for (int e = tid; !C::kClassicFft && e < 8 * C::kPhases * 15; e += kThreads) {
     const int slot = e / 15, i = e % 15;
-    const int k1 = slot % R;
+    const int k1 = C::kPhases == 2 ? 2 * (slot & 7) + (slot >> 3) : slot % R;   // two phases: by parity of k1
     const int sidx = i < 1 ? 0 : i < 3 ? 1 : i < 7 ? 2 : 3;
     const int k = i - ((1 << sidx) - 1), Lp = 2 << sidx, d = 16 / Lp;
     reinterpret_cast<float2*>(t2)[e] = w_nf(8 * k1 * d + k * (C::kFftN / Lp));
   }
   // pass 3 (8 points over n3; lane = (kk, k2 low), combination c = 2 g + j: k2 = (lane & 7) + 8 j):
   // (W_NF^(R k2 + k1))^d W_L^k = W_NF^((R k2 + k1) d + k NF / L), L = 2^(s+1), d = 8 / L
-  for (int e = tid; e < C::kPhases * 2 * 7 * 64; e += kThreads) {
+  for (int e = tid; !C::kClassicFft && e < C::kPhases * 2 * 7 * 64; e += kThreads) {
     const int ln = e & 63, i = (e >> 6) % 7, c = e / (7 * 64);
-    const int k1 = (8 * (c >> 1) + (ln >> 3)) % R, k2 = (ln & 7) + 8 * (c & 1);
+    const int k1 = C::kPhases == 2 ? 2 * (ln >> 3) + (c >> 1) : (ln >> 3) % R, k2 = (ln & 7) + 8 * (c & 1);
     const int sidx = i < 1 ? 0 : i < 3 ? 1 : 2;
     const int k = i - ((1 << sidx) - 1), Lp = 2 << sidx, d = 8 / Lp;
     reinterpret_cast<float2*>(t3)[e] = w_nf((R * k2 + k1) * d + k * (C::kFftN / Lp));
@@ -660,6 +794,8 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
   // lane-constant LDS byte addresses
   const int kkL = lane >> 3, n3L = lane & 7;
   LaneAddr la;
+  la.t1c = t1c + lane * 16;
+  la.t2c = t2c + n3L * 8;
   la.tw2 = t2 + kkL * kTw2Stride;
   la.tw3 = t3 + lane * 8;
   la.ex1_w = ex + lane * 8;
@@ -941,9 +1077,15 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, Cfg<N>::kWavesPerWG / 4) void amc
             di[lo + 1] = __builtin_fmaf(d1r, w4.w, d1i * w4.z);
             if constexpr (C::kSplit2 && i % 4 == 3) __builtin_amdgcn_sched_barrier(0);   // 16 loads in flight, not 64
           });
-          float pk4 = fft_peak<R>(sr, si, la);
-          __builtin_amdgcn_sched_barrier(0);
-          return __builtin_fmaxf(pk4, fft_peak<R>(dr, di, la));
+          if constexpr (C::kClassicFft) {
+            float pk4 = fft_peak_classic<R>(sr, si, la);
+            __builtin_amdgcn_sched_barrier(0);
+            return __builtin_fmaxf(pk4, fft_peak_classic<R>(dr, di, la));
+          } else {
+            float pk4 = fft_peak<R>(sr, si, la);
+            __builtin_amdgcn_sched_barrier(0);
+            return __builtin_fmaxf(pk4, fft_peak<R>(dr, di, la));
+          }
         };
         if constexpr (!C::kSplit2) {
           peak = fft4096([&](auto ic) {

@@ -32,11 +32,11 @@
  *     which evaluates in complex128 (features.py:46-58) -- including the inf / 0 its
  *     float32 store produces for |x|^6 beyond float32 (feature_extraction.py:35,56).
  *     Such frames run at the block kernel's rate (~1/10 of the fast path).
- *   - AMCX_VARIANT_WAVE / AUTO on a power-of-two frame size is TWO launches on the stream:
+ *   - AMCX_VARIANT_WAVE / AUTO on a power-of-two frame size is THREE launches on the stream:
  *     the throughput kernel marks the frames it cannot finish exactly in band -- feature 5
  *     (a standard deviation, >= 0 or NaN) stored negative: finite = a phase step within an
- *     fp32 ulp of +-pi, -inf = outside the fp32 range -- and amcx_fixup_kernel rewrites
- *     them.  A consumer on ANOTHER stream that reads `out_dev` between the two launches
+ *     fp32 ulp of +-pi, -inf = outside the fp32 range -- and amcx_fixup_kernel /
+ *     amcx_range_fixup_kernel rewrite them.  A consumer on ANOTHER stream that reads `out_dev` between the launches
  *     sees those marks; order it after the whole call (event / stream sync), as usual.
  *   - re-entrant and thread-safe; launches are asynchronous on `hip_stream`
  *     (a hipStream_t, NULL = default stream); completion = caller's stream sync.

@@ -7,7 +7,7 @@ TAG=${1:-r1}; shift
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-BENCH="python3 bench.py --no-cpu-baseline --steps 20 --warmup 5 $@"
+BENCH="python3 bench.py --no-cpu-baseline --no-h2d --steps 20 --warmup 5 $@"
 set -x
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/bench_trace.json 2> $OUT/trace.err || exit 1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > /dev/null 2> $OUT/pmc_fetch.err || exit 1
@@ -17,6 +17,9 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFL
 set +x
 python3 tools/prof_summary.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
-# keep only the small CSVs (stats + per-dispatch rows of our kernels)
+# keep only the condensed results: summary.txt / pmc_traffic.json / the --stats table (gpurun merges <= 64 MiB back)
 find $OUT -name "*.db" -delete
+find $OUT -name "*counter_collection.csv" -delete
+find $OUT -name "*kernel_trace.csv" -delete
+find $OUT -name "*agent_info.csv" -delete
 du -sh $OUT

@@ -7,7 +7,7 @@
 // one half of the frame's work removed (where do cycles and clock go?).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-math-errno -fno-slp-vectorize \
 //         [-DAMCX_ABL_NOFFT | -DAMCX_ABL_NOSTATS] tools/wave_clock.hip -o tools/wave_clock
-//   tools/wave_clock [frame_size=2048] [valu_instr_per_frame=0]
+//   tools/wave_clock [frame_size=2048] [valu_instr_per_frame=0] [only_config=-1] [seconds=2.5]
 #define AMCX_WAVE_STAMPS 2
 #include "../amcpy_amd/csrc/amcx_wave_kernel.h"
 #include <stdio.h>
@@ -72,6 +72,9 @@ void run(const char* label, const float2* d_iq, long long F, float* d_out, unsig
   fflush(stdout);
 }
 
+static int g_only = -1;        // run only this configuration (index below), all if < 0
+static double g_seconds = 2.5;
+
 template <int N>
 void all(long long F) {
   const size_t n_samp = (size_t)F * N;
@@ -87,21 +90,26 @@ void all(long long F) {
       CHECK(hipMemcpy(d_iq + o, h.data(), std::min(tile, n_samp - o) * 8, hipMemcpyHostToDevice));
   }
   CHECK(hipMemset(d_zero, 0, n_samp * 8));
-  run<N>("random, all CUs", d_iq, F, d_out, d_st, 256, 2.5);
-  run<N>("zeros,  all CUs", d_zero, F, d_out, d_st, 256, 2.5);
-  run<N>("random, all CUs (again)", d_iq, F, d_out, d_st, 256, 2.5);
-  // row stride 0: every frame is frame 0 (L1/L2-resident) -> what the HBM latency at the head of a frame costs
-  run<N>("random, frame 0 only (L2)", d_iq, F, d_out, d_st, 256, 2.5, 0);
-  run<N>("random, 224 workgroups", d_iq, F, d_out, d_st, 224, 2.5);
-  run<N>("random, 192 workgroups", d_iq, F, d_out, d_st, 192, 2.5);
-  run<N>("random, 128 workgroups", d_iq, F, d_out, d_st, 128, 2.5);
-  run<N>("random, 64 workgroups", d_iq, F, d_out, d_st, 64, 2.5);
+  const double T = g_seconds;
+  auto want = [](int k) { return g_only < 0 || g_only == k; };
+  if (want(0)) run<N>("random, all CUs", d_iq, F, d_out, d_st, 256, T);
+  if (want(1)) run<N>("zeros,  all CUs", d_zero, F, d_out, d_st, 256, T);
+  if (want(2)) run<N>("random, all CUs (again)", d_iq, F, d_out, d_st, 256, T);
+  // row stride 0: every frame is frame 0 (L1/L2-resident): the same arithmetic on the same random bits
+  // with nothing streamed from HBM
+  if (want(3)) run<N>("random, frame 0 only (L2)", d_iq, F, d_out, d_st, 256, T, 0);
+  if (want(4)) run<N>("random, 224 workgroups", d_iq, F, d_out, d_st, 224, T);
+  if (want(5)) run<N>("random, 192 workgroups", d_iq, F, d_out, d_st, 192, T);
+  if (want(6)) run<N>("random, 128 workgroups", d_iq, F, d_out, d_st, 128, T);
+  if (want(7)) run<N>("random, 64 workgroups", d_iq, F, d_out, d_st, 64, T);
   CHECK(hipFree(d_iq)); CHECK(hipFree(d_zero)); CHECK(hipFree(d_out)); CHECK(hipFree(d_st));
 }
 
 int main(int argc, char** argv) {
   const int N = argc > 1 ? atoi(argv[1]) : 2048;
   g_valu_per_frame = argc > 2 ? atof(argv[2]) : 0;
+  g_only = argc > 3 ? atoi(argv[3]) : -1;
+  g_seconds = argc > 4 ? atof(argv[4]) : 2.5;
 #if defined(AMCX_ABL_NOFFT)
   printf("# build: FFT removed (AMCX_ABL_NOFFT)\n");
 #elif defined(AMCX_ABL_NOSTATS)
@@ -114,6 +122,7 @@ int main(int argc, char** argv) {
     case 1024: all<1024>(F); break;
     case 2048: all<2048>(F); break;
     case 4096: all<4096>(F); break;
+    case 8192: all<8192>(F); break;
     default: printf("frame size 1024, 2048 or 4096\n"); return 2;
   }
   return 0;

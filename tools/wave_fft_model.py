@@ -163,17 +163,20 @@ def model_fused(x, R1):
             y1[:, k1, b] = sum(reg[:, i, b] * W(R1, i * k1) for i in range(R1))
     z = np.zeros((L, PH, 16), complex)
     n2w, qw = lane >> 2, lane & 3
+    # two phases (R = 16): phase g carries the k1 of parity g, k1 = 2 kk + g -- after the first
+    # decimation-in-frequency stage of pass 1 those are the two independent halves of the registers
+    k1_of = (lambda g, kk: 2 * kk + g) if PH == 2 else (lambda g, kk: kk)
     for g in range(PH):
         lds = np.full(1088, 0j, complex)
         for kk in range(min(8, R1)):
             for b in range(2):
-                lds[ex1_addr(kk, n2w, 2 * qw + b)] = y1[:, 8 * g + kk, b]
+                lds[ex1_addr(kk, n2w, 2 * qw + b)] = y1[:, k1_of(g, kk), b]
         for n2 in range(16):
             z[:, g, n2] = lds[ex1_addr(lane >> 3, n2, lane & 7)]
-    # pass 2: twist w = W_(N/8)^k1, k1 = 8g + (lane>>3): the table depends on k1 only (16 x 15 entries)
+    # pass 2: twist w = W_(N/8)^k1: the table depends on the k1 slot only (8 PH x 15 entries)
     y2 = np.zeros((L, PH, 16), complex)  # position p holds k2 = bitrev(p)
     for g in range(PH):
-        k1 = 8 * g + (lane >> 3)
+        k1 = k1_of(g, lane >> 3)
         w = W(N // 8, 1) ** k1
         y2[:, g, :] = twisted_dit(z[:, g, :].T, dit_twiddles(w, 16)).T
     u = np.zeros((L, PH, 2, 8), complex)
@@ -188,7 +191,7 @@ def model_fused(x, R1):
     X = np.zeros(N, complex)
     for g in range(PH):
         for j in range(2):
-            k1 = 8 * g + (lane >> 3)
+            k1 = k1_of(g, lane >> 3)
             k2 = (lane & 7) + 8 * j
             w3 = W(N, 1) ** (R1 * k2 + k1)
             out = twisted_dit(u[:, g, j, :].T, dit_twiddles(w3, 8))

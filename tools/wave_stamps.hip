@@ -26,7 +26,12 @@ template <int N> void run(const float2* d_iq, long long F, float* d_out, unsigne
   CHECK(hipMemcpy(h.data(), d_st, h.size() * 8, hipMemcpyDeviceToHost));
   double s[kStampSections] = {0};
   for (int w = 0; w < nw; ++w) for (int k = 0; k < kStampSections; ++k) s[k] += (double)h[w * kStampSections + k];
-  const char* names[kStampSections] = {"load+stats sweep", "envelope sweep", "fft pass1+xchg1", "fft pass2/3+xchg2", "reduce(last of batch)", "finalize(batch)", "-", "reduce+stash+loop"};
+  // stamp k closes the interval that ENDS at AMCX_STAMP(k) in amcx_wave_kernel.h: 7 = top of a frame (so it holds the
+  // previous frame's FFT and the loop / load issue), 0 = end of the statistics sweep (incl. the wait for the frame's loads),
+  // 3 = end of the envelope sweep, 1 = end of the wave reduction, 4 = after the batch's last frame (its FFT), 5 = finalisation
+  const char* names[kStampSections] = {"load wait + statistics sweep", "wave reduction of the sums", "-", "envelope second sweep",
+                                       "FFT of the batch's last frame", "fp64 finalisation + store", "-",
+                                       "FFT of the other frames + loop + load issue"};
   double real_us = s[6] / nw / 100.0; s[6] = 0;
   { double mn = 1e30, mx = 0; for (int w = 0; w < nw; ++w) { double v = (double)h[w * kStampSections + 6] / 100.0; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
     printf("   wave lifetime us: min %.1f  mean %.1f  max %.1f   (kernel %.1f)\n", mn, real_us, mx, ms * 1e3);
@@ -38,7 +43,7 @@ template <int N> void run(const float2* d_iq, long long F, float* d_out, unsigne
   double tot = 0; for (double v : s) tot += v;
   double frames_per_wave = (double)F / nw;
   printf("N=%d  kernel %.3f ms  (%.1f M frames/s)  mean wave lifetime %.1f us -> s_memtime clock %.2f GHz; cycles per frame per wave: %.0f\n", N, ms, F / ms / 1e3, real_us, tot / nw / real_us / 1e3, tot / nw / frames_per_wave);
-  for (int k = 0; k < kStampSections; ++k) if (s[k] > 0) printf("   %-20s %6.1f %%   %8.0f cycles/frame\n", names[k], 100.0 * s[k] / tot, s[k] / nw / frames_per_wave);
+  for (int k = 0; k < kStampSections; ++k) if (s[k] > 0) printf("   %-44s %6.1f %%   %8.0f cycles/frame\n", names[k], 100.0 * s[k] / tot, s[k] / nw / frames_per_wave);
 }
 int main() {
   const long long F = 6 * 26 * 4096 / 2;   // 319488 frames, 5.2 GB
