@@ -89,11 +89,29 @@ def _cpu_model():
 
 
 def _host_cores():
+    """Cores this process may really use: the affinity mask, capped by a cgroup CPU quota if one is set
+    (a 1-GPU share of a large host shows all 256 cores in the mask but schedules on 16)."""
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", None)):
+        try:
+            txt = open(path).read().strip()
+            if parse is not None:
+                quota, period = parse(txt)
+                if quota != "max":
+                    cores = max(1, min(cores, int(float(quota) / float(period) + 0.5)))
+            else:
+                quota = int(txt)
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip())
+                if quota > 0:
+                    cores = max(1, min(cores, int(quota / period + 0.5)))
+            break
+        except Exception:
+            continue
     return cores
 
 
@@ -109,6 +127,15 @@ def cpu_baseline(max_procs: int | None = None, seconds: float = 10.0):
     grid = synth.snr_grid(n_snr)
     jobs = [(mod, mi, si, float(grid[si]), min(n_frames, 64), N)
             for mi, mod in enumerate(synth.MODS6[:n_mods]) for si in range(n_snr)]
+    # one core's rate, measured alone first: value / this = the cores the pool effectively had
+    import numpy as np
+    from oracle import iq_features_oracle as orc
+    solo = synth.host_block(jobs[0][0], jobs[0][3], 8, N, seed=1000).astype(np.complex128)
+    orc.calculate_features(range(1, 19), solo[0])
+    t0 = time.perf_counter()
+    for f in range(8):
+        orc.calculate_features(range(1, 19), solo[f])
+    one_core = 8 / (time.perf_counter() - t0)
     ctx = mp.get_context("fork")
     counter = ctx.Value("i", 0)
     with ctx.Pool(procs, initializer=_cpu_init, initargs=(jobs, counter)) as pool:
@@ -120,6 +147,7 @@ def cpu_baseline(max_procs: int | None = None, seconds: float = 10.0):
     value = frames / wall
     return {
         "value": value, "unit": "frames/s", "cores": procs, "kind": "port", "cpu_model": _cpu_model(),
+        "one_core_frames_per_s": one_core, "effective_cores": value / one_core,
         "sample": f"{procs} worker processes, each cycling over 64 frames of one (modulation, SNR) block of the "
                   f"BASELINE configs[0] shape ({n_mods} mods x {n_snr} SNR x {n_frames} x {N}, complex128 input, "
                   f"oracle.calculate_features per frame) for {wall:.1f} s after pool warm-up: {frames} frames",

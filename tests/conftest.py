@@ -20,12 +20,13 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session", autouse=True)
 def _library_is_built():
-    """A fresh checkout has no libamcx.so (build artefacts stay out of git): build it once,
-    as __graft_entry__.build() does.  Nothing here substitutes for it -- without hipcc the
+    """A fresh checkout has no libamcx.so (build artefacts stay out of git), and an edited kernel
+    must not be tested through a stale library: (re)build when any source is newer, as
+    __graft_entry__.build() does.  Nothing here substitutes for it -- without hipcc the
     tests that need the library fail with the loader's ImportError."""
     from amcpy_amd.csrc import build as b
-    if not b.LIB.exists() and Path(b.HIPCC).exists():
-        b.build(verbose=False)
+    if Path(b.HIPCC).exists():
+        b.build(force=False, verbose=False)     # no-op unless a source is newer than the library (build.stale)
 
 
 @pytest.fixture(scope="session")
