@@ -818,7 +818,18 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, (Cfg<N>::kWavesPerWG + 3) / 4) vo
       if (lane == 0) got = __hip_atomic_fetch_add(&counters[0], (unsigned)kFramesPerWave, __ATOMIC_RELAXED,
                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
       got = __builtin_amdgcn_readfirstlane(got);
+#ifdef AMCX_EXP_INTERLEAVE   // experiment (tools/wave_clock.hip): chunks dealt round-robin over the workgroups, so that
+      {                       // all waves of the chip read inside one moving window of HBM instead of 256 distant slices
+        const long long chunk = (long long)(got / kFramesPerWave) * gridDim.x + blockIdx.x;
+        f0 = chunk * kFramesPerWave;
+        if (f0 >= n_frames) break;
+        const long long left = n_frames - f0;
+        n_here = left < kFramesPerWave ? (int)left : kFramesPerWave;
+      }
+      if (false) {
+#else
       if ((long long)got < body_len) {
+#endif
         f0 = slice0 + got;
         const long long left = body_len - got;
         n_here = left < kFramesPerWave ? (int)left : kFramesPerWave;
@@ -838,6 +849,23 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, (Cfg<N>::kWavesPerWG + 3) / 4) vo
     // byte is read once -> non-temporal
     auto load_frame = [&](float (&xr)[2 * ROWS], float (&xi)[2 * ROWS], long long f) {
       const float2* src = iq + f * row_stride + 2 * lane;
+#ifdef AMCX_EXP_LOAD_POLICY   // experiment (tools/wave_clock.hip): another cache policy on the frame loads, e.g. "sc0 sc1"
+      if constexpr (ROWS == 16) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        v4f v[ROWS];
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i)
+          asm volatile("global_load_dwordx4 %0, %1, off " AMCX_EXP_LOAD_POLICY : "=v"(v[i]) : "v"(src + 128 * i));
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                       "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) {
+          xr[2 * i] = v[i].x; xi[2 * i] = v[i].y; xr[2 * i + 1] = v[i].z; xi[2 * i + 1] = v[i].w;
+        }
+        return;
+      }
+#endif
       static_for<ROWS>([&](auto ii) {
         constexpr int i = decltype(ii)::value;
         typedef float v4f __attribute__((ext_vector_type(4)));

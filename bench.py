@@ -127,19 +127,12 @@ def cpu_baseline(max_procs: int | None = None, seconds: float = 10.0):
     grid = synth.snr_grid(n_snr)
     jobs = [(mod, mi, si, float(grid[si]), min(n_frames, 64), N)
             for mi, mod in enumerate(synth.MODS6[:n_mods]) for si in range(n_snr)]
-    # one core's rate, measured alone first: value / this = the cores the pool effectively had
-    import numpy as np
-    from oracle import iq_features_oracle as orc
-    solo = synth.host_block(jobs[0][0], jobs[0][3], 8, N, seed=1000).astype(np.complex128)
-    orc.calculate_features(range(1, 19), solo[0])
-    t0 = time.perf_counter()
-    for f in range(8):
-        orc.calculate_features(range(1, 19), solo[f])
-    one_core = 8 / (time.perf_counter() - t0)
     ctx = mp.get_context("fork")
     counter = ctx.Value("i", 0)
     with ctx.Pool(procs, initializer=_cpu_init, initargs=(jobs, counter)) as pool:
         pool.map(_cpu_spin, [0.05] * procs, chunksize=1)           # every worker up and warm
+        solo = pool.map(_cpu_spin, [1.5], chunksize=1)[0]          # ONE worker busy: a core's own rate
+        one_core = solo[0] / solo[1]                               # (value / this = the cores the pool effectively had)
         t0 = time.perf_counter()
         res = pool.map(_cpu_spin, [seconds] * procs, chunksize=1)
         wall = time.perf_counter() - t0
