@@ -826,7 +826,8 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, (Cfg<N>::kWavesPerWG + 3) / 4) vo
         const long long left = n_frames - f0;
         n_here = left < kFramesPerWave ? (int)left : kFramesPerWave;
       }
-      if (false) {
+      if (true) {
+      } else if (false) {
 #else
       if ((long long)got < body_len) {
 #endif
