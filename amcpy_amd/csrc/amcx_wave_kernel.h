@@ -1,15 +1,16 @@
 // AMCX_VARIANT_WAVE: one wavefront (64 lanes) per frame, frame held in registers.
 // Instantiated for the power-of-two frame sizes 128 ... 8192.
 //
-// Why not "one 256-thread workgroup per frame": this path is VALU/power-bound, not
-// HBM-bound (~107 fp32 VALU ops per sample), so the design
-// minimises instructions per sample:
+// Why not "one 256-thread workgroup per frame": this path is bound by the board's power cap
+// and by VALU issue, not by HBM (~105 fp32 VALU instructions per sample; DESIGN.md section
+// 4.3), so the design minimises instructions per sample:
 //   * 16-64 samples per lane amortise every cross-lane reduction over 4-8x more
 //     work than a 256-thread block would (8 samples per lane at N = 2048);
 //   * waves never synchronise with each other: no s_barrier in the frame loop,
 //     the LDS exchange buffer is private to the wave;
-//   * the FFT is three register passes (radix 16/8, 16, 8 with compile-time
-//     twiddles) joined by two conflict-free LDS transposes, instead of log2(N)
+//   * the FFT is three register passes (16 or 8 points over the rows with compile-time
+//     twiddles, then 16 and 8 points whose butterflies carry the inter-pass twiddles: 6 FMAs
+//     each, twisted_dit) joined by two conflict-free LDS transposes, instead of log2(N)
 //     shared-memory radix-2 stages (176 B/sample of LDS traffic -> 32 B);
 //   * centred statistics are one-pass shifted sums (shift = mean of the first
 //     64 samples' value); the envelope alone needs a second sweep over |x|,
@@ -21,13 +22,15 @@
 // tools/wave_fft_model.py).  A frame is ROWS = N/128 rows of 128 samples:
 //   load     lane l, row i, b in {0,1}  <- x[128 i + 2 l + b]   (global_load_dwordx4, coalesced)
 // Register FFT of NF = 128 R points (R = 16 -> 2048, 8 -> 1024, 4 -> 512, 2 -> 256, 1 -> 128), NF = R * 16 * 8:
-//   pass 1   R-point DFT over i   -> k1 ; twiddle W_NF^((2l+b) k1)
-//   xchg 1   phases g = k1>>3:  LDS[kk*136 + b*68 + l] (kk = k1&7); reader lane l'
-//            (kk = l'>>3, n3 = l'&7) takes n2 = 0..15 at [kk*136 + (n3&1)*68 + 4 n2 + (n3>>1)];
-//            for R < 8 the eight kk slots are filled by 8/R consecutive frames (slot j R + k1)
-//   pass 2   16-point DFT over n2 -> k2 ; twiddle W_128^(n3 k2)
+//   pass 1   R-point DFT over i   -> k1   (no twiddle here: W_NF^((8 n2 + n3) k1) rides passes 2 and 3)
+//   xchg 1   phases g (R = 16: k1 = 2 kk + g, the two independent halves of pass 1's output; R <= 8: one phase,
+//            k1 = kk):  LDS[kk*136 + b*68 + l]; reader lane l' (kk = l'>>3, n3 = l'&7) takes n2 = 0..15 at
+//            [kk*136 + (n3&1)*68 + 4 n2 + (n3>>1)]; for R < 8 the eight kk slots are filled by 8/R consecutive
+//            frames (slot j R + k1)
+//   pass 2   16-point DFT over n2 of z[n2] (W_(NF/8)^k1)^n2 -> k2   (twisted decimation in time, factors T2[slot][15])
 //   xchg 2   LDS[k2*65 + 8 kk + n3]; reader lane l'' (kk = l''>>3, k2 = (l''&7) + 8 j)
-//   pass 3   8-point DFT over n3  -> X[k1 + R k2 + 16 R k3]; only max |X|^2 is kept
+//   pass 3   8-point DFT over n3 of u[n3] (W_NF^(R k2 + k1))^n3 -> X[k1 + R k2 + 16 R k3]   (factors T3[g][j][7][lane]);
+//            only max |X|^2 is kept
 // N = 4096 is one radix-2 decimation-in-frequency split in front of that machine:
 //   X[2k]   = FFT_2048(x[n] + x[n+2048]),  X[2k+1] = FFT_2048((x[n] - x[n+2048]) W_4096^n).
 // The whole 32 KiB frame sits in 128 VGPRs, so that variant runs 2 waves per SIMD
@@ -46,10 +49,12 @@
 //
 // 768-thread workgroups (N <= 2048): 12 waves = exactly 3 per SIMD, one workgroup per CU;
 // LDS, not registers, sets that number (125 VGPRs at N = 2048 since the sums are reduced
-// before the FFT; 16 waves measured no faster, the board is at its power cap).
+// before the FFT).  16 waves fit with the exchange buffer at its exact 8672 bytes and batches of
+// four frames (-DAMCX_EXP_WAVES16): 5.6 % fewer cycles per frame, +1 % frames/s -- the board is at
+// its power cap and the clock gives the difference back.
 // (Two 6-wave workgroups did NOT co-reside at the 160 VGPRs of round 1a: their waves
 // landed 2,2,1,1 on the SIMDs, profiles/r1a.)  LDS per workgroup at N = 2048:
-// twiddles 15 KiB + 960 B, 12 x 8704 B exchange, 12 x 1056 B stash = 133.4 KB.
+// factor tables 1920 + 14336 B, 12 x 8672 B exchange, 12 x 1056 B stash = 133.3 KB.
 // Algorithmic HBM bytes per frame: 8*N read + 72 written.
 #pragma once
 
