@@ -1,0 +1,68 @@
+/* Plain-C client of include/amcx.h: what a non-Python caller of the boundary looks like.
+ *   gcc -std=c99 -Iinclude tests/c_abi/abi_check.c -Lamcpy_amd/lib -lamcx -Wl,-rpath,$PWD/amcpy_amd/lib -lm -o abi_check
+ *   ./abi_check            argument / error-code checks only: needs no GPU
+ *   ./abi_check compute N FILE   18 features of the N-sample complex64 frame in FILE (raw interleaved float32)
+ *                          through the host-buffer entry and through a reusable context (the two must agree
+ *                          bit for bit); prints them, one per line
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "amcx.h"
+
+#define CHECK(cond)                                                        \
+  do {                                                                     \
+    if (!(cond)) { fprintf(stderr, "abi_check: %s failed (line %d)\n", #cond, __LINE__); return 1; } \
+  } while (0)
+
+int main(int argc, char** argv) {
+  CHECK(amcx_abi_version() == AMCX_ABI_VERSION);
+  CHECK(strcmp(amcx_strerror(AMCX_OK), "ok") == 0);
+  CHECK(amcx_strerror(-99) != NULL && amcx_last_hip_error() != NULL);
+  /* validation happens before any device is touched */
+  CHECK(amcx_features18_c64(NULL, -1, 2048, 2048, NULL, 18, NULL) == AMCX_EINVAL);
+  CHECK(amcx_features18_c64(NULL, 4, 2048, 100, NULL, 18, NULL) == AMCX_EINVAL);
+  CHECK(amcx_features18_c64(NULL, 4, 2048, 2048, NULL, 17, NULL) == AMCX_EINVAL);
+  CHECK(amcx_features18_c64(NULL, 0, 2048, 2048, NULL, 18, NULL) == AMCX_OK);
+  CHECK(amcx_features18_c64_ex(NULL, 0, 1000, 1000, NULL, 18, NULL, AMCX_VARIANT_WAVE) == AMCX_ENOTSUP);
+  CHECK(amcx_features18_c64_host(NULL, 3, 2048, 2048, NULL, 18, 0, AMCX_VARIANT_AUTO) == AMCX_EINVAL);
+  CHECK(amcx_ctx_create(0, NULL) == AMCX_EINVAL);
+  CHECK(amcx_ctx_destroy(NULL) == AMCX_OK);
+  char name[96];
+  CHECK(amcx_kernel_name(2048, AMCX_VARIANT_AUTO, name, (int32_t)sizeof name) == AMCX_OK);
+  CHECK(strstr(name, "wave_kernel<2048>") != NULL);
+  CHECK(amcx_kernel_name(1000, AMCX_VARIANT_AUTO, name, (int32_t)sizeof name) == AMCX_OK);
+  CHECK(strstr(name, "block_kernel") != NULL);
+  if (argc < 4 || strcmp(argv[1], "compute") != 0) {
+    /* without a GPU the host-buffer entries must refuse, not compute */
+    if (amcx_device_count() <= 0) {
+      float x[2 * 64] = {1.0f}, out[18];
+      amcx_ctx* c = NULL;
+      CHECK(amcx_features18_c64_host(x, 1, 64, 64, out, 18, 0, AMCX_VARIANT_AUTO) == AMCX_ENODEV);
+      CHECK(amcx_ctx_create(0, &c) == AMCX_ENODEV && c == NULL);
+    }
+    printf("abi_check ok\n");
+    return 0;
+  }
+  const int n = atoi(argv[2]);
+  CHECK(n >= AMCX_MIN_FRAME_SIZE && n <= AMCX_MAX_FRAME_SIZE);
+  float* x = (float*)malloc(sizeof(float) * 2 * (size_t)n);
+  CHECK(x != NULL);
+  FILE* fh = fopen(argv[3], "rb");
+  CHECK(fh != NULL);
+  CHECK(fread(x, sizeof(float) * 2, (size_t)n, fh) == (size_t)n);
+  fclose(fh);
+  float once[18], looped[18];
+  int rc = amcx_features18_c64_host(x, 1, n, n, once, 18, 0, AMCX_VARIANT_AUTO);
+  if (rc != AMCX_OK) { fprintf(stderr, "amcx_features18_c64_host: %s %s\n", amcx_strerror(rc), amcx_last_hip_error()); return 2; }
+  amcx_ctx* ctx = NULL;
+  CHECK(amcx_ctx_create(0, &ctx) == AMCX_OK && ctx != NULL);
+  for (int rep = 0; rep < 3; ++rep)
+    CHECK(amcx_ctx_features18_c64_host(ctx, x, 1, n, n, looped, 18, AMCX_VARIANT_AUTO) == AMCX_OK);
+  CHECK(amcx_ctx_destroy(ctx) == AMCX_OK);
+  CHECK(memcmp(once, looped, sizeof once) == 0);
+  for (int j = 0; j < 18; ++j) printf("%.9g\n", once[j]);
+  free(x);
+  return 0;
+}

@@ -798,3 +798,53 @@ def test_calculate_features_in_a_loop_reuses_its_context():
     # complex128 frames take the double entry of the same context
     row = calculate_features([6, 11], x[0].astype(np.complex128) * (1 + 1e-9))
     assert np.allclose(row, [batch[0][5], batch[0][10]], rtol=1e-6)
+
+
+def test_scale_sweep_wave_equals_block_across_the_range_threshold():
+    """The same frames at scales 1e-9 ... 1e9 (powers of ten, so not exact in binary): every
+    feature follows its scaling law, and the wave variant -- fp32 sums inside 1e-10 <= mean|x|^2
+    <= 1e10, the fp64-sum fix-up outside -- agrees with the block variant on both sides of the
+    two thresholds (1e-5 and 1e5 in amplitude) and right at them."""
+    from amcpy_amd import synth
+    base = np.concatenate([synth.host_block(m, 6.0, 2, 2048, seed=321 + i) for i, m in enumerate(synth.MODS6)])
+    order = np.array([2, 0, 0, 0, 0, 1, 0.5, 0, 0, 2, 2, 4, 4, 4, 6, 6, 6, 6])      # feature j scales as s**order[j]
+    ref = _run(base.astype(np.complex64), "block").astype(np.float64)
+    S = orc.conditioning_scales(base.astype(np.complex128))
+    for k in range(-9, 10):
+        s = 10.0 ** k
+        x = (base.astype(np.complex128) * s).astype(np.complex64)
+        wave = _run(x, "wave").astype(np.float64)
+        block = _run(x, "block").astype(np.float64)
+        with np.errstate(all="ignore"):
+            law = s ** order
+            want = (ref * law).astype(np.float32).astype(np.float64)          # incl. float32 overflow / underflow
+            tol = 3e-5 * np.maximum(np.abs(ref), S) * law + 1.5e-45
+        for name, got in (("wave", wave), ("block", block)):
+            fin = np.isfinite(want) & (np.abs(want) > 1e-37)
+            assert np.array_equal(np.isinf(got), np.isinf(want)), (name, k)
+            with np.errstate(invalid="ignore"):
+                bad = np.argwhere(fin & (np.abs(got - want) > tol))
+            assert bad.size == 0, (name, k, bad[:4], got[tuple(bad[0])], want[tuple(bad[0])])
+        both = np.isfinite(wave) & np.isfinite(block)
+        assert np.all(np.abs(wave[both] - block[both]) <= tol[both]), k
+
+
+def test_plain_c_client_computes_the_same_features(tmp_path):
+    """tests/c_abi/abi_check.c through the host-buffer entry and through a reusable context
+    (bit-identical to each other, checked in C) equals the Python binding's result for the same
+    frame -- the boundary needs neither Python nor torch."""
+    import subprocess
+    from amcpy_amd.features import features18_host
+    from tests.test_host_cpu import _build_abi_check
+    exe = _build_abi_check(tmp_path)
+    for n in (2048, 1000):
+        k = np.arange(n, dtype=np.float64)
+        ph, a = 0.37 * k + 0.0009 * k * k, 1.0 + 0.25 * np.sin(0.05 * k)       # a chirp with amplitude ripple
+        x = ((a * np.cos(ph)).astype(np.float32) + 1j * (a * np.sin(ph)).astype(np.float32)).astype(np.complex64)
+        path = tmp_path / f"frame_{n}.c64"
+        x.tofile(path)
+        r = subprocess.run([str(exe), "compute", str(n), str(path)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        got = np.array([float(v) for v in r.stdout.split()], dtype=np.float32)     # %.9g round-trips a float32
+        want = features18_host(x[None, :])[0]
+        assert got.shape == (18,) and np.array_equal(got, want), (n, got, want)

@@ -368,3 +368,22 @@ def test_two_rank_run_extraction_rank0_decodes_and_publishes(tmp_path):
         b = scipy.io.loadmat(str(cfg.paths.calculated_features / f"{m}_features.mat"))
         key = cfg.signals.mat_info[m]
         assert b[key].shape == (3, 7, 18) and np.array_equal(a[key], b[key])
+
+
+def _build_abi_check(tmp_path):
+    exe = tmp_path / "abi_check"
+    lib_dir = REPO / "amcpy_amd" / "lib"
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", f"-I{REPO / 'include'}", str(REPO / "tests" / "c_abi" / "abi_check.c"),
+           f"-L{lib_dir}", "-lamcx", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib", "-lm", "-o", str(exe)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_plain_c_client_of_the_abi(tmp_path):
+    """include/amcx.h is a C header: a C99 client compiles against it with -Wall -Werror, links
+    libamcx.so and gets the documented error codes -- and, without a GPU, ENODEV from the
+    host-buffer entries instead of a CPU computation."""
+    exe = _build_abi_check(tmp_path)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "abi_check ok" in r.stdout, r.stdout + r.stderr
