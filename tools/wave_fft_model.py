@@ -21,7 +21,7 @@ def conflict_free_read(addrs):
 
 def ex1_addr(kk, n2, n3):
     """exchange 1, one phase (k1 = 8g+kk): complex-unit address; padded layout
-    [kk: stride 136][b = n3&1: stride 68][writer lane = 4*n2 + (n3>>1)]  (8704 B)"""
+    [kk: stride 136][b = n3&1: stride 68][writer lane = 4*n2 + (n3>>1)]  (8672 B used)"""
     return kk * 136 + (n3 & 1) * 68 + n2 * 4 + (n3 >> 1)
 
 def ex2_addr(kk, k2, n3):
