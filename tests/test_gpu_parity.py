@@ -848,3 +848,33 @@ def test_plain_c_client_computes_the_same_features(tmp_path):
         got = np.array([float(v) for v in r.stdout.split()], dtype=np.float32)     # %.9g round-trips a float32
         want = features18_host(x[None, :])[0]
         assert got.shape == (18,) and np.array_equal(got, want), (n, got, want)
+
+
+def test_upload_pipeline_many_chunks_equals_one_launch():
+    """HipEngine with chunks far smaller than the data (dozens of trips round its two pinned / device
+    slots, ragged last chunk), from a Fortran-ordered complex128 container with rows longer than the
+    frame, from a complex64 memmap-like array, and twice in a row (slots reused across calls): every
+    row equals the one-launch result on the same frames, bit for bit."""
+    torch = _torch()
+    from amcpy_amd.feature_extraction import FrameRows, HipEngine
+    from amcpy_amd.features import features18
+    rng = np.random.default_rng(17)
+    n_snr, n_frames, L, N = 3, 211, 300, 256
+    full = rng.standard_normal((n_snr, n_frames + 5, L)) + 1j * rng.standard_normal((n_snr, n_frames + 5, L))
+    parsed = np.asfortranarray(full)                                  # as scipy.io.loadmat returns it
+    flat = full[:, :n_frames, :N].reshape(-1, N)
+    want128 = features18(torch.from_numpy(flat).cuda().to(torch.complex64)).cpu().numpy()
+    eng = HipEngine(N, chunk_bytes=37 * N * 16, threads=4)            # 37 frames per chunk: 18 chunks, the last ragged
+    rows = FrameRows(parsed, n_snr, n_frames)
+    for _ in range(2):
+        got = eng(rows)
+        assert eng.stats["chunks"] == 18 and got.shape == (n_snr * n_frames, 18)
+        assert np.array_equal(got, want128, equal_nan=True)
+    part = eng(rows.slice(100, 433))                                  # a rank's contiguous range
+    assert np.array_equal(part, want128[100:433], equal_nan=True)
+    x64 = flat.astype(np.complex64)
+    want64 = features18(torch.from_numpy(x64).cuda()).cpu().numpy()
+    got64 = HipEngine(N, chunk_bytes=50 * N * 8)(x64)                 # complex64 goes up as it is
+    assert np.array_equal(got64, want64, equal_nan=True)
+    assert np.array_equal(want64, want128, equal_nan=True)            # GPU rounding of doubles == numpy's astype
+    assert HipEngine(N)(x64[:0]).shape == (0, 18)
