@@ -129,3 +129,33 @@ def test_extract_roundtrip_fixture_is_reference_rows():
         got = orc.features18_batch(x.reshape(-1, fs)).astype(np.float32).reshape(out.shape)
         assert np.allclose(got, out, rtol=2e-6, atol=0, equal_nan=True)
         assert str(g[f"label_{mod}"]) == mod
+
+
+def test_oracle_at_extreme_scales_matches_reference():
+    """range_n2048.npz (captured from the reference): frames at scales 1e-12 ... 1e12, a mixed-scale
+    frame and a single 5e7 spike.  Both oracle evaluators on the complex128 cast reproduce the
+    reference's float64 values (and therefore its float32-stored inf / 0 pattern)."""
+    g = load_npz("range_n2048.npz")
+    x, gold = g["iq"].astype(np.complex128), g["golden64_f64"]
+    fused = orc.features18_batch(x)
+    assert np.allclose(fused, gold, rtol=5e-9, atol=0, equal_nan=True)
+    for i in range(0, x.shape[0], 6):
+        got = np.array(orc.calculate_features(range(1, 19), x[i]))
+        assert np.array_equal(got, gold[i], equal_nan=True), i      # same numpy calls: bit for bit
+    with np.errstate(all="ignore"):
+        stored = gold.astype(np.float32)
+    assert np.array_equal(stored, g["golden64"], equal_nan=True)
+    assert np.isinf(stored).any() and (stored == 0).any()           # the fixture does exercise both ends
+
+
+def test_oracle_on_genuine_doubles_matches_reference_run():
+    """extract_roundtrip_f64.npz: what the reference's run_extraction stored (float32) for a container
+    of doubles that are not float32-representable equals the oracle on the same doubles."""
+    g = load_npz("extract_roundtrip_f64.npz")
+    fs = int(g["frame_size"])
+    for m in (str(v) for v in g["mods"]):
+        x = g[f"in_{m}"]
+        assert x.dtype == np.complex128 and not np.array_equal(x, x.astype(np.complex64))
+        got = orc.features18_batch(x[:, :, :fs].reshape(-1, fs)).astype(np.float32)
+        want = g[f"out_{m}"].reshape(-1, 18)
+        assert np.allclose(got, want, rtol=2e-6, atol=0, equal_nan=True), m
