@@ -276,6 +276,65 @@ def extract_raw_stream(path, frame_size: int, *, skip_samples: int = 0, max_fram
     return np.asarray(fn(frames), dtype=np.float32)
 
 
+class _PairRows:
+    """Frame source over a dataset of float32 (I, Q) pairs shaped (F, L, 2) that supports slicing --
+    a numpy array / memmap or an ``h5py.Dataset`` (RadioML-2018.01A's ``X``: 2 555 904 x 1024 x 2,
+    reference old/dataset.py:50-56).  The pairs are bit-identical to complex64, so a chunk is read
+    (h5py decodes it from the file) and re-viewed, never converted."""
+
+    def __init__(self, dataset, lo: int = 0, hi: Optional[int] = None):
+        shape = tuple(dataset.shape)
+        if len(shape) != 3 or shape[2] != 2:
+            raise ValueError(f"expected an (F, L, 2) dataset of (I, Q) pairs, got shape {shape}")
+        if np.dtype(dataset.dtype) != np.float32:
+            raise TypeError(f"(I, Q) pairs must be float32, got {dataset.dtype}")
+        self.ds, self.lo = dataset, lo
+        self.hi = shape[0] if hi is None else hi
+        self.dtype = np.dtype(np.complex64)
+        self.shape = (self.hi - self.lo, shape[1])
+
+    def gather(self, dst, g0, g1, n):
+        blk = np.ascontiguousarray(self.ds[self.lo + g0:self.lo + g1])          # (g, L, 2) float32
+        np.copyto(dst, blk.view(np.complex64)[..., 0][:, :n])
+
+
+def extract_iq_pairs(dataset, frame_size: Optional[int] = None, *, first_frame: int = 0,
+                     max_frames: Optional[int] = None, compute=None, device: Optional[int] = None) -> np.ndarray:
+    """Features of frames stored as float32 (I, Q) pairs, ``dataset[f, n] = (I, Q)`` -- RadioML's
+    ``(F, 1024, 2)`` layout (reference old/dataset.py:50-56, old/dataset_analysis.py:22).  ``dataset``
+    is anything sliceable with ``.shape`` and ``.dtype`` (numpy array, memmap, h5py.Dataset); frames go
+    up chunk by chunk through the pinned, overlapped path, so the set never has to fit in host memory.
+    Returns ``(n_frames, 18)`` float32."""
+    F, L = int(dataset.shape[0]), int(dataset.shape[1])
+    N = L if frame_size is None else int(frame_size)
+    if N < 2 or N > L:
+        raise ValueError(f"frame_size {N} outside 2 .. {L}")
+    lo = min(max(0, int(first_frame)), F)
+    hi = F if max_frames is None else min(F, lo + int(max_frames))
+    rows = _PairRows(dataset, lo, hi)
+    if hi <= lo:
+        return np.empty((0, 18), dtype=np.float32)
+    if compute is not None:                       # injected engine (tests): plain (F, N) arrays
+        block = np.empty((hi - lo, N), dtype=np.complex64)
+        rows.gather(block, 0, hi - lo, N)
+        return np.asarray(compute(block), dtype=np.float32)
+    return HipEngine(N, device)(rows)
+
+
+def extract_radioml_hdf5(path, *, key: str = "X", frame_size: Optional[int] = None, first_frame: int = 0,
+                         max_frames: Optional[int] = None, device: Optional[int] = None) -> np.ndarray:
+    """``extract_iq_pairs`` on dataset ``key`` of a RadioML-style HDF5 file (``GOLD_XYZ_OSC.0001_1024.hdf5``:
+    ``X`` float32 (2 555 904, 1024, 2), reference old/dataset.py:43-56).  Needs ``h5py``, which the reference
+    lists for its legacy scripts; raises ImportError with that hint where it is not installed."""
+    try:
+        import h5py
+    except ImportError as exc:                    # not a silent fallback: say what is missing
+        raise ImportError("extract_radioml_hdf5 needs h5py (pip install h5py); any sliceable (F, L, 2) float32 "
+                          "dataset can be passed to extract_iq_pairs instead") from exc
+    with h5py.File(str(path), "r") as fh:
+        return extract_iq_pairs(fh[key], frame_size, first_frame=first_frame, max_frames=max_frames, device=device)
+
+
 # ----------------------------------------------------------------------------
 # run_extraction
 # ----------------------------------------------------------------------------

@@ -878,3 +878,19 @@ def test_upload_pipeline_many_chunks_equals_one_launch():
     assert np.array_equal(got64, want64, equal_nan=True)
     assert np.array_equal(want64, want128, equal_nan=True)            # GPU rounding of doubles == numpy's astype
     assert HipEngine(N)(x64[:0]).shape == (0, 18)
+
+
+def test_iq_pair_dataset_through_the_engine():
+    """extract_iq_pairs on a RadioML-shaped (F, 1024, 2) float32 array (the configs[4] frame length): equal,
+    bit for bit, to handing the same frames over as complex64 -- and to the zero-copy device view."""
+    torch = _torch()
+    from amcpy_amd import synth
+    from amcpy_amd.feature_extraction import extract_iq_pairs
+    from amcpy_amd.features import features18, features18_iq_pairs
+    x = np.concatenate([synth.host_block(m, 2.0, 40, 1024, seed=900 + i) for i, m in enumerate(synth.MODS6)])
+    pairs = np.ascontiguousarray(np.stack([x.real, x.imag], axis=-1).astype(np.float32))     # (240, 1024, 2)
+    want = features18(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert np.array_equal(extract_iq_pairs(pairs), want)
+    assert np.array_equal(extract_iq_pairs(pairs, first_frame=17, max_frames=100), want[17:117])
+    assert np.array_equal(features18_iq_pairs(torch.from_numpy(pairs).cuda()).cpu().numpy(), want)
+    _assert_parity(want, orc.features18_batch(x), x, "RadioML-shaped (I, Q) pairs, N = 1024")

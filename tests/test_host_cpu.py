@@ -387,3 +387,50 @@ def test_plain_c_client_of_the_abi(tmp_path):
     exe = _build_abi_check(tmp_path)
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "abi_check ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_iq_pair_dataset_framing(tmp_path):
+    """extract_iq_pairs: an (F, L, 2) float32 dataset (RadioML layout, reference old/dataset.py:50-56) is
+    re-viewed as complex64 frames chunk by chunk; works on anything sliceable (here: a memmap and a
+    minimal h5py.Dataset look-alike); the engine is stubbed."""
+    from amcpy_amd.feature_extraction import extract_iq_pairs, extract_radioml_hdf5, _PairRows
+    rng = np.random.default_rng(2)
+    pairs = rng.standard_normal((50, 64, 2)).astype(np.float32)
+    want = pairs[..., 0] + 1j * pairs[..., 1]
+    path = tmp_path / "pairs.f32"
+    pairs.tofile(path)
+    mm = np.memmap(path, dtype=np.float32, mode="r", shape=(50, 64, 2))
+
+    class FakeDataset:                       # what h5py hands out: shape, dtype, __getitem__ returning ndarrays
+        shape, dtype = pairs.shape, pairs.dtype
+        reads = []
+
+        def __getitem__(self, idx):
+            self.reads.append(idx)
+            return pairs[idx]
+
+    seen = []
+
+    def compute(block):
+        seen.append(np.array(block))
+        return np.zeros((block.shape[0], 18), dtype=np.float32)
+
+    for ds in (pairs, mm, FakeDataset()):
+        seen.clear()
+        out = extract_iq_pairs(ds, 32, first_frame=5, max_frames=20, compute=compute)
+        assert out.shape == (20, 18) and out.dtype == np.float32
+        assert seen[0].dtype == np.complex64 and np.array_equal(seen[0], want[5:25, :32])
+    rows = _PairRows(FakeDataset(), 10, 40)
+    dst = np.empty((7, 64), dtype=np.complex64)
+    rows.gather(dst, 3, 10, 64)
+    assert np.array_equal(dst, want[13:20])
+    assert extract_iq_pairs(pairs, compute=compute, first_frame=60).shape == (0, 18)
+    with pytest.raises(ValueError):
+        extract_iq_pairs(pairs[..., :1], compute=compute)
+    with pytest.raises(TypeError):
+        extract_iq_pairs(pairs.astype(np.float64), compute=compute)
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError, match="h5py"):
+            extract_radioml_hdf5(tmp_path / "missing.hdf5")
