@@ -1,21 +1,24 @@
-// Two tiny launches behind the wave kernel.  The throughput kernel does its per-sample
+// The small launches behind the wave kernel.  The throughput kernel does its per-sample
 // arithmetic and its sums in fp32 and never takes a slow path itself (an in-kernel re-sweep
 // cost 60-760 spilled VGPRs, profiles/README.md); instead its finaliser FLAGS, in band, the
 // frames it cannot finish exactly -- feature 5 (a standard deviation: >= 0 or NaN) is stored
-//   negative and finite : some phase step lay within an fp32 ulp of +-pi (amcx_math.h kTieBand);
-//                         amcx_fixup_kernel recomputes f5 and f9 with the sign of every such
-//                         step decided exactly (exact_step).  Typically < 0.3 % of frames.
 //   -infinity           : the frame is outside the range in which fp32 sixth-order sums are
 //                         trustworthy (mean power outside [kRangeLoPower, kRangeHiPower], or a
 //                         sum overflowed: |x| >~ 1e5 or <~ 1e-5, a single huge sample, an
-//                         infinite sample).  amcx_range_fixup_kernel recomputes all 18 features
-//                         with the block kernel's frame routine, whose sums are fp64 -- the
-//                         reference evaluates in complex128 (features.py:46-58) and stays finite
-//                         over the whole complex64 range, overflowing only in its float32 store.
-// Each scan reads 4 bytes per frame.  They are two kernels because they want different shapes:
+//                         infinite sample).  Redone by the wave kernel's own range pass on a
+//                         power-of-two pre-scaled copy (amcx_range_wave_kernel, N = 1024, 2048, 4096)
+//                         or, at the other wave sizes, by amcx_range_fixup_kernel below with the
+//                         block kernel's fp64-sum frame routine -- the reference evaluates in
+//                         complex128 (features.py:46-58) and stays finite over the whole
+//                         complex64 range, overflowing only in its float32 store.
+//   negative and finite : some phase step lay within an fp32 ulp of +-pi (amcx_math.h kTieBand);
+//                         amcx_fixup_kernel recomputes f5 and f9 with the sign of every such
+//                         step decided exactly (exact_step).  Typically < 0.3 % of frames.  It runs
+//                         last: a range-pass frame can carry a tie flag too.
+// Each scan reads 4 bytes per frame.  The kernels are separate because they want different shapes:
 // a flagged tie frame costs ~20 us of latency, so the 0.3 % of them need many small workgroups
 // in flight (8 N bytes of LDS each, 7 per CU at N = 2048: 30 us per 639 k frames); the range
-// path needs the block kernel's 16 N bytes and registers, and normally finds nothing (~8 us).
+// routines need the wave kernel's or the block kernel's footprint and normally find nothing (~10 us).
 // One kernel with the larger footprint took 50-60 us.  A caller that reads `out` on another
 // stream BETWEEN the launches of one amcx_features18_c64 call sees the flags (include/amcx.h).
 #pragma once
@@ -129,8 +132,10 @@ __global__ __launch_bounds__(kBlockThreads, 2) void amcx_range_fixup_kernel(
   }
 }
 
+// block_range: also launch amcx_range_fixup_kernel (frame sizes without a range pass of the wave kernel);
+// it goes FIRST, so that a range-flagged frame that also holds a near-pi step gets its tie fix afterwards
 inline hipError_t launch_fixup(const float2* iq, int64_t n_frames, int32_t N, int64_t row_stride,
-                               float* out, int64_t out_stride, hipStream_t stream, int cus) {
+                               float* out, int64_t out_stride, hipStream_t stream, int cus, bool block_range) {
   const size_t tail = sizeof(double) * kBlockWaves * kMaxReduce + sizeof(int) * (kFixListCap + 4);
   const size_t lds_tie = (size_t)8 * (N + (N & 1)) + tail, lds_range = (size_t)16 * N + tail;
   // > 64 KiB of dynamic LDS needs the attribute: set once per device to the most any N asks for
@@ -149,19 +154,22 @@ inline hipError_t launch_fixup(const float2* iq, int64_t n_frames, int32_t N, in
     if (dev >= 0 && dev < 64) attr_set[dev] = true;   // benign race: idempotent
   }
   const int64_t max_grid = (n_frames + 63) / 64;
-  int64_t grid = (int64_t)cus * 16;     // few flagged frames per workgroup: they are handled one at a time
+  int64_t grid;
+  if (block_range) {
+    int per_cu = (int)((160 * 1024) / lds_range);
+    per_cu = per_cu < 1 ? 1 : per_cu > 2 ? 2 : per_cu;      // launch bound: two workgroups per CU
+    grid = (int64_t)cus * per_cu;
+    if (grid > max_grid) grid = max_grid;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(amcx_range_fixup_kernel, dim3((unsigned)grid), dim3(kBlockThreads), lds_range, stream, iq,
+                       (long long)n_frames, (int)N, (long long)row_stride, out, (long long)out_stride);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  grid = (int64_t)cus * 16;     // few flagged frames per workgroup: they are handled one at a time
   if (grid > max_grid) grid = max_grid;
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL(amcx_fixup_kernel, dim3((unsigned)grid), dim3(kBlockThreads), lds_tie, stream, iq,
-                     (long long)n_frames, (int)N, (long long)row_stride, out, (long long)out_stride);
-  e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  int per_cu = (int)((160 * 1024) / lds_range);
-  per_cu = per_cu < 1 ? 1 : per_cu > 2 ? 2 : per_cu;      // launch bound: two workgroups per CU
-  grid = (int64_t)cus * per_cu;
-  if (grid > max_grid) grid = max_grid;
-  if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(amcx_range_fixup_kernel, dim3((unsigned)grid), dim3(kBlockThreads), lds_range, stream, iq,
                      (long long)n_frames, (int)N, (long long)row_stride, out, (long long)out_stride);
   return hipGetLastError();
 }

@@ -169,7 +169,17 @@ __device__ inline void frequency_features(double Kw, double swd1, double swd2, d
 // stores float32: feature_extraction.py:35,56).  Formulas: features.py:66-185;
 // C60 uses +3*m20^3 and m62 is real-only, as the reference has them
 // (features.py:147,57).
-__device__ inline void finalize_features(const FrameSums& s, int N, float* __restrict__ out) {
+// SCALED (the range pass of the wave kernel): the sums are those of the frame multiplied by 2^-ex, ex even;
+// feature j of the frame itself is the scaled one times 2^(ex * order_j) with order = 2, 0, 0, 0, 0, 1, 1/2, 0, 0, 2, 2,
+// 4, 4, 4, 6, 6, 6, 6 -- applied in fp64 before the float32 store, so that store overflows / underflows exactly where the
+// reference's does (feature_extraction.py:35,56).
+template <bool SCALED = false>
+__device__ inline void finalize_features(const FrameSums& s, int N, float* __restrict__ out, int ex = 0) {
+  [[maybe_unused]] const int h = ex / 2;                 // ex is even: 2^(h * twice_order) is exact
+  auto put = [&](int j, int twice_order, double v) {
+    if constexpr (SCALED) v = __builtin_ldexp(v, h * twice_order);
+    out[j] = (float)v;
+  };
   const double n = (double)N;
   const double inv = 1.0 / n, inv_nm1 = 1.0 / (n - 1.0);
   // non-finite input anywhere -> the reference's numpy arithmetic yields NaN
@@ -180,7 +190,7 @@ __device__ inline void finalize_features(const FrameSums& s, int N, float* __res
     return;
   }
   // ---- f1: gamma_max
-  out[0] = (float)(s.gmax_raw * inv);
+  put(0, 4, s.gmax_raw * inv);
 
   // ---- phase: f2 = std1(|theta|), f3 = std1(theta); both from sums about a shift
   // close to the mean (no E[v^2] - E[v]^2 on raw values: |theta| can have a tiny
@@ -191,8 +201,8 @@ __device__ inline void finalize_features(const FrameSums& s, int N, float* __res
   const double ma = s.sab1 * inv;                       // mean of shifted |theta|
   double cabs2 = s.sab2 - n * ma * ma;                  // sum (|theta|-mean)^2
   if (cabs2 < 0) cabs2 = 0;
-  out[1] = (float)q_sqrt(cabs2 * inv_nm1);
-  out[2] = (float)q_sqrt(ct2 * inv_nm1);
+  put(1, 0, q_sqrt(cabs2 * inv_nm1));
+  put(2, 0, q_sqrt(ct2 * inv_nm1));
 
   // ---- envelope: f4, f6, f7, f8
   // an all-zero frame reaches here as N samples of power kTinyPower (the angle
@@ -203,11 +213,11 @@ __device__ inline void finalize_features(const FrameSums& s, int N, float* __res
     const double mad = s.sad1 * inv;                    // mean |a-mu|
     double v = s.sad2 - n * mad * mad;                  // sum (|a-mu| - mad)^2
     if (v < 0) v = 0;
-    out[3] = (float)q_div(q_sqrt(v * inv_nm1), mu);       // 0/0 -> NaN for a zero frame
-    out[5] = (float)mu;
-    out[6] = (float)(q_sqrt(zero_frame ? 0.0 : s.sa) * inv);
+    put(3, 0, q_div(q_sqrt(v * inv_nm1), mu));            // 0/0 -> NaN for a zero frame
+    put(5, 2, mu);
+    put(6, 1, q_sqrt(zero_frame ? 0.0 : s.sa) * inv);
     const double m2 = s.sad2 * inv, m4 = s.sad4 * inv;
-    out[7] = (float)q_div(m4, m2 * m2);                 // m2 == 0 -> NaN (scipy rule)
+    put(7, 0, q_div(m4, m2 * m2));                      // m2 == 0 -> NaN (scipy rule)
   }
 
   // ---- frequency phi = w / 2pi over N-1 values: f5, f9
@@ -237,20 +247,20 @@ __device__ inline void finalize_features(const FrameSums& s, int N, float* __res
   const double q20r = m20r * m20r - m20i * m20i, q20i = 2.0 * m20r * m20i;   // m20^2
   const double n20 = m20r * m20r + m20i * m20i;                              // |m20|^2
 
-  out[9] = (float)cabs(m20r, m20i);                                          // C20
-  out[10] = (float)__builtin_fabs(m21);                                      // C21
-  out[11] = (float)cabs(m40r - 3.0 * q20r, m40i - 3.0 * q20i);               // C40
-  out[12] = (float)cabs(m41r - 3.0 * m20r * m21, m41i - 3.0 * m20i * m21);   // C41
-  out[13] = (float)__builtin_fabs(m42 - n20 - 2.0 * m21 * m21);              // C42
+  put(9, 4, cabs(m20r, m20i));                                               // C20
+  put(10, 4, __builtin_fabs(m21));                                           // C21
+  put(11, 8, cabs(m40r - 3.0 * q20r, m40i - 3.0 * q20i));                    // C40
+  put(12, 8, cabs(m41r - 3.0 * m20r * m21, m41i - 3.0 * m20i * m21));        // C41
+  put(13, 8, __builtin_fabs(m42 - n20 - 2.0 * m21 * m21));                   // C42
   {  // C60 = m60 - 15 m20 m40 + 3 m20^3
     const double pr = m20r * m40r - m20i * m40i, pi = m20r * m40i + m20i * m40r;
     const double cr = q20r * m20r - q20i * m20i, ci = q20r * m20i + q20i * m20r;
-    out[14] = (float)cabs(m60r - 15.0 * pr + 3.0 * cr, m60i - 15.0 * pi + 3.0 * ci);
+    put(14, 12, cabs(m60r - 15.0 * pr + 3.0 * cr, m60i - 15.0 * pi + 3.0 * ci));
   }
   {  // C61 = m61 - 5 m21 m40 - 10 m20 m41 + 30 m20^2 m21
     const double pr = m20r * m41r - m20i * m41i, pi = m20r * m41i + m20i * m41r;
-    out[15] = (float)cabs(m61r - 5.0 * m21 * m40r - 10.0 * pr + 30.0 * q20r * m21,
-                          m61i - 5.0 * m21 * m40i - 10.0 * pi + 30.0 * q20i * m21);
+    put(15, 12, cabs(m61r - 5.0 * m21 * m40r - 10.0 * pr + 30.0 * q20r * m21,
+                     m61i - 5.0 * m21 * m40i - 10.0 * pi + 30.0 * q20i * m21));
   }
   {  // C62 = m62 - 6 m20 m42 - 8 m21 m41 - m22 m40 + 6 m20^2 m22 + 24 m21^2 m20
     // m22 m40 = conj(m20) m40 ; m20^2 m22 = m20 |m20|^2
@@ -259,13 +269,13 @@ __device__ inline void finalize_features(const FrameSums& s, int N, float* __res
                       24.0 * m21 * m21 * m20r;
     const double im = -6.0 * m20i * m42 - 8.0 * m21 * m41i - ai + 6.0 * m20i * n20 +
                       24.0 * m21 * m21 * m20i;
-    out[16] = (float)cabs(re, im);
+    put(16, 12, cabs(re, im));
   }
   {  // C63 = m63 - 9 m21 m42 + 12 m21^3 - 3 m20 m43 - 3 m22 m41 + 18 m20 m21 m22
     // m20 conj(m41) + conj(m20) m41 = 2 Re(m20 conj(m41)), real
     const double cross = 2.0 * (m20r * m41r + m20i * m41i);
-    out[17] = (float)__builtin_fabs(m63 - 9.0 * m21 * m42 + 12.0 * m21 * m21 * m21 -
-                                    3.0 * cross + 18.0 * m21 * n20);
+    put(17, 12, __builtin_fabs(m63 - 9.0 * m21 * m42 + 12.0 * m21 * m21 * m21 -
+                               3.0 * cross + 18.0 * m21 * n20));
   }
 }
 

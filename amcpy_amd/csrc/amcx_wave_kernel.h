@@ -705,10 +705,17 @@ __device__ __forceinline__ float fft_back(const LaneAddr& la) {
 }
 
 // ---------------------------------------------------------------------------
-template <int N>
-__global__ __launch_bounds__(Cfg<N>::kThreads, (Cfg<N>::kWavesPerWG + 3) / 4) void amcx_features18_wave_kernel(
+// RANGE = false: the throughput kernel.  RANGE = true: the range pass behind it (amcx_range_wave_kernel):
+// the same machine over only the frames the throughput kernel flagged as outside its fp32 range
+// (f5 = -inf), each multiplied by an exact power of two first -- 2^-ex, ex the even-rounded exponent of
+// its largest component, so that every component is below 4 and no sixth-order product can overflow --
+// and un-scaled in the fp64 finaliser through the features' scaling laws (finalize_features<true>).
+// Waves take blocks of up to 64 frames, read their flags with one load and skip blocks without a flag.
+template <int N, bool RANGE>
+__device__ __forceinline__ void wave_body(
     const float2* __restrict__ iq, long long n_frames, long long row_stride,
     float* __restrict__ out, long long out_stride AMCX_STAMP_ARG) {
+  static_assert(!RANGE || (N >= 1024 && N <= 4096), "range pass: the sizes whose frame sits in one register set");
   using C = Cfg<N>;
   constexpr int R = C::kFftRows, ROWS = C::kHeldRows;
   constexpr int kWavesPerWG = C::kWavesPerWG, kThreads = C::kThreads, kTailFrames = C::kTailFrames;
@@ -818,7 +825,24 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, (Cfg<N>::kWavesPerWG + 3) / 4) vo
     // grab the next chunk of this workgroup's slice (lane 0 asks, the wave follows)
     long long f0;
     int n_here;
-    {
+    [[maybe_unused]] unsigned long long todo = 0;     // range pass: flagged frames of this block of 64
+    if constexpr (RANGE) {
+      // blocks of up to 64 frames (one flag per lane), smaller when the slice is short: at least ~4 blocks per wave,
+      // so that a slice full of flagged frames is still spread over all twelve waves
+      int blk = 64;
+      while (blk > 8 && slice_len < (long long)blk * kWavesPerWG * 4) blk >>= 1;
+      unsigned got = 0;
+      if (lane == 0) got = __hip_atomic_fetch_add(&counters[0], (unsigned)blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      got = __builtin_amdgcn_readfirstlane(got);
+      if ((long long)got >= slice_len) break;
+      f0 = slice0 + got;
+      const long long left = slice_len - got;
+      float flag = 0.f;
+      if (lane < (left < blk ? left : blk)) flag = out[(f0 + lane) * out_stride + 4];
+      todo = __builtin_amdgcn_ballot_w64(flag == -__builtin_inff());
+      if (todo == 0) continue;
+      n_here = 0;
+    } else {
       unsigned got = 0;
       if (lane == 0) got = __hip_atomic_fetch_add(&counters[0], (unsigned)kFramesPerWave, __ATOMIC_RELAXED,
                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1163,8 +1187,75 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, (Cfg<N>::kWavesPerWG + 3) / 4) vo
       if (lane == 63) row[kNumSums] = pk;        // overwrites the zero pad slot 27 (LDS ops of a wave are in order)
     };
 
+    // ---- batch finalisation: lane g turns the sums in stash row g into 18 features ----
+    auto finalise = [&](int count) {
+      lds_wave_fence();
+      if (lane < count) {
+        const float* row = stash + (lane * C::kFlushes + (C::kFlushes - 1)) * kStashStride;   // the frame's last row
+        auto sm = [&](int k) -> double {           // sum k of the frame: its stash rows added in fp64
+          double t = row[k];
+          if constexpr (C::kFlushes > 1) {
+#pragma unroll
+            for (int h = 1; h < C::kFlushes; ++h) t += (double)row[k - h * kStashStride];
+          }
+          return t;
+        };
+        FrameSums F;
+        F.sA = sm(0); F.sBh = sm(1); F.sP = sm(2); F.sAA = sm(3); F.sX4 = sm(4); F.sAB = sm(5);
+        F.sAP = sm(6); F.sBP = sm(7); F.sAAA = sm(8); F.sABB = sm(9); F.sAAB = sm(10);
+        F.sBBB = sm(11); F.sAAP = sm(12); F.sX4P = sm(13); F.sABP = sm(14);
+        F.sa = sm(15); F.sad1 = sm(16); F.sad2 = sm(17); F.sad4 = sm(18);
+        F.std1 = sm(19); F.std2 = sm(20); F.sab1 = sm(21); F.sab2 = sm(22);
+        F.swd1 = sm(23); F.swd2 = sm(24); F.swd3 = sm(25); F.swd4 = sm(26);
+        F.gmax_raw = row[27]; F.Kt = row[28]; F.Kw = row[29]; F.Ka = row[30];
+        F.pi_tie = row[31] != 0.0f;
+        float feat[18];
+        long long f;
+        if constexpr (RANGE) {
+          const int code = (int)row[kNumSums + 5];              // (ex + 128) * 64 + index within the block
+          finalize_features<true>(F, N, feat, (code >> 6) - 128);
+          f = f0 + (code & 63);
+        } else {
+          finalize_features(F, N, feat);
+          if (is_outside_fp32_range(F, N)) feat[4] = -__builtin_inff();   // all 18 redone by the range pass
+          f = f0 + lane;
+        }
+        float* dst = out + f * out_stride;
+#pragma unroll
+        for (int j = 0; j < 18; ++j) dst[j] = feat[j];
+      }
+      lds_wave_fence();
+    };
+
     using Slot0 = std::integral_constant<int, 0>;
-    if constexpr (C::kGroup > 1) {
+    if constexpr (RANGE) {
+      while (todo != 0) {
+        int cnt = 0;
+        for (; cnt < kFramesPerWave && todo != 0; ++cnt) {
+          const int idx = __builtin_ctzll(todo);
+          todo &= todo - 1;
+          float xr[2 * ROWS], xi[2 * ROWS];
+          load_frame(xr, xi, f0 + idx);
+          float m = 0.f;                                       // largest |component|: NaNs drop out of the maximum
+          static_for<2 * ROWS>([&](auto ee) {
+            constexpr int e = decltype(ee)::value;
+            m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(xr[e])), __builtin_fabsf(xi[e]));
+          });
+          m = bcast_l63(wave_max_l63(m));
+          int ex = 0;                                          // an infinite component keeps 0: the sums go NaN
+          if (m >= 0x1p-125f && m <= 3.4028235e38f) ex = (((__builtin_bit_cast(int, m) >> 23) & 0xff) - 127) & ~1;
+          const float sc = __builtin_bit_cast(float, (127 - ex) << 23);      // 2^-ex, exact
+          static_for<2 * ROWS>([&](auto ee) {
+            constexpr int e = decltype(ee)::value;
+            xr[e] *= sc; xi[e] *= sc;
+          });
+          frame(xr, xi, cnt, Slot0{});
+          if (lane == 63)
+            stash[(cnt * C::kFlushes + (C::kFlushes - 1)) * kStashStride + kNumSums + 5] = (float)((ex + 128) * 64 + idx);
+        }
+        finalise(cnt);
+      }
+    } else if constexpr (C::kGroup > 1) {
       // short frames, ping-pong prefetch as below, kGroup frames per run of FFT passes 2-3
       constexpr int G = C::kGroup;
       float ar[2 * ROWS], ai[2 * ROWS], br[2 * ROWS], bi[2 * ROWS];
@@ -1218,35 +1309,7 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, (Cfg<N>::kWavesPerWG + 3) / 4) vo
 
     AMCX_STAMP(4);
     asm volatile("; MARK finalize");
-    // ---- batch finalisation: lane g turns frame g's sums into 18 features ----
-    lds_wave_fence();
-    if (lane < n_here) {
-      const float* row = stash + (lane * C::kFlushes + (C::kFlushes - 1)) * kStashStride;   // the frame's last row
-      auto sm = [&](int k) -> double {           // sum k of the frame: its stash rows added in fp64
-        double t = row[k];
-        if constexpr (C::kFlushes > 1) {
-#pragma unroll
-          for (int h = 1; h < C::kFlushes; ++h) t += (double)row[k - h * kStashStride];
-        }
-        return t;
-      };
-      FrameSums F;
-      F.sA = sm(0); F.sBh = sm(1); F.sP = sm(2); F.sAA = sm(3); F.sX4 = sm(4); F.sAB = sm(5);
-      F.sAP = sm(6); F.sBP = sm(7); F.sAAA = sm(8); F.sABB = sm(9); F.sAAB = sm(10);
-      F.sBBB = sm(11); F.sAAP = sm(12); F.sX4P = sm(13); F.sABP = sm(14);
-      F.sa = sm(15); F.sad1 = sm(16); F.sad2 = sm(17); F.sad4 = sm(18);
-      F.std1 = sm(19); F.std2 = sm(20); F.sab1 = sm(21); F.sab2 = sm(22);
-      F.swd1 = sm(23); F.swd2 = sm(24); F.swd3 = sm(25); F.swd4 = sm(26);
-      F.gmax_raw = row[27]; F.Kt = row[28]; F.Kw = row[29]; F.Ka = row[30];
-      F.pi_tie = row[31] != 0.0f;
-      float feat[18];
-      finalize_features(F, N, feat);
-      if (is_outside_fp32_range(F, N)) feat[4] = -__builtin_inff();   // all 18 redone by amcx_fixup_kernel
-      float* dst = out + (f0 + lane) * out_stride;
-#pragma unroll
-      for (int j = 0; j < 18; ++j) dst[j] = feat[j];
-    }
-    lds_wave_fence();
+    if constexpr (!RANGE) finalise(n_here);
     AMCX_STAMP(5);
   }
 #ifdef AMCX_WAVE_STAMPS
@@ -1260,6 +1323,26 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, (Cfg<N>::kWavesPerWG + 3) / 4) vo
   }
 #endif
 }
+
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::kThreads, (Cfg<N>::kWavesPerWG + 3) / 4) void amcx_features18_wave_kernel(
+    const float2* __restrict__ iq, long long n_frames, long long row_stride,
+    float* __restrict__ out, long long out_stride AMCX_STAMP_ARG) {
+#ifdef AMCX_WAVE_STAMPS
+  wave_body<N, false>(iq, n_frames, row_stride, out, out_stride, stamp_out);
+#else
+  wave_body<N, false>(iq, n_frames, row_stride, out, out_stride);
+#endif
+}
+
+#ifndef AMCX_WAVE_STAMPS
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::kThreads, (Cfg<N>::kWavesPerWG + 3) / 4) void amcx_range_wave_kernel(
+    const float2* __restrict__ iq, long long n_frames, long long row_stride,
+    float* __restrict__ out, long long out_stride) {
+  wave_body<N, true>(iq, n_frames, row_stride, out, out_stride);
+}
+#endif
 
 }  // namespace wave
 
@@ -1281,10 +1364,16 @@ inline const char* wave_kernel_name(int frame_size) {
 }
 
 #ifndef AMCX_WAVE_STAMPS
-template <int N>
+// sizes with a range pass of their own (the others' flagged frames go to the block-kernel routine)
+inline bool wave_has_range_pass(int frame_size) { return frame_size == 1024 || frame_size == 2048 || frame_size == 4096; }
+
+template <int N, bool RANGE = false>
 inline hipError_t launch_wave_n(const float2* iq, int64_t n_frames, int64_t row_stride, float* out,
                                 int64_t out_stride, hipStream_t stream, int cus) {
-  auto kern = wave::amcx_features18_wave_kernel<N>;
+  auto kern = [] {
+    if constexpr (RANGE) return wave::amcx_range_wave_kernel<N>;
+    else return wave::amcx_features18_wave_kernel<N>;
+  }();
   constexpr int lds = wave::Cfg<N>::kLdsBytes;
   // > 64 KiB of dynamic LDS needs the attribute; it is per device, so once per (kernel, device)
   static bool lds_attr_set[64] = {};
@@ -1315,6 +1404,17 @@ inline hipError_t launch_wave(const float2* iq, int64_t n_frames, int32_t frame_
     case 2048: return launch_wave_n<2048>(iq, n_frames, row_stride, out, out_stride, stream, cus);
     case 4096: return launch_wave_n<4096>(iq, n_frames, row_stride, out, out_stride, stream, cus);
     case 8192: return launch_wave_n<8192>(iq, n_frames, row_stride, out, out_stride, stream, cus);
+    default: return hipErrorNotSupported;
+  }
+}
+
+inline hipError_t launch_wave_range(const float2* iq, int64_t n_frames, int32_t frame_size,
+                                    int64_t row_stride, float* out, int64_t out_stride,
+                                    hipStream_t stream, int cus) {
+  switch (frame_size) {
+    case 1024: return launch_wave_n<1024, true>(iq, n_frames, row_stride, out, out_stride, stream, cus);
+    case 2048: return launch_wave_n<2048, true>(iq, n_frames, row_stride, out, out_stride, stream, cus);
+    case 4096: return launch_wave_n<4096, true>(iq, n_frames, row_stride, out, out_stride, stream, cus);
     default: return hipErrorNotSupported;
   }
 }

@@ -26,18 +26,21 @@
  *     NaN/Inf in the data are not errors: a frame holding a non-finite sample
  *     yields 18 NaNs, as numpy's arithmetic does for the reference.
  *   - amplitude range: samples are exact zeros or 1e-15 <~ |x| <~ 1e15.  Inside
- *     1e-5 <~ rms|x| <~ 1e5 the throughput kernel's fp32 sums hold; outside it (and whenever
- *     one of its sums overflows: a single 1e7 sample among unit ones) the frame is
- *     recomputed with fp64 sums by the fix-up launch, so results match the reference --
- *     which evaluates in complex128 (features.py:46-58) -- including the inf / 0 its
- *     float32 store produces for |x|^6 beyond float32 (feature_extraction.py:35,56).
- *     Such frames run at the block kernel's rate (~1/10 of the fast path).
+ *     1e-5 <~ rms|x| <~ 1e5 the throughput kernel's fp32 sums hold; a frame outside it (or any
+ *     of whose sums overflows: a single 1e7 sample among unit ones) is flagged and redone
+ *     behind it -- at frame sizes 1024, 2048 and 4096 by a range pass of the same kernel on a
+ *     copy multiplied by an exact power of two and un-scaled in fp64 (a data set that is
+ *     out of range throughout, e.g. raw 24-bit ADC counts, runs at half the normal rate), at
+ *     the other wave sizes by the block kernel's fp64-sum routine (~1/10 of the rate) -- so
+ *     results match the reference, which evaluates in complex128 (features.py:46-58),
+ *     including the inf / 0 its float32 store produces for |x|^6 beyond float32
+ *     (feature_extraction.py:35,56).
  *   - AMCX_VARIANT_WAVE / AUTO on a power-of-two frame size is THREE launches on the stream:
  *     the throughput kernel marks the frames it cannot finish exactly in band -- feature 5
  *     (a standard deviation, >= 0 or NaN) stored negative: finite = a phase step within an
- *     fp32 ulp of +-pi, -inf = outside the fp32 range -- and amcx_fixup_kernel /
- *     amcx_range_fixup_kernel rewrite them.  A consumer on ANOTHER stream that reads `out_dev` between the launches
- *     sees those marks; order it after the whole call (event / stream sync), as usual.
+ *     fp32 ulp of +-pi, -inf = outside the fp32 range -- and amcx_range_wave_kernel (or
+ *     amcx_range_fixup_kernel) and amcx_fixup_kernel rewrite them.  A consumer on ANOTHER
+ *     stream that reads `out_dev` between the launches sees those marks; order it after the whole call (event / stream sync), as usual.
  *   - re-entrant and thread-safe; launches are asynchronous on `hip_stream`
  *     (a hipStream_t, NULL = default stream); completion = caller's stream sync.
  *     The device entry points allocate nothing and never synchronise, so after one

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Worst case for the range path: a whole data set scaled like raw 24-bit ADC counts (x 1e7), so
-every frame is outside the throughput kernel's fp32 range, is flagged (f5 = -inf) and recomputed
-with fp64 sums by amcx_range_fixup_kernel.  Prints the rate of that path, of the same data
-pre-scaled by an exact power of two into range, and checks both against each other through the
-features' scaling laws."""
+every frame is outside the throughput kernel's fp32 range, is flagged (f5 = -inf) and goes through
+the range pass (amcx_range_wave_kernel: the same machine on a power-of-two pre-scaled copy; frame
+sizes without one: amcx_range_fixup_kernel, fp64 sums).  Prints the rate of that path, of the same
+data pre-scaled by hand into range, and checks both against each other through the features'
+scaling laws."""
 import sys
 from pathlib import Path
 
@@ -38,7 +39,7 @@ def rate(x, label):
 
 in_range = rate(arena, "unit-power data (fast path)")
 big = arena * 1e7
-out_big = rate(big, "the same x 1e7 (every frame through the fp64-sum fix-up)")
+out_big = rate(big, "the same x 1e7 (every frame flagged, then the range pass)")
 scaled = rate(big * 2.0 ** -23, "x 1e7 pre-scaled by 2^-23 (exact) back into range")
 order = torch.tensor([2, 0, 0, 0, 0, 1, 0.5, 0, 0, 2, 2, 4, 4, 4, 6, 6, 6, 6], device="cuda", dtype=torch.float64)
 law = (2.0 ** 23) ** order
@@ -48,7 +49,7 @@ rel = (out_big.double() - want.double()).abs() / want.double().abs().clamp_min(1
 rel[~fin] = 0
 well = [0, 1, 2, 3, 4, 5, 6, 7, 8, 10]                        # ids 1-9, 11: plain relative is meaningful
 cum = [9, 11, 12, 13, 14, 15, 16, 17]                        # cancellation-dominated: fp32 sums vs fp64 sums differ here
-print("x 1e7 through the fix-up vs the pre-scaled fast path, scaling laws applied: worst plain relative difference "
+print("x 1e7 through the range pass vs the hand-pre-scaled fast path, scaling laws applied: worst plain relative difference "
       f"{rel.reshape(-1, 18)[:, well].max().item():.2e} on ids 1-9, 11; {rel.reshape(-1, 18)[:, cum].max().item():.2e} on the "
-      f"cancellation-dominated cumulants (fp64 sums against fp32 sums); inf pattern equal: "
+      f"cancellation-dominated cumulants; inf pattern equal: "
       f"{bool((torch.isinf(want) == torch.isinf(out_big)).all())}")
