@@ -38,8 +38,8 @@
  *   - AMCX_VARIANT_WAVE / AUTO on a power-of-two frame size is THREE launches on the stream:
  *     the throughput kernel marks the frames it cannot finish exactly in band -- feature 5
  *     (a standard deviation, >= 0 or NaN) stored negative: finite = a phase step within an
- *     fp32 ulp of +-pi, -inf = outside the fp32 range -- and amcx_range_wave_kernel (or
- *     amcx_range_fixup_kernel) and amcx_fixup_kernel rewrite them.  A consumer on ANOTHER
+ *     fp32 ulp of +-pi, -inf = outside the fp32 range -- and the kernels amcx_range_wave_kernel
+ *     or amcx_range_fixup_kernel, then amcx_fixup_kernel, rewrite them.  A consumer on ANOTHER
  *     stream that reads `out_dev` between the launches sees those marks; order it after the whole call (event / stream sync), as usual.
  *   - re-entrant and thread-safe; launches are asynchronous on `hip_stream`
  *     (a hipStream_t, NULL = default stream); completion = caller's stream sync.
