@@ -894,3 +894,34 @@ def test_iq_pair_dataset_through_the_engine():
     assert np.array_equal(extract_iq_pairs(pairs, first_frame=17, max_frames=100), want[17:117])
     assert np.array_equal(features18_iq_pairs(torch.from_numpy(pairs).cuda()).cpu().numpy(), want)
     _assert_parity(want, orc.features18_batch(x), x, "RadioML-shaped (I, Q) pairs, N = 1024")
+
+
+@pytest.mark.parametrize("N", [1024, 2048, 4096])
+def test_range_pass_mixed_batches_and_scaling_laws(N):
+    """The wave kernel's range pass (frames flagged f5 = -inf redone on a power-of-two pre-scaled copy):
+    in a batch where some frames are in range and others are scaled by 2^30 or 2^-40 (out of range both
+    ways), every frame's 18 floats equal what the frame yields alone -- flagged and unflagged frames
+    share 8..64-frame scan blocks, with ragged counts -- and a scaled frame equals its in-range
+    original through the scaling laws (an exact power of two changes no rounding: at most the final
+    float32 store differs, by its overflow / underflow)."""
+    torch = _torch()
+    from amcpy_amd import synth
+    from amcpy_amd.features import features18
+    base = np.concatenate([synth.host_block(m, 4.0, 7, N, seed=555 + i) for i, m in enumerate(synth.MODS6)])   # 42 frames
+    rng = np.random.default_rng(N)
+    kinds = rng.integers(0, 3, size=201)                       # 0: as is, 1: x 2^30, 2: x 2^-40
+    pick = rng.integers(0, base.shape[0], size=201)
+    scale = np.array([1.0, 2.0 ** 30, 2.0 ** -40])[kinds]
+    batch = (base[pick].astype(np.complex128) * scale[:, None]).astype(np.complex64)       # exact: powers of two
+    got = features18(torch.from_numpy(batch).cuda()).cpu().numpy()
+    ref = features18(torch.from_numpy(base).cuda()).cpu().numpy().astype(np.float64)
+    order = np.array([2, 0, 0, 0, 0, 1, 0.5, 0, 0, 2, 2, 4, 4, 4, 6, 6, 6, 6])
+    for i in range(0, 201, 5):                                 # alone == in the batch, bit for bit
+        alone = features18(torch.from_numpy(batch[i:i + 1]).cuda()).cpu().numpy()[0]
+        assert np.array_equal(alone, got[i], equal_nan=True), (N, i, kinds[i])
+    with np.errstate(all="ignore"):
+        want = (ref[pick] * scale[:, None] ** order[None, :]).astype(np.float32)
+    same = np.isfinite(want) & (np.abs(want) > 1.2e-38)        # normal floats: the laws are exact
+    assert np.array_equal(np.isinf(got), np.isinf(want))
+    assert np.allclose(got[same], want[same], rtol=2.5e-7, atol=0), N
+    assert np.all(got[kinds == 0] == ref[pick][kinds == 0].astype(np.float32))
