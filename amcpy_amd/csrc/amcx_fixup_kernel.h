@@ -72,15 +72,27 @@ __global__ __launch_bounds__(kBlockThreads) void amcx_fixup_kernel(
     for (int q = 0; q < n_flagged; ++q) {
       const long long f = base + list[q];
       const float2* src = iq + f * row_stride;
+      // angles and cross products are scale-free, their fp32 evaluation is not (|x|^2 must stay inside float32): work
+      // on the frame times 2^-ex, ex the exponent of its largest component -- exact, and a no-op for ordinary data
+      float m = 0.f;
       for (int n = tid; n < N; n += kBlockThreads) {
         const float2 x = src[n];
+        m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(x.x), __builtin_fabsf(x.y)));
+      }
+      m = block_max(m, scratch);                                      // NaN if the frame holds one: no scaling then
+      int ex = 0;
+      if (m >= 0x1p-125f && m <= 3.4028235e38f) ex = ((__builtin_bit_cast(int, m) >> 23) & 0xff) - 127;
+      if (ex > 126) ex = 126;
+      const float sc = __builtin_bit_cast(float, (127 - ex) << 23);
+      for (int n = tid; n < N; n += kBlockThreads) {
+        const float2 x = make_float2(src[n].x * sc, src[n].y * sc);
         const float a = __builtin_amdgcn_sqrtf(__builtin_fmaf(x.x, x.x, __builtin_fmaf(x.y, x.y, kTinyPower)));
         th[n] = fast_angle(x.x, x.y, a);
       }
       __syncthreads();
       double s1[1] = {0};
       for (int n = tid; n + 1 < N; n += kBlockThreads) {
-        const float2 p = src[n], r = src[n + 1];
+        const float2 p = make_float2(src[n].x * sc, src[n].y * sc), r = make_float2(src[n + 1].x * sc, src[n + 1].y * sc);
         const float w = exact_step(th[n + 1], th[n], p.x, p.y, r.x, r.y);
         wv[n] = w;
         s1[0] += w;

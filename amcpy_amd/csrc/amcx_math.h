@@ -135,7 +135,11 @@ __device__ inline bool is_outside_fp32_range(const FrameSums& s, int N) {
   z = __builtin_fma(s.sa, 0.0, z);   z = __builtin_fma(s.sad2, 0.0, z); z = __builtin_fma(s.sad4, 0.0, z);
   z = __builtin_fma(s.gmax_raw, 0.0, z);
   const double n = (double)N;
-  const bool zero_frame = s.sP <= 2.0 * n * (double)kTinyPower;
+  // An all-zero frame shows as N samples of power kTinyPower with every angle exactly 0; samples below
+  // ~3e-19, whose squares underflow, show the same power but not the same angles (only a frame of
+  // non-negative reals that small is indistinguishable from zeros in fp32).  The former stays, the
+  // latter is flagged like any other out-of-range frame.
+  const bool zero_frame = s.sP <= 2.0 * n * (double)kTinyPower && s.std2 == 0.0 && s.sab2 == 0.0 && s.Kt == 0.0;
   const double pbar = s.sP / n;
   return (z != z) || (!zero_frame && !(pbar >= kRangeLoPower && pbar <= kRangeHiPower));
 }

@@ -25,7 +25,9 @@
  *   - every function returns 0 or a negative AMCX_E* code and never throws.
  *     NaN/Inf in the data are not errors: a frame holding a non-finite sample
  *     yields 18 NaNs, as numpy's arithmetic does for the reference.
- *   - amplitude range: samples are exact zeros or 1e-15 <~ |x| <~ 1e15.  Inside
+ *   - amplitude range: at frame sizes 1024, 2048 and 4096 any normal float32 (the squares of
+ *     samples below ~3e-19 underflow; a frame of nothing but non-negative reals that small is
+ *     taken for zeros); at the other sizes exact zeros or 1e-15 <~ |x| <~ 1e15.  Inside
  *     1e-5 <~ rms|x| <~ 1e5 the throughput kernel's fp32 sums hold; a frame outside it (or any
  *     of whose sums overflows: a single 1e7 sample among unit ones) is flagged and redone
  *     behind it -- at frame sizes 1024, 2048 and 4096 by a range pass of the same kernel on a

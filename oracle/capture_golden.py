@@ -20,6 +20,7 @@ Fixtures:
   edges_n{N}.npz          degenerate frames and what the reference returns
   range_n2048.npz         ordinary frames at scales 1e-12 ... 1e12 (and mixed-scale ones): the
                           reference's float32-stored outputs incl. their inf / 0 pattern
+  range_extreme_n2048.npz the same frames at 1e-30, 1e-20, 1e20, 1e30 (the ends of float32)
   extract_roundtrip.npz   a tiny `run_extraction(cfg)` run by the reference:
                           input container + the six output files' contents
   extract_roundtrip_f64.npz  the same on a container of genuine doubles (not float32 casts)
@@ -210,7 +211,27 @@ def range_frames(N):
     return z
 
 
+def range_extreme_frames(N):
+    """The same three frames at the ends of float32: 1e-30, 1e-20, 1e20, 1e30 (|x|^2 itself leaves float32)."""
+    from amcpy_amd import synth
+    base = {
+        "qpsk10": synth.host_block("QPSK", 10.0, 1, N, seed=4242)[0].astype(np.complex128),
+        "qam16_20": synth.host_block("16QAM", 20.0, 1, N, seed=4243)[0].astype(np.complex128),
+        "wgn": synth.host_block("WGN", 0.0, 1, N, seed=4244)[0].astype(np.complex128),
+    }
+    return {f"{k}_x{tag}": (v * scale).astype(np.complex64)
+            for tag, scale in (("1e-30", 1e-30), ("1e-20", 1e-20), ("1e20", 1e20), ("1e30", 1e30))
+            for k, v in base.items()}
+
+
 def capture_range(rfeat, N):
+    ze = range_extreme_frames(N)
+    names_e = sorted(ze)
+    xe = np.stack([ze[k] for k in names_e])
+    ge = np.stack([_ref18(rfeat, f, np.complex128) for f in xe])
+    with np.errstate(all="ignore"):
+        np.savez(OUT / f"range_extreme_n{N}.npz", iq=xe, names=np.array(names_e), golden64_f64=ge,
+                 golden64=ge.astype(np.float32))
     z = range_frames(N)
     names = sorted(z)
     x = np.stack([z[k] for k in names])
@@ -294,7 +315,7 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "range":
         capture_range(rfeat, 2048)
         capture_roundtrip_f64(rfe, rcfg)
-        for name in ("range_n2048.npz", "extract_roundtrip_f64.npz"):
+        for name in ("range_n2048.npz", "range_extreme_n2048.npz", "extract_roundtrip_f64.npz"):
             print(f"{name:28s} {(OUT / name).stat().st_size:9d} B")
         return
     capture_kat(rfeat)

@@ -925,3 +925,32 @@ def test_range_pass_mixed_batches_and_scaling_laws(N):
     assert np.array_equal(np.isinf(got), np.isinf(want))
     assert np.allclose(got[same], want[same], rtol=2.5e-7, atol=0), N
     assert np.all(got[kinds == 0] == ref[pick][kinds == 0].astype(np.float32))
+
+
+def test_ends_of_float32_through_the_range_pass():
+    """range_extreme_n2048.npz (captured from the reference): the range fixture's frames at 1e-30, 1e-20,
+    1e20 and 1e30 -- |x|^2 itself leaves float32.  The reference, evaluating in complex128, still returns
+    finite scale-free features, a finite mean magnitude, and inf / 0 / float32 denormals for the rest.
+    The wave kernel flags such frames (also the ones whose power underflows to that of an all-zero
+    frame: their angles give them away) and its range pass, working on the frame times an exact power
+    of two, reproduces all of it."""
+    g = load_npz("range_extreme_n2048.npz")
+    x, names, gold32 = g["iq"], [str(n) for n in g["names"]], g["golden64"]
+    got = _run(x, "auto")
+    S = orc.conditioning_scales(x.astype(np.complex128))
+    inf_or_zero = ~np.isfinite(gold32) | (gold32 == 0)
+    tiny = np.abs(gold32) < 1.2e-38                                   # float32 denormals (and zeros): fewer bits
+    bad = np.argwhere(~np.isfinite(gold32) & (got != gold32))
+    assert bad.size == 0, [(names[i], j + 1, got[i, j], gold32[i, j]) for i, j in bad[:6]]
+    assert np.all(np.abs(got[tiny].astype(np.float64) - gold32[tiny].astype(np.float64)) <= 1e-5 * np.abs(gold32[tiny]) + 1.5e-45)
+    rest = ~inf_or_zero & ~tiny
+    with np.errstate(all="ignore"):
+        diff = np.abs(got.astype(np.float64) - gold32.astype(np.float64))
+        scaled = diff / np.maximum(np.abs(gold32.astype(np.float64)), S)
+    scaled[~rest] = 0.0
+    i, j = np.unravel_index(scaled.argmax(), scaled.shape)
+    print("\n[ends of float32] worst scaled rel per feature:", " ".join(f"{v:.1e}" for v in scaled.max(axis=0)))
+    assert scaled.max() <= TOL, (names[i], j + 1, got[i, j], gold32[i, j])
+    # an all-zero frame is still a zero frame (not flagged, not scaled): NaN pattern of the reference
+    z = _run(np.zeros((1, 2048), np.complex64), "auto")[0]
+    assert np.isnan(z[[3, 7, 8]]).all() and np.all(z[[0, 1, 2, 4, 5, 6] + list(range(9, 18))] == 0)

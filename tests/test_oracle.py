@@ -159,3 +159,11 @@ def test_oracle_on_genuine_doubles_matches_reference_run():
         got = orc.features18_batch(x[:, :, :fs].reshape(-1, fs)).astype(np.float32)
         want = g[f"out_{m}"].reshape(-1, 18)
         assert np.allclose(got, want, rtol=2e-6, atol=0, equal_nan=True), m
+
+
+def test_oracle_at_the_ends_of_float32_matches_reference():
+    g = load_npz("range_extreme_n2048.npz")
+    x, gold = g["iq"].astype(np.complex128), g["golden64_f64"]
+    assert np.allclose(orc.features18_batch(x), gold, rtol=5e-9, atol=0, equal_nan=True)
+    got = np.array(orc.calculate_features(range(1, 19), x[0]))
+    assert np.array_equal(got, gold[0], equal_nan=True)
