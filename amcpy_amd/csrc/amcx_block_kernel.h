@@ -158,8 +158,24 @@ __device__ __forceinline__ void block_frame(const float2* __restrict__ src, int 
   const int tid = threadIdx.x;
   (void)bh; (void)tlo; (void)thi; (void)M;
   {
-    for (int n = tid; n < N; n += kBlockThreads) xs[n] = src[n];
-    __syncthreads();
+    // The frame is staged times 2^-ex, ex the even-rounded exponent of its largest component (exact; 1 for
+    // ordinary data up to a factor < 4), and the finaliser un-scales in fp64 through the features' scaling
+    // laws: every fp32 intermediate (|x|^2, the spectrum) then stays inside float32 for any normal float32
+    // input, as the reference's complex128 evaluation does (features.py:46-58).
+    float mx = 0.f;
+    for (int n = tid; n < N; n += kBlockThreads) {
+      const float2 x = src[n];
+      xs[n] = x;
+      mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(x.x), __builtin_fabsf(x.y)));
+    }
+    mx = block_max(mx, scratch);                       // NaN if the frame holds one (no scaling then); barriers inside
+    int ex = 0;
+    if (mx >= 0x1p-125f && mx <= 3.4028235e38f) ex = (((__builtin_bit_cast(int, mx) >> 23) & 0xff) - 127) & ~1;
+    if (ex != 0) {
+      const float sc = __builtin_bit_cast(float, (127 - ex) << 23);
+      for (int n = tid; n < N; n += kBlockThreads) xs[n] = make_float2(xs[n].x * sc, xs[n].y * sc);
+      __syncthreads();
+    }
 
     FrameSums S;
     // ---- pass A: mixed moments, envelope and phase first sums ------------
@@ -300,7 +316,7 @@ __device__ __forceinline__ void block_frame(const float2* __restrict__ src, int 
     }
     peak = block_max(peak, scratch);   // barriers inside: LDS free for the next frame
     S.gmax_raw = peak;
-    if (tid == 0) finalize_features(S, N, out_row);
+    if (tid == 0) finalize_features<true>(S, N, out_row, ex);
   }
 }
 

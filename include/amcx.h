@@ -25,18 +25,17 @@
  *   - every function returns 0 or a negative AMCX_E* code and never throws.
  *     NaN/Inf in the data are not errors: a frame holding a non-finite sample
  *     yields 18 NaNs, as numpy's arithmetic does for the reference.
- *   - amplitude range: at frame sizes 1024, 2048 and 4096 any normal float32 (the squares of
- *     samples below ~3e-19 underflow; a frame of nothing but non-negative reals that small is
- *     taken for zeros); at the other sizes exact zeros or 1e-15 <~ |x| <~ 1e15.  Inside
- *     1e-5 <~ rms|x| <~ 1e5 the throughput kernel's fp32 sums hold; a frame outside it (or any
- *     of whose sums overflows: a single 1e7 sample among unit ones) is flagged and redone
- *     behind it -- at frame sizes 1024, 2048 and 4096 by a range pass of the same kernel on a
- *     copy multiplied by an exact power of two and un-scaled in fp64 (a data set that is
- *     out of range throughout, e.g. raw 24-bit ADC counts, runs at half the normal rate), at
- *     the other wave sizes by the block kernel's fp64-sum routine (~1/10 of the rate) -- so
- *     results match the reference, which evaluates in complex128 (features.py:46-58),
- *     including the inf / 0 its float32 store produces for |x|^6 beyond float32
- *     (feature_extraction.py:35,56).
+ *   - amplitude range: any normal float32 sample, at every frame size (the squares of samples
+ *     below ~3e-19 underflow; a frame of nothing but non-negative reals that small is taken
+ *     for zeros).  The block kernel stages each frame times an exact power of two and
+ *     un-scales in fp64.  The throughput kernel's fp32 sums hold inside 1e-5 <~ rms|x| <~ 1e5;
+ *     a frame outside that (or any of whose sums overflows: a single 1e7 sample among unit
+ *     ones) is flagged and redone behind it -- at frame sizes 1024, 2048 and 4096 by a range
+ *     pass of the same kernel on a copy multiplied by an exact power of two (a data set that
+ *     is out of range throughout, e.g. raw 24-bit ADC counts, runs at half the normal rate),
+ *     at the other wave sizes by the block kernel's routine (~1/10 of the rate) -- so results
+ *     match the reference, which evaluates in complex128 (features.py:46-58), including the
+ *     inf / 0 / denormals its float32 store produces (feature_extraction.py:35,56).
  *   - AMCX_VARIANT_WAVE / AUTO on a power-of-two frame size is THREE launches on the stream:
  *     the throughput kernel marks the frames it cannot finish exactly in band -- feature 5
  *     (a standard deviation, >= 0 or NaN) stored negative: finite = a phase step within an

@@ -936,12 +936,25 @@ def test_ends_of_float32_through_the_range_pass():
     of two, reproduces all of it."""
     g = load_npz("range_extreme_n2048.npz")
     x, names, gold32 = g["iq"], [str(n) for n in g["names"]], g["golden64"]
-    got = _run(x, "auto")
     S = orc.conditioning_scales(x.astype(np.complex128))
+    for variant in VARIANTS_POW2:            # the block kernel stages every frame times a power of two as well
+        _check_ends_of_float32(_run(x, variant), gold32, S, names, variant)
+    # non-power-of-two frame sizes (block kernel, Bluestein): the first 1000 samples of the same frames vs the oracle
+    x1000 = np.ascontiguousarray(x[:, :1000])
+    with np.errstate(all="ignore"):
+        gold1000 = orc.features18_batch(x1000.astype(np.complex128)).astype(np.float32)
+    _check_ends_of_float32(_run(x1000, "auto"), gold1000, orc.conditioning_scales(x1000.astype(np.complex128)), names, "N=1000")
+    # an all-zero frame is still a zero frame (not flagged, not scaled): NaN pattern of the reference
+    for variant in VARIANTS_POW2:
+        z = _run(np.zeros((1, 2048), np.complex64), variant)[0]
+        assert np.isnan(z[[3, 7, 8]]).all() and np.all(z[[0, 1, 2, 4, 5, 6] + list(range(9, 18))] == 0)
+
+
+def _check_ends_of_float32(got, gold32, S, names, what):
     inf_or_zero = ~np.isfinite(gold32) | (gold32 == 0)
     tiny = np.abs(gold32) < 1.2e-38                                   # float32 denormals (and zeros): fewer bits
     bad = np.argwhere(~np.isfinite(gold32) & (got != gold32))
-    assert bad.size == 0, [(names[i], j + 1, got[i, j], gold32[i, j]) for i, j in bad[:6]]
+    assert bad.size == 0, (what, [(names[i], j + 1, got[i, j], gold32[i, j]) for i, j in bad[:6]])
     assert np.all(np.abs(got[tiny].astype(np.float64) - gold32[tiny].astype(np.float64)) <= 1e-5 * np.abs(gold32[tiny]) + 1.5e-45)
     rest = ~inf_or_zero & ~tiny
     with np.errstate(all="ignore"):
@@ -949,8 +962,5 @@ def test_ends_of_float32_through_the_range_pass():
         scaled = diff / np.maximum(np.abs(gold32.astype(np.float64)), S)
     scaled[~rest] = 0.0
     i, j = np.unravel_index(scaled.argmax(), scaled.shape)
-    print("\n[ends of float32] worst scaled rel per feature:", " ".join(f"{v:.1e}" for v in scaled.max(axis=0)))
-    assert scaled.max() <= TOL, (names[i], j + 1, got[i, j], gold32[i, j])
-    # an all-zero frame is still a zero frame (not flagged, not scaled): NaN pattern of the reference
-    z = _run(np.zeros((1, 2048), np.complex64), "auto")[0]
-    assert np.isnan(z[[3, 7, 8]]).all() and np.all(z[[0, 1, 2, 4, 5, 6] + list(range(9, 18))] == 0)
+    print(f"\n[ends of float32, {what}] worst scaled rel per feature:", " ".join(f"{v:.1e}" for v in scaled.max(axis=0)))
+    assert scaled.max() <= TOL, (what, names[i], j + 1, got[i, j], gold32[i, j])
