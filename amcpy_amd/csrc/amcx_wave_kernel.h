@@ -752,6 +752,13 @@ __device__ __forceinline__ void wave_body(
   const long long tail_len = slice_len < kTailFrames ? slice_len : kTailFrames;
   const long long body_len = slice_len - tail_len;          // grabbed kFramesPerWave at a time
 
+  if constexpr (RANGE) {
+    // normally nothing is flagged: look first, and leave before the twiddle tables cost 5 us of sincospif
+    int mine = 0;
+    for (long long k = tid; k < slice_len; k += kThreads) mine |= out[(slice0 + k) * out_stride + 4] == -__builtin_inff();
+    if (!__syncthreads_or(mine)) return;
+  }
+
   // ---- twiddle tables, once per workgroup -----------------------------------
   // W_NF^e = exp(-2 pi i e / NF) with an integer exponent: exact argument reduction
   auto w_nf = [](int e) {
