@@ -12,11 +12,20 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("AMCX_LIB", _HERE / "lib" / "libamcx.so"))
 
-ABI_VERSION = 1
+ABI_VERSION = 2          # the version this binding was written against; any library >= it will do (include/amcx.h)
 NUM_FEATURES = 18
 VARIANT_AUTO, VARIANT_BLOCK, VARIANT_WAVE = 0, 1, 2
 VARIANTS = {"auto": VARIANT_AUTO, "block": VARIANT_BLOCK, "wave": VARIANT_WAVE}
 OK, EINVAL, ENOTSUP, EHIP, ENODEV, ENOMEM = 0, -1, -2, -3, -4, -5
+SRC_C64, SRC_C128, SRC_F32_SPLIT, SRC_F64_SPLIT = 0, 1, 2, 3
+
+
+class UploadStats(C.Structure):
+    """amcx_upload_stats (include/amcx.h)."""
+    _fields_ = [("frames", C.c_int64), ("source_bytes", C.c_int64), ("pcie_bytes", C.c_int64),
+                ("chunks", C.c_int32), ("threads", C.c_int32), ("plane_major", C.c_int32), ("reserved", C.c_int32),
+                ("seconds", C.c_double), ("seconds_staging", C.c_double), ("seconds_waiting", C.c_double)]
+
 
 # every symbol include/amcx.h declares: (restype, argtypes)
 _i64, _i32, _vp, _fp = C.c_int64, C.c_int32, C.c_void_p, C.POINTER(C.c_float)
@@ -33,6 +42,13 @@ SIGNATURES = {
     "amcx_ctx_destroy": (C.c_int, [_vp]),
     "amcx_ctx_features18_c64_host": (C.c_int, [_vp, _vp, _i64, _i32, _i64, _vp, _i64, _i32]),
     "amcx_ctx_features18_c128_host": (C.c_int, [_vp, _vp, _i64, _i32, _i64, _vp, _i64, _i32]),
+    "amcx_ctx_features18_strided_host": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i64, _i32, _i64, _i64, _i64,
+                                                   _vp, _i64, _i32]),
+    "amcx_stage_host": (C.c_int, [_vp, _vp, _i32, _i64, _i64, _i32, _i64, _i64, _i64, _i64, _i64, _vp, _i64, _i32,
+                                  C.POINTER(_i32), C.POINTER(_i32)]),
+    "amcx_ctx_configure": (C.c_int, [_vp, _i32, _i64, _i32]),
+    "amcx_ctx_upload_stats": (C.c_int, [_vp, C.POINTER(UploadStats)]),
+    "amcx_pack_planes_c64": (C.c_int, [_vp, _i32, _i32, _i64, _i64, _i64, _i32, _vp, _i64, _i32, _vp]),
     "amcx_kernel_name": (C.c_int, [_i32, _i32, C.c_char_p, _i32]),
     "amcx_probe_read_bw": (C.c_int, [_vp, _i64, _vp, _vp]),
     "amcx_group_stats_f32": (C.c_int, [_vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp]),
@@ -67,8 +83,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype, fn.argtypes = res, args
     got = lib.amcx_abi_version()
-    if got != ABI_VERSION:
-        raise ImportError(f"libamcx ABI {got}, binding expects {ABI_VERSION}")
+    if got < ABI_VERSION:
+        raise ImportError(f"libamcx ABI {got} is older than the {ABI_VERSION} this binding needs")
     _lib = lib
     return lib
 
@@ -107,6 +123,22 @@ class HostContext:
         entry = lib.amcx_ctx_features18_c128_host if x2.dtype == np.complex128 else lib.amcx_ctx_features18_c64_host
         check(entry(self._h, x2.ctypes.data, x2.shape[0], int(frame_size), x2.shape[1],
                     out.ctypes.data, out.shape[1], int(variant)))
+
+    def configure(self, threads: int = 0, slot_bytes: int = 0, round_on_device: int = -1) -> None:
+        check(load().amcx_ctx_configure(self._h, int(threads), int(slot_bytes), int(round_on_device)))
+
+    def run_strided(self, re_ptr: int, im_ptr, kind: int, n_snr: int, n_frames: int, frame_size: int,
+                    strides, out, variant: int = VARIANT_AUTO) -> None:
+        """amcx_ctx_features18_strided_host: `strides` = (snr, frame, sample) in source elements;
+        out: C-contiguous (n_snr * n_frames, >= 18) float32.  The caller keeps the source alive."""
+        check(load().amcx_ctx_features18_strided_host(
+            self._h, re_ptr, im_ptr, int(kind), int(n_snr), int(n_frames), int(frame_size),
+            int(strides[0]), int(strides[1]), int(strides[2]), out.ctypes.data, out.shape[1], int(variant)))
+
+    def upload_stats(self) -> dict:
+        st = UploadStats()
+        check(load().amcx_ctx_upload_stats(self._h, C.byref(st)))
+        return {name: getattr(st, name) for name, _ in UploadStats._fields_ if name != "reserved"}
 
     def close(self) -> None:
         if self._h:

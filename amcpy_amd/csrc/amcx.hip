@@ -5,12 +5,15 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
+#include <chrono>
 #include <new>
 
 #include "amcx_block_kernel.h"
 #include "amcx_wave_kernel.h"
 #include "amcx_fixup_kernel.h"
 #include "amcx_post_kernels.h"
+#include "amcx_pack_kernel.h"
+#include "amcx_upload.h"
 
 namespace {
 
@@ -43,17 +46,29 @@ int resolve_variant(int32_t frame_size, int32_t variant) {
   }
 }
 
+// CUs of the calling thread's current device (cached per device: a node may mix partitioned and whole GPUs)
 int cu_count() {
-  static int cus = 0;   // benign race: every writer stores the same value
-  if (cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-      cus = n;
-    else
-      return 256;
+  static int cus[64] = {};   // benign race: every writer of a slot stores the same value
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 256; }
+  if (dev >= 0 && dev < 64 && cus[dev] > 0) return cus[dev];
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    return 256;
   }
-  return cus;
+  if (dev >= 0 && dev < 64) cus[dev] = n;
+  return n;
+}
+
+// include/amcx.h, DEVICE OWNERSHIP: a device pointer must live on the current device.  Pointers the
+// runtime does not know (or host-visible ones) are let through -- the launch itself will say.
+bool on_another_device(const void* p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (a.type != hipMemoryTypeDevice) return false;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return a.device != dev;
 }
 
 // spectral-term variant of the block kernel for this frame size
@@ -121,20 +136,6 @@ __global__ __launch_bounds__(256) void amcx_probe_read_kernel(const float4* __re
   if (threadIdx.x == 0) partial[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
 }
 
-// complex128 -> complex64, row-packed: dst[f][n] = (float2) src[f][n], n < N
-__global__ __launch_bounds__(256) void amcx_c128_to_c64_kernel(const double2* __restrict__ src,
-                                                              long long n_frames, int N,
-                                                              long long src_stride, float2* __restrict__ dst) {
-  const long long total = n_frames * N;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const long long f = i / N;
-    const int n = (int)(i - f * N);
-    const double2 v = src[f * src_stride + n];
-    dst[i] = make_float2((float)v.x, (float)v.y);
-  }
-}
-
 }  // namespace
 
 extern "C" {
@@ -179,6 +180,7 @@ int amcx_features18_c64_ex(const void* iq_dev, int64_t n_frames, int32_t frame_s
   if (iq_dev == nullptr || out_dev == nullptr) return AMCX_EINVAL;
   if ((reinterpret_cast<uintptr_t>(iq_dev) & 7u) || (reinterpret_cast<uintptr_t>(out_dev) & 3u))
     return AMCX_EINVAL;
+  if (on_another_device(iq_dev) || on_another_device(out_dev)) return AMCX_EINVAL;
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
   const float2* iq = static_cast<const float2*>(iq_dev);
   if (v == AMCX_VARIANT_WAVE) {
@@ -218,6 +220,18 @@ struct amcx_ctx {
   void* d_in = nullptr;   size_t in_cap = 0;     // uploaded rows (complex64 or complex128)
   void* d_c64 = nullptr;  size_t c64_cap = 0;    // complex128 rows rounded to complex64
   float* d_out = nullptr; size_t out_cap = 0;
+  // strided containers (amcx_ctx_features18_strided_host): staging pool, three pinned slots, a second stream
+  amcx::Pool pool;
+  int threads = 0;                               // 0: not yet sized
+  size_t slot_bytes = size_t(32) << 20;
+  bool round_on_device = false;
+  hipStream_t copy_stream = nullptr;
+  char* pin = nullptr;     size_t pin_cap = 0;   // kPinSlots x slot
+  void* d_slab = nullptr;  size_t slab_cap = 0;  // 2 x slot: uploaded chunks
+  void* d_frames = nullptr; size_t frames_cap = 0;   // plane-major sources: the frame-major complex64 image
+  hipEvent_t up_done[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t slab_free[2] = {nullptr, nullptr};
+  amcx_upload_stats stats = {};
 };
 
 }  // extern "C"
@@ -281,7 +295,7 @@ int ctx_run(amcx_ctx* c, const void* iq_host, bool is_c128, int64_t n_frames, in
     if (e != hipSuccess) break;
     const void* d_frames = c->d_in;
     if (is_c128) {
-      hipLaunchKernelGGL(amcx_c128_to_c64_kernel, dim3(2048), dim3(256), 0, c->stream,
+      hipLaunchKernelGGL(amcx::amcx_c128_to_c64_kernel, dim3(2048), dim3(256), 0, c->stream,
                          static_cast<const double2*>(c->d_in), (long long)nf, (int)frame_size,
                          (long long)frame_size, static_cast<float2*>(c->d_c64));
       e = hipGetLastError();
@@ -297,6 +311,177 @@ int ctx_run(amcx_ctx* c, const void* iq_host, bool is_c128, int64_t n_frames, in
     if (e != hipSuccess) break;
   }
   if (rc == AMCX_OK && e != hipSuccess) rc = hip_fail(e, "amcx_ctx_features18 host entry");
+  // a failure must not leave copies into out_host or kernels on the scratch in flight behind the error code
+  if (rc != AMCX_OK) (void)hipStreamSynchronize(c->stream);
+  return rc;
+}
+
+// ---- strided host containers ----------------------------------------------------------------------
+constexpr int kPinSlots = 3;
+
+// which axis is contiguous decides how a container goes up: rows (a frame's samples contiguous) or sample
+// planes (the snr or the frame axis contiguous); false: no axis has unit stride
+bool classify_layout(int64_t S, int64_t K, int32_t N, int64_t ss, int64_t sk, int64_t sn, bool* rows,
+                     bool* inner_snr, amcx::RunMap* map) {
+  const int64_t F = S * K;
+  *rows = sn == 1;
+  *inner_snr = false;
+  if (*rows) {                        // run = one frame's N samples; run index = g = s * K + k
+    map->cnt_b = K; map->stride_a = ss; map->stride_b = sk; map->run_len = N;
+  } else if (sk == 1 && K > 1) {      // plane position j = s * K + k = g; runs of K frames
+    map->cnt_b = S; map->stride_a = sn; map->stride_b = ss; map->run_len = K;
+    if (ss == K) { map->cnt_b = 1; map->run_len = F; }          // the plane is one run
+  } else if (ss == 1 || S == 1) {     // plane position j = k * S + s; runs of S snr values
+    *inner_snr = true;
+    map->cnt_b = K; map->stride_a = sn; map->stride_b = sk; map->run_len = S;
+    if (sk == S) { map->cnt_b = 1; map->run_len = F; }
+  } else {
+    return false;
+  }
+  return true;
+}
+
+
+double wall_now() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int strided_prepare(amcx_ctx* c, size_t slot, size_t dslot, size_t frames_bytes, size_t out_bytes) {
+  if (c->threads == 0) {
+    unsigned hw = std::thread::hardware_concurrency();
+    c->threads = (int)(hw == 0 ? 4 : hw > 8 ? 8 : hw);
+  }
+  c->pool.resize(c->threads);
+  if (c->copy_stream == nullptr) AMCX_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  for (auto& ev : c->up_done) if (ev == nullptr) AMCX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  for (auto& ev : c->slab_free) if (ev == nullptr) AMCX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  if (c->pin_cap < kPinSlots * slot) {
+    if (c->pin) { (void)hipHostFree(c->pin); c->pin = nullptr; c->pin_cap = 0; }
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->pin), kPinSlots * slot, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      c->pin = nullptr;
+      return AMCX_ENOMEM;
+    }
+    c->pin_cap = kPinSlots * slot;
+  }
+  int rc = ctx_reserve(&c->d_slab, &c->slab_cap, 2 * dslot);
+  if (rc == AMCX_OK && frames_bytes) rc = ctx_reserve(&c->d_frames, &c->frames_cap, frames_bytes);
+  if (rc == AMCX_OK) rc = ctx_reserve(reinterpret_cast<void**>(&c->d_out), &c->out_cap, out_bytes);
+  return rc;
+}
+
+int ctx_run_strided(amcx_ctx* c, const void* re, const void* im, int32_t kind, int64_t S, int64_t K,
+                    int32_t N, int64_t ss, int64_t sk, int64_t sn, float* out_host, int64_t out_row_stride,
+                    int32_t variant) {
+  if (c == nullptr) return AMCX_EINVAL;
+  if (S < 0 || K < 0 || ss < 0 || sk < 0 || sn < 0 || out_row_stride < AMCX_NUM_FEATURES ||
+      kind < AMCX_SRC_C64 || kind > AMCX_SRC_F64_SPLIT)
+    return AMCX_EINVAL;
+  const int v = resolve_variant(N, variant);
+  if (v < 0) return v;
+  if (S == 0 || K == 0) return AMCX_OK;
+  if (S > (int64_t(1) << 40) / K) return AMCX_EINVAL;
+  if (re == nullptr || out_host == nullptr) return AMCX_EINVAL;
+  const int64_t F = S * K;
+  bool rows = false, inner_snr = false;
+  amcx::RunMap map;
+  if (!classify_layout(S, K, N, ss, sk, sn, &rows, &inner_snr, &map)) return AMCX_ENOTSUP;
+  const bool as_c128 = c->round_on_device && kind == AMCX_SRC_C128;
+  const size_t esz = as_c128 ? 16 : 8;
+  const size_t src_esz = kind == AMCX_SRC_C64 ? 8 : kind == AMCX_SRC_C128 ? 16 : kind == AMCX_SRC_F32_SPLIT ? 4 : 8;
+  const int64_t unit = rows ? N : F;                      // staged elements per chunk unit (a frame / a plane)
+  const int64_t n_units = rows ? F : N;
+  size_t slot = c->slot_bytes;
+  if (slot < (size_t)unit * esz) slot = (size_t)unit * esz;       // a slot holds at least one frame / one plane
+  if (slot > (size_t(4) << 30)) return AMCX_ENOMEM;               // > 4 GiB per plane: split the call by snr
+  slot = (slot + 4095) & ~size_t(4095);
+
+  DeviceGuard guard;
+  AMCX_HIP(guard.enter(c->device));
+  const double t_start = wall_now();
+  // rows of complex128 rounded on the device: each device slot is followed by room for its rounded rows
+  const size_t dslot = (rows && as_c128) ? slot + slot / 2 : slot;
+  int rc = strided_prepare(c, slot, dslot, rows ? 0 : (size_t)F * N * 8, sizeof(float) * AMCX_NUM_FEATURES * (size_t)F);
+  if (rc != AMCX_OK) return rc;
+  amcx::Source src;
+  src.re = static_cast<const char*>(re);
+  src.im = (kind >= AMCX_SRC_F32_SPLIT) ? static_cast<const char*>(im) : nullptr;
+  src.kind = kind;
+  amcx_upload_stats st = {};
+  st.frames = F; st.threads = c->pool.size(); st.plane_major = rows ? 0 : 1;
+  st.source_bytes = F * (int64_t)N * (int64_t)src_esz * ((kind >= AMCX_SRC_F32_SPLIT && src.im) ? 2 : 1);
+
+  hipError_t e = hipSuccess;
+  const int64_t units_per_slot = (int64_t)(slot / ((size_t)unit * esz));
+  int64_t u = 0;
+  for (int ch = 0; u < n_units && rc == AMCX_OK; ++ch) {
+    // the first chunks are small so that the link starts early: 1/16, 1/8, 1/4, 1/2 of a slot, then whole slots
+    int64_t take = ch < 4 ? units_per_slot >> (4 - ch) : units_per_slot;
+    if (take < 1) take = 1;
+    if (take > n_units - u) take = n_units - u;
+    const int ps = ch % kPinSlots, ds = ch & 1;
+    char* pinned = c->pin + (size_t)ps * slot;
+    char* dev = static_cast<char*>(c->d_slab) + (size_t)ds * dslot;
+    const size_t bytes = (size_t)take * (size_t)unit * esz;
+    if (ch >= kPinSlots) {                                  // the upload that last read this pinned slot is done
+      const double t0 = wall_now();
+      e = hipEventSynchronize(c->up_done[ps]);
+      st.seconds_waiting += wall_now() - t0;
+      if (e != hipSuccess) break;
+    }
+    {
+      const double t0 = wall_now();
+      // rows: run = frame g; planes: a plane is map.cnt_b runs
+      const int64_t per_unit = rows ? 1 : map.cnt_b;
+      amcx::stage_runs(c->pool, pinned, src, map, u * per_unit, (u + take) * per_unit, as_c128);
+      st.seconds_staging += wall_now() - t0;
+    }
+    if (ch >= 2) { e = hipStreamWaitEvent(c->copy_stream, c->slab_free[ds], 0); if (e != hipSuccess) break; }
+    e = hipMemcpyAsync(dev, pinned, bytes, hipMemcpyHostToDevice, c->copy_stream);
+    if (e != hipSuccess) break;
+    e = hipEventRecord(c->up_done[ps], c->copy_stream);
+    if (e != hipSuccess) break;
+    e = hipStreamWaitEvent(c->stream, c->up_done[ps], 0);
+    if (e != hipSuccess) break;
+    st.pcie_bytes += (int64_t)bytes;
+    if (rows) {
+      const void* d_rows = dev;
+      if (as_c128) {
+        float2* rounded = reinterpret_cast<float2*>(dev + slot);
+        hipLaunchKernelGGL(amcx::amcx_c128_to_c64_kernel, dim3(2048), dim3(256), 0, c->stream,
+                           reinterpret_cast<const double2*>(dev), (long long)take, (int)N, (long long)N, rounded);
+        e = hipGetLastError();
+        if (e != hipSuccess) break;
+        d_rows = rounded;
+      }
+      rc = amcx_features18_c64_ex(d_rows, take, N, N, c->d_out + (size_t)u * AMCX_NUM_FEATURES, AMCX_NUM_FEATURES,
+                                  c->stream, v);
+    } else {
+      float2* frames = static_cast<float2*>(c->d_frames);
+      e = as_c128 ? amcx::launch_pack_planes(reinterpret_cast<const double2*>(dev), (int)take, (long long)F, (long long)F,
+                                             (int)S, (long long)K, inner_snr ? 1 : 0, frames, (long long)N, (int)u, c->stream)
+                  : amcx::launch_pack_planes(reinterpret_cast<const float2*>(dev), (int)take, (long long)F, (long long)F,
+                                             (int)S, (long long)K, inner_snr ? 1 : 0, frames, (long long)N, (int)u, c->stream);
+      if (e != hipSuccess) break;
+    }
+    if (rc != AMCX_OK) break;
+    e = hipEventRecord(c->slab_free[ds], c->stream);
+    if (e != hipSuccess) break;
+    u += take;
+    st.chunks = ch + 1;
+  }
+  if (rc == AMCX_OK && e == hipSuccess && !rows)
+    rc = amcx_features18_c64_ex(c->d_frames, F, N, N, c->d_out, AMCX_NUM_FEATURES, c->stream, v);
+  if (rc == AMCX_OK && e == hipSuccess)
+    e = hipMemcpy2DAsync(out_host, sizeof(float) * (size_t)out_row_stride, c->d_out, sizeof(float) * AMCX_NUM_FEATURES,
+                         sizeof(float) * AMCX_NUM_FEATURES, (size_t)F, hipMemcpyDeviceToHost, c->stream);
+  if (rc == AMCX_OK && e != hipSuccess) rc = hip_fail(e, "amcx_ctx_features18_strided_host");
+  // success or not, nothing of this call is in flight when it returns
+  hipError_t e1 = hipStreamSynchronize(c->copy_stream), e2 = hipStreamSynchronize(c->stream);
+  if (rc == AMCX_OK && (e1 != hipSuccess || e2 != hipSuccess))
+    rc = hip_fail(e1 != hipSuccess ? e1 : e2, "amcx_ctx_features18_strided_host (sync)");
+  st.seconds = wall_now() - t_start;
+  c->stats = st;
   return rc;
 }
 
@@ -328,10 +513,90 @@ int amcx_ctx_destroy(amcx_ctx* c) {
   DeviceGuard guard;
   (void)guard.enter(c->device);
   if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+  if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+  for (auto ev : c->up_done) if (ev) (void)hipEventDestroy(ev);
+  for (auto ev : c->slab_free) if (ev) (void)hipEventDestroy(ev);
   if (c->d_in) (void)hipFree(c->d_in);
   if (c->d_c64) (void)hipFree(c->d_c64);
   if (c->d_out) (void)hipFree(c->d_out);
-  delete c;
+  if (c->d_slab) (void)hipFree(c->d_slab);
+  if (c->d_frames) (void)hipFree(c->d_frames);
+  if (c->pin) (void)hipHostFree(c->pin);
+  delete c;                                     // joins the staging threads
+  return AMCX_OK;
+}
+
+int amcx_ctx_features18_strided_host(amcx_ctx* ctx, const void* re, const void* im, int32_t kind,
+                                     int64_t n_snr, int64_t n_frames, int32_t frame_size,
+                                     int64_t stride_snr, int64_t stride_frame, int64_t stride_sample,
+                                     float* out_host, int64_t out_row_stride, int32_t variant) {
+  return ctx_run_strided(ctx, re, im, kind, n_snr, n_frames, frame_size, stride_snr, stride_frame, stride_sample,
+                         out_host, out_row_stride, variant);
+}
+
+int amcx_stage_host(const void* re, const void* im, int32_t kind, int64_t n_snr, int64_t n_frames,
+                    int32_t frame_size, int64_t stride_snr, int64_t stride_frame, int64_t stride_sample,
+                    int64_t first_unit, int64_t n_units, void* dst, int64_t dst_bytes, int32_t threads,
+                    int32_t* plane_major, int32_t* inner_snr_out) {
+  if (n_snr < 0 || n_frames < 0 || stride_snr < 0 || stride_frame < 0 || stride_sample < 0 || first_unit < 0 ||
+      n_units < 0 || threads < 0 || threads > 256 || kind < AMCX_SRC_C64 || kind > AMCX_SRC_F64_SPLIT ||
+      frame_size < AMCX_MIN_FRAME_SIZE || frame_size > AMCX_MAX_FRAME_SIZE)
+    return AMCX_EINVAL;
+  if (n_frames > 0 && n_snr > (int64_t(1) << 40) / n_frames) return AMCX_EINVAL;
+  bool rows = false, inner_snr = false;
+  amcx::RunMap map;
+  if (!classify_layout(n_snr, n_frames, frame_size, stride_snr, stride_frame, stride_sample, &rows, &inner_snr, &map))
+    return AMCX_ENOTSUP;
+  if (plane_major) *plane_major = rows ? 0 : 1;
+  if (inner_snr_out) *inner_snr_out = inner_snr ? 1 : 0;
+  const int64_t F = n_snr * n_frames, unit = rows ? frame_size : F, total_units = rows ? F : frame_size;
+  if (first_unit + n_units > total_units) return AMCX_EINVAL;
+  if (n_units == 0 || unit == 0) return AMCX_OK;
+  if (re == nullptr || dst == nullptr || dst_bytes < n_units * unit * 8) return AMCX_EINVAL;
+  amcx::Source src;
+  src.re = static_cast<const char*>(re);
+  src.im = (kind >= AMCX_SRC_F32_SPLIT) ? static_cast<const char*>(im) : nullptr;
+  src.kind = kind;
+  amcx::Pool pool;
+  pool.resize(threads < 1 ? 1 : threads);
+  const int64_t per_unit = rows ? 1 : map.cnt_b;
+  amcx::stage_runs(pool, static_cast<char*>(dst), src, map, first_unit * per_unit, (first_unit + n_units) * per_unit, false);
+  return AMCX_OK;
+}
+
+int amcx_ctx_configure(amcx_ctx* ctx, int32_t threads, int64_t slot_bytes, int32_t round_on_device) {
+  if (ctx == nullptr || threads < 0 || threads > 256 || slot_bytes < 0) return AMCX_EINVAL;
+  if (threads > 0) ctx->threads = threads;
+  if (slot_bytes > 0) ctx->slot_bytes = (size_t)slot_bytes < 4096 ? 4096 : (size_t)slot_bytes;
+  if (round_on_device >= 0) ctx->round_on_device = round_on_device != 0;
+  return AMCX_OK;
+}
+
+int amcx_ctx_upload_stats(const amcx_ctx* ctx, amcx_upload_stats* out) {
+  if (ctx == nullptr || out == nullptr) return AMCX_EINVAL;
+  *out = ctx->stats;
+  return AMCX_OK;
+}
+
+int amcx_pack_planes_c64(const void* slab_dev, int32_t src_kind, int32_t n_planes, int64_t plane_stride,
+                         int64_t n_snr, int64_t n_frames, int32_t inner_snr, void* frames_dev,
+                         int64_t row_stride_elems, int32_t n0, void* hip_stream) {
+  if (n_planes < 0 || n_snr < 0 || n_frames < 0 || n0 < 0 || (src_kind != AMCX_SRC_C64 && src_kind != AMCX_SRC_C128))
+    return AMCX_EINVAL;
+  if (n_snr > 0x7fffffffLL || (n_frames > 0 && n_snr > (int64_t(1) << 40) / n_frames)) return AMCX_EINVAL;
+  const int64_t P = n_snr * n_frames;
+  if (plane_stride < P || row_stride_elems < (int64_t)n0 + n_planes) return AMCX_EINVAL;
+  if (n_planes == 0 || P == 0) return AMCX_OK;
+  if (slab_dev == nullptr || frames_dev == nullptr) return AMCX_EINVAL;
+  if (on_another_device(slab_dev) || on_another_device(frames_dev)) return AMCX_EINVAL;
+  hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+  float2* dst = static_cast<float2*>(frames_dev);
+  hipError_t e = src_kind == AMCX_SRC_C128
+      ? amcx::launch_pack_planes(static_cast<const double2*>(slab_dev), n_planes, P, plane_stride, (int)n_snr, n_frames,
+                                 inner_snr, dst, row_stride_elems, n0, stream)
+      : amcx::launch_pack_planes(static_cast<const float2*>(slab_dev), n_planes, P, plane_stride, (int)n_snr, n_frames,
+                                 inner_snr, dst, row_stride_elems, n0, stream);
+  if (e != hipSuccess) return hip_fail(e, "amcx_pack_planes_c64");
   return AMCX_OK;
 }
 

@@ -1,0 +1,185 @@
+// Host side of the real-data path: pageable container memory -> pinned staging slots, by a small
+// persistent thread pool, in whatever order the container keeps its samples.
+//
+// The reference hands every frame to a worker thread as a numpy slice of what scipy.io.loadmat
+// returned (feature_extraction.py:46-48,64-72).  That array is pageable, complex128 and
+// Fortran-ordered; the copy engine wants pinned memory, the kernels want complex64.  One pass of
+// the staging threads does both conversions that have to happen on the host anyway: it copies
+// contiguous RUNS of the source (whole sample planes of a Fortran-ordered container, whole rows of a
+// C-ordered one) into a pinned slot and rounds doubles to float32 on the way (cvtpd2ps: round to
+// nearest even, bit-identical to numpy's astype and to the GPU's conversion), so that PCIe carries
+// 8 bytes per sample instead of 16.  MATLAB v5 files keep real and imaginary parts as two separate
+// arrays; the split kinds interleave them in the same pass, so a memory-mapped .mat goes up without
+// a complex array ever being built on the host (amcpy_amd/matfile.py).  Measured on the MI355X box
+// (profiles/r3_h2d_probe.txt): 8 threads copy pageable -> pinned at 138 GB/s, the link does 57 GB/s.
+#pragma once
+
+#include <stdint.h>
+#include <string.h>
+
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace amcx {
+
+// ---- a fork-join pool whose caller works too ----------------------------------------------------
+// run(parts, f) calls f(0..parts-1) on the workers AND the calling thread and returns when all are
+// done.  Parts are handed out one at a time, so a worker that wakes late (a condition-variable wake
+// costs tens of microseconds, a 2 MB part takes as long) simply finds less left to do.
+class Pool {
+ public:
+  ~Pool() { resize(1); }
+  int size() const { return (int)workers_.size() + 1; }
+  void resize(int n) {             // n threads in all (the caller is one of them)
+    if (n < 1) n = 1;
+    if (n == size()) return;
+    {
+      std::lock_guard<std::mutex> g(m_);
+      stop_ = true;
+    }
+    wake_.notify_all();
+    for (auto& t : workers_) t.join();
+    workers_.clear();
+    stop_ = false;
+    for (int i = 1; i < n; ++i) workers_.emplace_back([this] { loop(); });
+  }
+  void run(int parts, const std::function<void(int)>& f) {
+    if (parts <= 0) return;
+    if (workers_.empty() || parts == 1) {
+      for (int p = 0; p < parts; ++p) f(p);
+      return;
+    }
+    {
+      std::lock_guard<std::mutex> g(m_);
+      job_ = &f; parts_ = parts; next_ = 0; left_ = parts; ++gen_;
+    }
+    wake_.notify_all();
+    work();
+    std::unique_lock<std::mutex> g(m_);
+    done_.wait(g, [this] { return left_ == 0; });
+    job_ = nullptr;
+  }
+
+ private:
+  void work() {
+    for (;;) {
+      int p;
+      const std::function<void(int)>* f;
+      {
+        std::lock_guard<std::mutex> g(m_);
+        if (job_ == nullptr || next_ >= parts_) return;
+        p = next_++;
+        f = job_;
+      }
+      (*f)(p);
+      std::lock_guard<std::mutex> g(m_);
+      if (--left_ == 0) done_.notify_all();
+    }
+  }
+  void loop() {
+    unsigned long long seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> g(m_);
+        wake_.wait(g, [&] { return stop_ || gen_ != seen; });
+        if (stop_) return;
+        seen = gen_;
+      }
+      work();
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex m_;
+  std::condition_variable wake_, done_;
+  const std::function<void(int)>* job_ = nullptr;
+  int parts_ = 0, next_ = 0, left_ = 0;
+  unsigned long long gen_ = 0;
+  bool stop_ = false;
+};
+
+// ---- source description ---------------------------------------------------------------------------
+// kinds as in include/amcx.h (AMCX_SRC_*): interleaved complex64 / complex128, or split real / imaginary
+// arrays of float32 / float64 (im == nullptr: a real signal, imaginary part zero)
+struct Source {
+  const char* re = nullptr;
+  const char* im = nullptr;
+  int kind = 0;
+};
+enum { kSrcC64 = 0, kSrcC128 = 1, kSrcF32Split = 2, kSrcF64Split = 3 };
+
+// run i of the source starts at element (i / cnt_b) * stride_a + (i % cnt_b) * stride_b and is
+// run_len contiguous elements long; staged runs are packed back to back
+struct RunMap {
+  int64_t cnt_b = 1, stride_a = 0, stride_b = 0, run_len = 0;
+  int64_t offset(int64_t i) const { return (i / cnt_b) * stride_a + (i % cnt_b) * stride_b; }
+};
+
+// count elements starting at source element `off` -> dst.  as_c128: complex128 copied as it is
+// (16 bytes per element, rounded later on the device); otherwise dst is complex64.
+inline void stage_elems(char* dst, const Source& s, int64_t off, int64_t count, bool as_c128) {
+  switch (s.kind) {
+    case kSrcC64:
+      memcpy(dst, s.re + off * 8, (size_t)count * 8);
+      return;
+    case kSrcC128: {
+      if (as_c128) { memcpy(dst, s.re + off * 16, (size_t)count * 16); return; }
+      const double* __restrict__ p = reinterpret_cast<const double*>(s.re) + 2 * off;
+      float* __restrict__ q = reinterpret_cast<float*>(dst);
+      for (int64_t i = 0; i < 2 * count; ++i) q[i] = (float)p[i];
+      return;
+    }
+    case kSrcF32Split: {
+      const float* __restrict__ a = reinterpret_cast<const float*>(s.re) + off;
+      float* __restrict__ q = reinterpret_cast<float*>(dst);
+      if (s.im != nullptr) {
+        const float* __restrict__ b = reinterpret_cast<const float*>(s.im) + off;
+        for (int64_t i = 0; i < count; ++i) { q[2 * i] = a[i]; q[2 * i + 1] = b[i]; }
+      } else {
+        for (int64_t i = 0; i < count; ++i) { q[2 * i] = a[i]; q[2 * i + 1] = 0.f; }
+      }
+      return;
+    }
+    default: {
+      const double* __restrict__ a = reinterpret_cast<const double*>(s.re) + off;
+      float* __restrict__ q = reinterpret_cast<float*>(dst);
+      if (s.im != nullptr) {
+        const double* __restrict__ b = reinterpret_cast<const double*>(s.im) + off;
+        for (int64_t i = 0; i < count; ++i) { q[2 * i] = (float)a[i]; q[2 * i + 1] = (float)b[i]; }
+      } else {
+        for (int64_t i = 0; i < count; ++i) { q[2 * i] = (float)a[i]; q[2 * i + 1] = 0.f; }
+      }
+      return;
+    }
+  }
+}
+
+// runs [run0, run1) of the source, packed into dst, split over the pool at element granularity
+inline void stage_runs(Pool& pool, char* dst, const Source& s, const RunMap& m, int64_t run0, int64_t run1,
+                       bool as_c128) {
+  const int64_t total = (run1 - run0) * m.run_len;
+  if (total <= 0) return;
+  const size_t esz = as_c128 ? 16 : 8;
+  // parts of >= 256 KiB staged, about four per thread, so late wakers and slow cores even out
+  int64_t parts = pool.size() > 1 ? (int64_t)pool.size() * 4 : 1;
+  const int64_t min_elems = (int64_t)(256 * 1024 / esz);
+  if (parts > (total + min_elems - 1) / min_elems) parts = (total + min_elems - 1) / min_elems;
+  if (parts < 1) parts = 1;
+  const int64_t per = ((total + parts - 1) / parts + 63) & ~int64_t(63);
+  const std::function<void(int)> job = [&](int p) {
+    int64_t e = (int64_t)p * per;
+    const int64_t e1 = (e + per < total) ? e + per : total;
+    while (e < e1) {
+      const int64_t r = e / m.run_len, within = e - r * m.run_len;
+      int64_t n = m.run_len - within;
+      if (n > e1 - e) n = e1 - e;
+      stage_elems(dst + (size_t)e * esz, s, m.offset(run0 + r) + within, n, as_c128);
+      e += n;
+    }
+  };
+  pool.run((int)((total + per - 1) / per), job);
+}
+
+}  // namespace amcx

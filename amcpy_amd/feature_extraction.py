@@ -12,34 +12,43 @@ that loads those files is untouched.
 What is different underneath:
 * every variable of the container is decoded ONCE, by one process, one
   modulation at a time (the reference decodes the whole file in each of its six
-  child processes, feature_extraction.py:46-47);
-* there are no worker processes or threads on the compute side: a modulation's
-  frames go to the GPU in chunks through two pinned staging buffers, the gather
-  of chunk k+1 (host threads) and its upload (copy stream) overlapping the
-  kernel on chunk k.  ``scipy.io.loadmat`` hands back Fortran-ordered arrays, so
-  the ``[0:frame_size]`` slice of a frame (feature_extraction.py:68) is gathered
-  straight into the staging buffer -- no full transposed copy of the container
-  is ever made.  ``cfg.signals.num_threads`` is the number of gather threads;
+  child processes, feature_extraction.py:46-47), and the three stages overlap:
+  a reader thread decodes modulation k+1 while modulation k is on the GPU and a
+  writer thread saves k-1;
+* there are no worker processes or threads on the compute side.  A modulation goes
+  to the GPU AS IT LIES in host memory (``amcx_ctx_features18_strided_host``,
+  include/amcx.h): ``scipy.io.loadmat`` hands back Fortran-ordered arrays, in which a
+  frame's samples are ``n_snr * n_frames`` elements apart but a sample PLANE is
+  contiguous, so planes are staged into pinned memory by a few host threads
+  (``cfg.signals.num_threads``; doubles are rounded to float32 on the way, so PCIe
+  carries 8 bytes per sample), uploaded while the next planes are staged, and
+  transposed to frame-major by a device kernel.  No transposed copy of the
+  container is ever made on the host and the ``[0:frame_size]`` slice of a frame
+  (feature_extraction.py:68) is just the first ``frame_size`` planes;
 * with several ranks (one process per GPU of one node, ``torch.distributed``
   initialised by the caller) rank 0 alone decodes the container and publishes
-  each modulation's packed frames as a memory-mapped file in shared memory;
-  every rank uploads its own contiguous frame range from it over its own PCIe
-  link, and rank 0 gathers the (F x 18) rows and writes the files
-  (amcpy_amd/sharding.py).  No collective touches the IQ data;
-* a failure raises: the reference's worker threads swallow exceptions and leave
-  zero rows behind (feature_extraction.py:33-39).
+  each modulation -- the part the configuration uses, in the order it lies in
+  memory -- as a memory-mapped file in shared memory; every rank uploads its own
+  contiguous frame range from it over its own PCIe link, and rank 0 gathers the
+  (F x 18) rows and writes the files (amcpy_amd/sharding.py).  No collective
+  touches the IQ data;
+* a failure raises, on every rank: the reference's worker threads swallow
+  exceptions and leave zero rows behind (feature_extraction.py:33-39), and its
+  parent ignores the children's exit codes (:96-97).
 """
 from __future__ import annotations
 
 import os
+import socket
 import tempfile
 import time
 from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
-from typing import Callable, Optional
+from typing import Callable, Iterator, List, Optional, Tuple
 
 import numpy as np
 
+from . import _lib
 from .config import Config
 from .sharding import gather_rows, shard_range, sharded_features
 
@@ -57,13 +66,35 @@ def _rank_world():
 # ----------------------------------------------------------------------------
 # frame sources: rows of the C-order flattening (snr-major) of a container array
 # ----------------------------------------------------------------------------
+class SplitComplex:
+    """A complex ``(n_snr, n_frames, L)`` container held as two real arrays of equal shape, strides
+    and dtype (float32 / float64) -- how a MATLAB v5 file stores a complex variable, so a
+    memory-mapped .mat goes to the GPU without a complex array being built (amcpy_amd/matfile.py).
+    ``imag`` may be None (a real signal).  Indexing returns an ordinary complex ndarray."""
+
+    def __init__(self, real: np.ndarray, imag: Optional[np.ndarray]):
+        if imag is not None and (imag.shape != real.shape or imag.strides != real.strides or imag.dtype != real.dtype):
+            raise ValueError("real and imaginary parts must agree in shape, strides and dtype")
+        if real.dtype not in (np.float32, np.float64):
+            raise TypeError(f"split containers hold float32 or float64, got {real.dtype}")
+        self.real, self.imag = real, imag
+        self.shape, self.ndim = real.shape, real.ndim
+        self.dtype = np.dtype(np.complex64 if real.dtype == np.float32 else np.complex128)
+
+    def __getitem__(self, idx) -> np.ndarray:
+        out = np.asarray(self.real[idx]).astype(self.dtype)
+        if self.imag is not None:
+            out.imag = self.imag[idx]
+        return out
+
+
 class FrameRows:
     """Frames ``[lo, hi)`` of ``parsed[:n_snr, :n_frames]`` flattened snr-major
     (frame g = snr * n_frames + k, the order feature_extraction.py:64-72 enqueues
     them in), WITHOUT materialising the flattening: for the Fortran-ordered arrays
     ``loadmat`` returns, ``reshape`` would be a full transposing copy."""
 
-    def __init__(self, parsed: np.ndarray, n_snr: int, n_frames: int, lo: int = 0, hi: Optional[int] = None):
+    def __init__(self, parsed, n_snr: int, n_frames: int, lo: int = 0, hi: Optional[int] = None):
         self.parsed, self.n_snr, self.n_frames = parsed, n_snr, n_frames
         self.lo = lo
         self.hi = n_snr * n_frames if hi is None else hi
@@ -76,16 +107,29 @@ class FrameRows:
     def slice(self, lo: int, hi: int) -> "FrameRows":
         return FrameRows(self.parsed, self.n_snr, self.n_frames, self.lo + lo, self.lo + hi)
 
-    def gather(self, dst: np.ndarray, g0: int, g1: int, n: int) -> None:
-        """dst[(g1-g0), n] <- the first n samples of frames [g0, g1) of this range."""
-        a, b = self.lo + g0, self.lo + g1
-        row = 0
-        while a < b:
+    def blocks(self) -> Iterator[Tuple[int, int, int, int]]:
+        """``(s0, s1, k0, k1)`` rectangles of the (snr, frame) grid that tile ``[lo, hi)`` in order:
+        at most a partial first snr row, a run of whole rows, a partial last row."""
+        a = self.lo
+        while a < self.hi:
             s, k = divmod(a, self.n_frames)
-            take = min(b - a, self.n_frames - k)
-            np.copyto(dst[row:row + take], self.parsed[s, k:k + take, :n], casting="same_kind")
-            row += take
-            a += take
+            if k == 0 and self.hi - a >= self.n_frames:
+                m = (self.hi - a) // self.n_frames
+                yield s, s + m, 0, self.n_frames
+                a += m * self.n_frames
+            else:
+                take = min(self.hi - a, self.n_frames - k)
+                yield s, s + 1, k, k + take
+                a += take
+
+    def gather(self, dst: np.ndarray, g0: int, g1: int, n: int) -> None:
+        """dst[(g1-g0), n] <- the first n samples of frames [g0, g1) of this range (host copy:
+        tests and injected engines; the production engine never calls it)."""
+        row = 0
+        for s0, s1, k0, k1 in self.slice(g0, g1).blocks():
+            for s in range(s0, s1):
+                np.copyto(dst[row:row + k1 - k0], self.parsed[s, k0:k1, :n], casting="same_kind")
+                row += k1 - k0
 
     def to_array(self) -> np.ndarray:
         out = np.empty(self.shape, dtype=self.dtype)
@@ -93,135 +137,121 @@ class FrameRows:
         return out
 
 
-class _ArrayRows:
-    """The same interface over a plain (F, L) array or memmap."""
-
-    def __init__(self, arr: np.ndarray):
-        self.arr, self.dtype, self.shape = arr, arr.dtype, arr.shape
-
-    def gather(self, dst, g0, g1, n):
-        np.copyto(dst, self.arr[g0:g1, :n], casting="same_kind")
-
-
-_POOL: Optional[ThreadPoolExecutor] = None
-_POOL_SIZE = 0
-
-
-def _gather_parallel(rows, dst: np.ndarray, g0: int, g1: int, n: int, threads: int) -> None:
-    """rows.gather split over host threads (numpy releases the GIL inside copyto)."""
-    global _POOL, _POOL_SIZE
-    count = g1 - g0
-    threads = max(1, min(threads, count // 64 if count >= 128 else 1))
-    if threads == 1:
-        rows.gather(dst, g0, g1, n)
-        return
-    if _POOL is None or _POOL_SIZE < threads:
-        if _POOL is not None:
-            _POOL.shutdown(wait=True)
-        _POOL, _POOL_SIZE = ThreadPoolExecutor(max_workers=threads, thread_name_prefix="amcx-gather"), threads
-    per = -(-count // threads)
-    futs = [_POOL.submit(rows.gather, dst[a:min(count, a + per)], g0 + a, g0 + min(count, a + per), n)
-            for a in range(0, count, per)]
-    for f in futs:
-        f.result()
+def _native_source(arr):
+    """(keepalive, re_ptr, im_ptr, kind, element strides, bytes per element) of a container the
+    native engine can read in place, or None if it has to be copied first."""
+    if isinstance(arr, SplitComplex):
+        re, im = arr.real, arr.imag
+        kind = _lib.SRC_F32_SPLIT if re.dtype == np.float32 else _lib.SRC_F64_SPLIT
+    elif isinstance(arr, np.ndarray) and arr.dtype in (np.complex64, np.complex128, np.float32, np.float64):
+        re, im = arr, None
+        kind = {np.dtype(np.complex64): _lib.SRC_C64, np.dtype(np.complex128): _lib.SRC_C128,
+                np.dtype(np.float32): _lib.SRC_F32_SPLIT, np.dtype(np.float64): _lib.SRC_F64_SPLIT}[arr.dtype]
+    else:
+        return None
+    item = re.itemsize
+    if any(st < 0 or st % item for st in re.strides):
+        return None
+    return (re, im), re.ctypes.data, (None if im is None else im.ctypes.data), kind, [st // item for st in re.strides], item
 
 
 # ----------------------------------------------------------------------------
-# host frames -> HBM -> features: the double-buffered upload pipeline
+# host container -> HBM -> features: the native upload pipeline
 # ----------------------------------------------------------------------------
 class HipEngine:
     """``engine(frames) -> (F, 18) float32`` through device memory.
 
-    ``frames`` is an (F, L) complex array / memmap or a :class:`FrameRows`.  Two slots,
-    each one pinned host buffer + one device buffer, are reused for every chunk and every
-    call: while the kernel runs on slot k the host threads gather chunk k+1 into the other
-    slot's pinned buffer and the copy stream uploads it.  Ordering is by events, not by
-    allocator stream tracking: a slot's pinned buffer is rewritten only after its last upload
-    has finished, its device buffer only after the kernel that read it has.  A complex128
-    container (MATLAB doubles) is uploaded as is and rounded to complex64 on the GPU
-    (PCIe moves 16 B/sample faster than a host ``astype`` produces 8 B/sample).
-    ``stats`` of the last call: bytes uploaded, seconds, frames."""
+    ``frames`` is an (F, L) array / memmap, or a :class:`FrameRows` over an (n_snr, n_frames, L)
+    container in any memory order (ndarray or :class:`SplitComplex`).  The container is read where it
+    lies by ``amcx_ctx_features18_strided_host``: host threads stage contiguous runs -- sample planes
+    of a Fortran-ordered container, rows of a C-ordered one -- into three pinned slots (rounding
+    doubles to float32 on the way), the copy engine drains them, a device kernel transposes planes to
+    frame-major, the feature kernel runs, the (F x 18) result comes back.  ``chunk_bytes`` is the size
+    of one pinned slot, ``threads`` the staging threads (the reference's ``num_threads``).
+    ``stats`` of the last call: frames, seconds, bytes over PCIe, source bytes, chunks, threads."""
 
-    def __init__(self, frame_size: int, device: Optional[int] = None, chunk_bytes: int = 256 << 20,
-                 threads: Optional[int] = None):
-        import torch
+    def __init__(self, frame_size: int, device: Optional[int] = None, chunk_bytes: int = 32 << 20,
+                 threads: Optional[int] = None, round_on_device: bool = False):
         self.N = int(frame_size)
-        self.dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        if device is None:
+            device = 0
+            try:
+                import torch
+                if torch.cuda.is_available():
+                    device = torch.cuda.current_device()
+            except Exception:
+                pass
+        self.device = int(device)
         self.chunk_bytes = int(chunk_bytes)
-        self.threads = max(1, min(threads or 8, os.cpu_count() or 1))
-        self._slots = {}            # torch dtype -> list of slot dicts
-        self._copy_stream = None
+        self.threads = max(1, min(int(threads or 8), os.cpu_count() or 1))
+        self.round_on_device = bool(round_on_device)
+        self._ctx: Optional[_lib.HostContext] = None
         self.stats = {}
 
-    def _ring(self, tdtype, rows: int):
-        import torch
-        ring = self._slots.get(tdtype)
-        if ring is None or ring[0]["host"].shape[0] < rows:
-            ring = []
-            for _ in range(2):
-                slot = {"host": torch.empty((rows, self.N), dtype=tdtype, pin_memory=True),
-                        "dev": torch.empty((rows, self.N), dtype=tdtype, device=self.dev),
-                        "uploaded": torch.cuda.Event(), "consumed": torch.cuda.Event()}
-                if tdtype != torch.complex64:
-                    slot["c64"] = torch.empty((rows, self.N), dtype=torch.complex64, device=self.dev)
-                ring.append(slot)
-            self._slots[tdtype] = ring
-        return ring
+    def _context(self) -> "_lib.HostContext":
+        if self._ctx is None:
+            self._ctx = _lib.HostContext(self.device)
+            self._ctx.configure(self.threads, self.chunk_bytes, int(self.round_on_device))
+        return self._ctx
+
+    def _run_block(self, src, base_elems: int, n_snr: int, n_frames: int, strides, out: np.ndarray) -> None:
+        keep, re_ptr, im_ptr, kind, _, item = src
+        ctx = self._context()
+        ctx.run_strided(re_ptr + base_elems * item, None if im_ptr is None else im_ptr + base_elems * item,
+                        kind, n_snr, n_frames, self.N, strides, out)
+        st = ctx.upload_stats()
+        for k in ("frames", "source_bytes", "pcie_bytes", "chunks", "seconds_staging", "seconds_waiting"):
+            self.stats[k] = self.stats.get(k, 0) + st[k]
+        self.stats["gather_threads"], self.stats["plane_major"] = st["threads"], st["plane_major"]
 
     def __call__(self, frames) -> np.ndarray:
-        import torch
-        from .features import features18
-
-        rows = frames if hasattr(frames, "gather") else _ArrayRows(np.asarray(frames))
+        if isinstance(frames, FrameRows):
+            rows = frames
+        else:
+            arr = frames if isinstance(frames, SplitComplex) else np.asarray(frames)
+            if arr.ndim != 2:
+                raise ValueError(f"expected (F, L) frames, got shape {arr.shape}")
+            rows = FrameRows(arr[None] if not isinstance(arr, SplitComplex) else
+                             SplitComplex(arr.real[None], None if arr.imag is None else arr.imag[None]),
+                             1, arr.shape[0])
         F, L = rows.shape
         if L < self.N:
             raise ValueError(f"rows of {L} samples are shorter than frame_size {self.N}")
         if F == 0:
             return np.empty((0, 18), dtype=np.float32)
-        if rows.dtype == np.complex64:
-            tdtype = torch.complex64
-        else:                       # doubles, or real / integer samples: staged as complex128
-            tdtype = torch.complex128
-        itemsize = 8 if tdtype == torch.complex64 else 16
-        per = max(1, min(F, self.chunk_bytes // (self.N * itemsize)))
-        with torch.cuda.device(self.dev):
-            ring = self._ring(tdtype, per)
-            if self._copy_stream is None:
-                self._copy_stream = torch.cuda.Stream(device=self.dev)
-            copy_stream, main = self._copy_stream, torch.cuda.current_stream(self.dev)
-            out = torch.empty((F, 18), dtype=torch.float32, device=self.dev)
-            t0 = time.perf_counter()
-            for k, f0 in enumerate(range(0, F, per)):
-                f1 = min(F, f0 + per)
-                n = f1 - f0
-                slot = ring[k & 1]
-                slot["uploaded"].synchronize()             # its pinned buffer is free again
-                _gather_parallel(rows, slot["host"][:n].numpy(), f0, f1, self.N, self.threads)
-                with torch.cuda.stream(copy_stream):
-                    copy_stream.wait_event(slot["consumed"])   # the kernel that read the device buffer is done
-                    slot["dev"][:n].copy_(slot["host"][:n], non_blocking=True)
-                    slot["uploaded"].record(copy_stream)
-                main.wait_event(slot["uploaded"])
-                x = slot["dev"][:n]
-                if tdtype != torch.complex64:
-                    slot["c64"][:n].copy_(x)               # round-to-nearest-even, on the GPU
-                    x = slot["c64"][:n]
-                features18(x, out=out[f0:f1])
-                slot["consumed"].record(main)
-            host_out = out.cpu().numpy()                    # synchronises the main stream
-            self.stats = {"frames": F, "seconds": time.perf_counter() - t0,
-                          "bytes_uploaded": F * self.N * itemsize, "chunks": -(-F // per),
-                          "gather_threads": self.threads}
-        return host_out
+        t0 = time.perf_counter()
+        self.stats = {}
+        parsed = rows.parsed
+        src = _native_source(parsed)
+        if src is not None:
+            st = src[4]
+            unit = [st[2] == 1, st[1] == 1 and rows.n_frames > 1, st[0] == 1 or rows.n_snr == 1]
+            if not any(unit):
+                src = None
+        if src is None:
+            # integer / half / exotic dtypes, negative or sub-element strides, no contiguous axis: one
+            # C-ordered copy of the part that is used, then the row path
+            block = np.ascontiguousarray(rows.to_array(), dtype=np.complex64 if rows.dtype == np.complex64 else np.complex128)
+            rows = FrameRows(block[None], 1, F)
+            src = _native_source(rows.parsed)
+        ss, sk, sn = src[4]
+        out = np.empty((F, 18), dtype=np.float32)
+        row = 0
+        for s0, s1, k0, k1 in rows.blocks():
+            n = (s1 - s0) * (k1 - k0)
+            self._run_block(src, s0 * ss + k0 * sk, s1 - s0, k1 - k0, (ss, sk, sn), out[row:row + n])
+            row += n
+        self.stats["seconds"] = time.perf_counter() - t0
+        self.stats["bytes_uploaded"] = self.stats.get("pcie_bytes", 0)
+        return out
+
+    def close(self) -> None:
+        if self._ctx is not None:
+            self._ctx.close()
+            self._ctx = None
 
 
-def _hip_compute(frame_size: int, device: Optional[int], chunk_bytes: int = 256 << 20,
-                 threads: Optional[int] = None) -> Callable:
-    """The production engine (kept under its round-1 name for callers that pass it on)."""
-    return HipEngine(frame_size, device, chunk_bytes, threads)
-
-
-def _check_container(parsed: np.ndarray, cfg: Config):
+def _check_container(parsed, cfg: Config):
     n_snr = len(cfg.signals.snr_values)
     n_frames = cfg.signals.num_frames
     N = cfg.signals.frame_size
@@ -257,9 +287,9 @@ def extract_raw_stream(path, frame_size: int, *, skip_samples: int = 0, max_fram
     float32 I/Q, no header -- what the reference's legacy reader takes with
     ``np.fromfile(..., dtype=np.complex64)`` and a fixed number of leading samples dropped,
     old/read_binary_stream.py:28,48,54-56).  The file is memory-mapped and cut into
-    consecutive ``frame_size``-sample frames (a trailing partial frame is dropped); frames go
-    up chunk by chunk through the same pinned, overlapped path as ``run_extraction``, so
-    the file never has to fit in host memory.  Returns ``(n_frames, 18)`` float32."""
+    consecutive ``frame_size``-sample frames (a trailing partial frame is dropped); the staging
+    threads read the mapping slot by slot, so the file never has to fit in host memory.
+    Returns ``(n_frames, 18)`` float32."""
     if frame_size < 2:
         raise ValueError("frame_size must be >= 2")
     if skip_samples < 0:
@@ -276,49 +306,49 @@ def extract_raw_stream(path, frame_size: int, *, skip_samples: int = 0, max_fram
     return np.asarray(fn(frames), dtype=np.float32)
 
 
-class _PairRows:
-    """Frame source over a dataset of float32 (I, Q) pairs shaped (F, L, 2) that supports slicing --
-    a numpy array / memmap or an ``h5py.Dataset`` (RadioML-2018.01A's ``X``: 2 555 904 x 1024 x 2,
-    reference old/dataset.py:50-56).  The pairs are bit-identical to complex64, so a chunk is read
-    (h5py decodes it from the file) and re-viewed, never converted."""
-
-    def __init__(self, dataset, lo: int = 0, hi: Optional[int] = None):
-        shape = tuple(dataset.shape)
-        if len(shape) != 3 or shape[2] != 2:
-            raise ValueError(f"expected an (F, L, 2) dataset of (I, Q) pairs, got shape {shape}")
-        if np.dtype(dataset.dtype) != np.float32:
-            raise TypeError(f"(I, Q) pairs must be float32, got {dataset.dtype}")
-        self.ds, self.lo = dataset, lo
-        self.hi = shape[0] if hi is None else hi
-        self.dtype = np.dtype(np.complex64)
-        self.shape = (self.hi - self.lo, shape[1])
-
-    def gather(self, dst, g0, g1, n):
-        blk = np.ascontiguousarray(self.ds[self.lo + g0:self.lo + g1])          # (g, L, 2) float32
-        np.copyto(dst, blk.view(np.complex64)[..., 0][:, :n])
+def _pairs_as_complex(block: np.ndarray) -> np.ndarray:
+    """(g, L, 2) float32 -> (g, L) complex64 view (bit-identical layouts); copies only if the pairs
+    are not interleaved in memory."""
+    if block.strides[-1] != 4 or block.strides[-2] != 8:
+        block = np.ascontiguousarray(block)
+    return block.view(np.complex64)[..., 0]
 
 
 def extract_iq_pairs(dataset, frame_size: Optional[int] = None, *, first_frame: int = 0,
-                     max_frames: Optional[int] = None, compute=None, device: Optional[int] = None) -> np.ndarray:
+                     max_frames: Optional[int] = None, compute=None, device: Optional[int] = None,
+                     chunk_frames: Optional[int] = None) -> np.ndarray:
     """Features of frames stored as float32 (I, Q) pairs, ``dataset[f, n] = (I, Q)`` -- RadioML's
     ``(F, 1024, 2)`` layout (reference old/dataset.py:50-56, old/dataset_analysis.py:22).  ``dataset``
-    is anything sliceable with ``.shape`` and ``.dtype`` (numpy array, memmap, h5py.Dataset); frames go
-    up chunk by chunk through the pinned, overlapped path, so the set never has to fit in host memory.
-    Returns ``(n_frames, 18)`` float32."""
-    F, L = int(dataset.shape[0]), int(dataset.shape[1])
+    is anything sliceable with ``.shape`` and ``.dtype``.  A numpy array or memmap is re-viewed as
+    complex64 and goes up in one native call; any other dataset (an ``h5py.Dataset``, which decodes
+    chunks from the file as they are sliced) is read ``chunk_frames`` at a time by a reader thread one
+    chunk ahead of the upload, so the set never has to fit in host memory.  Returns ``(n_frames, 18)``
+    float32."""
+    shape = tuple(dataset.shape)
+    if len(shape) != 3 or shape[2] != 2:
+        raise ValueError(f"expected an (F, L, 2) dataset of (I, Q) pairs, got shape {shape}")
+    if np.dtype(dataset.dtype) != np.float32:
+        raise TypeError(f"(I, Q) pairs must be float32, got {dataset.dtype}")
+    F, L = int(shape[0]), int(shape[1])
     N = L if frame_size is None else int(frame_size)
     if N < 2 or N > L:
         raise ValueError(f"frame_size {N} outside 2 .. {L}")
     lo = min(max(0, int(first_frame)), F)
     hi = F if max_frames is None else min(F, lo + int(max_frames))
-    rows = _PairRows(dataset, lo, hi)
     if hi <= lo:
         return np.empty((0, 18), dtype=np.float32)
     if compute is not None:                       # injected engine (tests): plain (F, N) arrays
-        block = np.empty((hi - lo, N), dtype=np.complex64)
-        rows.gather(block, 0, hi - lo, N)
+        block = np.ascontiguousarray(_pairs_as_complex(np.asarray(dataset[lo:hi]))[:, :N])
         return np.asarray(compute(block), dtype=np.float32)
-    return HipEngine(N, device)(rows)
+    engine = HipEngine(N, device)
+    if isinstance(dataset, np.ndarray):
+        return engine(_pairs_as_complex(dataset[lo:hi]))
+    step = int(chunk_frames or max(1, (256 << 20) // (L * 8)))
+    spans = [(a, min(hi, a + step)) for a in range(lo, hi, step)]
+    out = np.empty((hi - lo, 18), dtype=np.float32)
+    for (a, b), fut in _prefetched(spans, lambda ab: _pairs_as_complex(np.asarray(dataset[ab[0]:ab[1]]))):
+        out[a - lo:b - lo] = engine(fut.result())
+    return out
 
 
 def extract_radioml_hdf5(path, *, key: str = "X", frame_size: Optional[int] = None, first_frame: int = 0,
@@ -338,35 +368,86 @@ def extract_radioml_hdf5(path, *, key: str = "X", frame_size: Optional[int] = No
 # ----------------------------------------------------------------------------
 # run_extraction
 # ----------------------------------------------------------------------------
-def _shared_dir() -> Path:
-    """Where rank 0 publishes packed frames for the other ranks of the node: /dev/shm
-    (page cache, no disk) when it exists, the temp dir otherwise."""
-    shm = Path("/dev/shm")
-    return shm if shm.is_dir() and os.access(shm, os.W_OK) else Path(tempfile.gettempdir())
+def _prefetched(items: List, fn: Callable):
+    """``(item, future)`` pairs with ``fn(item)`` running on a reader thread ONE item ahead of the
+    consumer: while the caller works on item k, item k+1 is being read / decoded."""
+    with ThreadPoolExecutor(max_workers=1, thread_name_prefix="amcx-reader") as ex:
+        nxt = ex.submit(fn, items[0]) if items else None
+        for i, it in enumerate(items):
+            cur = nxt
+            nxt = ex.submit(fn, items[i + 1]) if i + 1 < len(items) else None
+            yield it, cur
 
 
-def _publish_packed(rows: FrameRows, N: int, threads: int) -> Path:
-    """Rank 0: frames -> a packed (F, N) .npy in shared memory, source dtype kept."""
-    F = rows.shape[0]
-    fd, name = tempfile.mkstemp(prefix="amcx_frames_", suffix=".npy", dir=str(_shared_dir()))
+def _shared_dir(need_bytes: int) -> Path:
+    """Where rank 0 publishes a modulation for the other ranks of the node: /dev/shm (page cache, no
+    disk) when it has room, the temp dir otherwise.  Writing a sparse tmpfs file past the mount's
+    capacity raises SIGBUS, not an exception, so room is checked BEFORE the file is mapped (a
+    container's default /dev/shm is 64 MB; a configs[1] modulation is 3.5 GB)."""
+    for cand in (Path("/dev/shm"), Path(tempfile.gettempdir())):
+        try:
+            if cand.is_dir() and os.access(cand, os.W_OK):
+                st = os.statvfs(cand)
+                if st.f_bavail * st.f_frsize >= need_bytes + (64 << 20):
+                    return cand
+        except OSError:
+            continue
+    raise OSError(f"neither /dev/shm nor {tempfile.gettempdir()} has {need_bytes / 1e9:.2f} GB free to publish a "
+                  "modulation to the other ranks")
+
+
+def _copy_parallel(dst: np.ndarray, src, threads: int) -> None:
+    """dst <- src over host threads, split along the slowest axis of dst (numpy releases the GIL in copyto)."""
+    axis = int(np.argmax(dst.strides))
+    n = dst.shape[axis]
+    threads = max(1, min(threads, n))
+    idx = [slice(None)] * dst.ndim
+
+    def part(a, b):
+        sl = list(idx)
+        sl[axis] = slice(a, b)
+        np.copyto(dst[tuple(sl)], src[tuple(sl)], casting="same_kind")
+
+    if threads == 1:
+        part(0, n)
+        return
+    per = -(-n // threads)
+    with ThreadPoolExecutor(max_workers=threads, thread_name_prefix="amcx-publish") as ex:
+        for f in [ex.submit(part, a, min(n, a + per)) for a in range(0, n, per)]:
+            f.result()
+
+
+def _publish_container(parsed, n_snr: int, n_frames: int, N: int, threads: int) -> Path:
+    """Rank 0: the part of the container the configuration uses -> an .npy in shared memory, IN THE
+    MEMORY ORDER IT HAS (Fortran for what loadmat returns: the copy is a run of contiguous planes,
+    no transposition), source dtype kept."""
+    used = parsed[:n_snr, :n_frames, :N]                 # a view (ndarray) or the assembled part (SplitComplex)
+    dtype = used.dtype if used.dtype in (np.complex64, np.complex128) else np.dtype(np.complex128)
+    fortran = used.strides[0] < used.strides[2]
+    need = n_snr * n_frames * N * dtype.itemsize
+    fd, name = tempfile.mkstemp(prefix="amcx_frames_", suffix=".npy", dir=str(_shared_dir(need)))
     os.close(fd)
-    dtype = rows.dtype if rows.dtype in (np.complex64, np.complex128) else np.dtype(np.complex128)
-    mm = np.lib.format.open_memmap(name, mode="w+", dtype=dtype, shape=(F, N))
-    step = max(1, (64 << 20) // (N * dtype.itemsize))
-    for g0 in range(0, F, step):
-        g1 = min(F, g0 + step)
-        _gather_parallel(rows, mm[g0:g1], g0, g1, N, threads)
-    mm.flush()
-    del mm
+    try:
+        mm = np.lib.format.open_memmap(name, mode="w+", dtype=dtype, shape=(n_snr, n_frames, N), fortran_order=fortran)
+        _copy_parallel(mm, used, threads)
+        mm.flush()
+        del mm
+    except BaseException:
+        Path(name).unlink(missing_ok=True)
+        raise
     return Path(name)
 
 
-def _load_variable(mat_path: Path, key: str) -> np.ndarray:
-    import scipy.io
-    data = scipy.io.loadmat(str(mat_path), variable_names=[key])
-    if key not in data:
-        raise KeyError(f"{mat_path} has no variable {key!r}")
-    return np.asarray(data[key])
+def _load_variable(mat_path: Path, key: str):
+    from .matfile import load_variable
+    return load_variable(mat_path, key)
+
+
+def _same_host(world: int) -> bool:
+    import torch.distributed as dist
+    hosts = [None] * world
+    dist.all_gather_object(hosts, socket.gethostname())
+    return len(set(hosts)) == 1
 
 
 def run_extraction(cfg: Config, *, compute=None, device: Optional[int] = None, verbose: bool = True) -> None:
@@ -380,52 +461,109 @@ def run_extraction(cfg: Config, *, compute=None, device: Optional[int] = None, v
     N = cfg.signals.frame_size
     threads = max(1, int(cfg.signals.num_threads))
     engine = compute if compute is not None else HipEngine(N, device, threads=threads)
-    for mod in cfg.signals.modulations_with_noise:
-        t0 = time.perf_counter()
-        key = cfg.signals.mat_info[mod]
-        feats = None
+    mods = list(cfg.signals.modulations_with_noise)
+    t_start = time.perf_counter()
+
+    def run(rows: FrameRows) -> np.ndarray:
+        if rows.shape[0] == 0:
+            return np.empty((0, 18), dtype=np.float32)
+        mat = engine(rows) if compute is None else compute(rows.to_array())
+        return np.asarray(mat, dtype=np.float32)
+
+    def save(mod: str, key: str, feats: np.ndarray, t0: float) -> None:
+        out_path = cfg.paths.calculated_features / f"{mod}_features.mat"
+        scipy.io.savemat(str(out_path), {"Modulation": mod, key: feats})
+        if verbose:
+            print(f"[{mod}] {feats.shape[0] * feats.shape[1]} frames in "
+                  f"{time.perf_counter() - t0:.2f}s -> {out_path}")
+
+    writer = ThreadPoolExecutor(max_workers=1, thread_name_prefix="amcx-writer") if rank == 0 else None
+    writes = []
+    published: List[Path] = []          # rank 0: shared files not yet removed
+    feed = None
+    try:
         if world == 1:
-            parsed = _load_variable(mat_path, key)          # one variable at a time: bounded host memory
-            n_snr, n_frames, _ = _check_container(parsed, cfg)
-            rows = FrameRows(parsed, n_snr, n_frames)
-            mat = engine(rows) if compute is None else compute(rows.to_array())
-            feats = np.asarray(mat, dtype=np.float32).reshape(n_snr, n_frames, 18)
-            del parsed, rows
+            feed = _prefetched(mods, lambda m: _load_variable(mat_path, cfg.signals.mat_info[m]))
+            for mod, fut in feed:
+                t0 = time.perf_counter()
+                key = cfg.signals.mat_info[mod]
+                parsed = fut.result()                   # one variable at a time (two while the next decodes)
+                n_snr, n_frames, _ = _check_container(parsed, cfg)
+                feats = run(FrameRows(parsed, n_snr, n_frames)).reshape(n_snr, n_frames, 18)
+                del parsed
+                writes.append(writer.submit(save, mod, key, feats, t0))
         else:
             import torch.distributed as dist
-            meta = [None]
-            if rank == 0:
+            shared_host = _same_host(world)
+
+            def decode_and_publish(mod):                # rank 0's reader thread
+                parsed = _load_variable(mat_path, cfg.signals.mat_info[mod])
+                n_snr, n_frames, _ = _check_container(parsed, cfg)
+                path = _publish_container(parsed, n_snr, n_frames, N, threads)
+                published.append(path)
+                return str(path), n_snr, n_frames
+
+            def decode_locally(mod):                    # ranks on different hosts: as the reference's children do
+                parsed = _load_variable(mat_path, cfg.signals.mat_info[mod])
+                n_snr, n_frames, _ = _check_container(parsed, cfg)
+                return parsed, n_snr, n_frames
+
+            if not shared_host:
+                feed = _prefetched(mods, decode_locally)
+            elif rank == 0:
+                feed = _prefetched(mods, decode_and_publish)
+            else:
+                feed = ((m, None) for m in mods)
+            for mod, fut in feed:
+                t0 = time.perf_counter()
+                key = cfg.signals.mat_info[mod]
+                # 1. the modulation: every rank learns where it is, or that rank 0 could not read it
+                meta, parsed = [None], None
+                if shared_host:
+                    if rank == 0:
+                        try:
+                            meta = [("ok",) + fut.result()]
+                        except Exception as exc:        # every rank must leave the collective
+                            meta = [("error", repr(exc), 0, 0)]
+                    dist.broadcast_object_list(meta, src=0)
+                    status, shared, n_snr, n_frames = meta[0]
+                    if status != "ok":
+                        raise RuntimeError(f"rank 0 could not read {key!r} from {mat_path}: {shared}")
+                # 2. this rank's frame range; a failure is kept until every rank has reported
+                local, failure = None, None
                 try:
-                    parsed = _load_variable(mat_path, key)
-                    n_snr, n_frames, _ = _check_container(parsed, cfg)
-                    shared = _publish_packed(FrameRows(parsed, n_snr, n_frames), N, threads)
-                    del parsed
-                    meta = [("ok", str(shared), n_snr, n_frames)]
-                except Exception as exc:                    # every rank must leave the collective
-                    meta = [("error", repr(exc), 0, 0)]
-            dist.broadcast_object_list(meta, src=0)
-            status, shared, n_snr, n_frames = meta[0]
-            if status != "ok":
-                raise RuntimeError(f"rank 0 could not read {key!r} from {mat_path}: {shared}")
-            try:
-                packed = np.load(shared, mmap_mode="r")
-                F = n_snr * n_frames
-                lo, hi = shard_range(F, rank, world)
-                local = (np.asarray(engine(packed[lo:hi]), dtype=np.float32) if hi > lo
-                         else np.empty((0, 18), dtype=np.float32))
-                del packed
-                mat = gather_rows(local, F, rank, world)
-            finally:
-                dist.barrier()                              # everyone has unmapped the file
-                if rank == 0:
+                    if shared_host:
+                        parsed = np.load(shared, mmap_mode="r")
+                    else:
+                        parsed, n_snr, n_frames = fut.result()
+                    F = n_snr * n_frames
+                    lo, hi = shard_range(F, rank, world)
+                    local = run(FrameRows(parsed, n_snr, n_frames, lo, hi))
+                except Exception as exc:
+                    failure = f"{type(exc).__name__}: {exc}"
+                del parsed
+                # 3. one status word per rank BEFORE the data collective: all ranks raise together
+                # (the all-gather is also the point after which nobody maps the shared file any more)
+                statuses = [None] * world
+                dist.all_gather_object(statuses, failure)
+                if shared_host and rank == 0:
                     Path(shared).unlink(missing_ok=True)
-            if rank == 0:
-                feats = mat.reshape(n_snr, n_frames, 18)
-        if rank == 0:
-            out_path = cfg.paths.calculated_features / f"{mod}_features.mat"
-            scipy.io.savemat(str(out_path), {"Modulation": mod, key: feats})
-            if verbose:
-                print(f"[{mod}] {feats.shape[0] * feats.shape[1]} frames in "
-                      f"{time.perf_counter() - t0:.2f}s -> {out_path}")
+                    published.remove(Path(shared))
+                bad = [(r, s) for r, s in enumerate(statuses) if s is not None]
+                if bad:
+                    raise RuntimeError(f"feature extraction of {mod!r} failed on " +
+                                       "; ".join(f"rank {r}: {s}" for r, s in bad))
+                mat = gather_rows(local, F, rank, world)
+                if rank == 0:
+                    writes.append(writer.submit(save, mod, key, mat.reshape(n_snr, n_frames, 18), t0))
+        for w in writes:
+            w.result()                                  # a failed savemat raises here
+    finally:
+        if feed is not None and hasattr(feed, "close"):
+            feed.close()                                # waits for a decode / publish still in flight
+        if writer is not None:
+            writer.shutdown(wait=True)
+        for path in list(published):
+            Path(path).unlink(missing_ok=True)
     if verbose and rank == 0:
-        print("All feature calculations complete!")
+        print(f"All feature calculations complete! ({time.perf_counter() - t_start:.2f}s)")

@@ -28,23 +28,33 @@ def shard_range(n_frames: int, rank: int, world: int) -> Tuple[int, int]:
 def gather_rows(local: np.ndarray, n_frames: int, rank: int, world: int, group=None) -> Optional[np.ndarray]:
     """Collect every rank's (n_local, 18) block on rank 0 as (n_frames, 18).
 
-    Uses ``torch.distributed.gather_object`` on whatever backend the caller
-    initialised (RCCL for GPU jobs, gloo in the CPU tests): at 72 bytes per
-    frame this is a latency-bound host-side step, not a bandwidth one.
-    Returns the full matrix on rank 0 and None elsewhere."""
+    One ``torch.distributed.gather`` of float32 tensors, each rank's block padded to the common
+    ``ceil(F / W)`` rows -- a plain copy (92 MB per rank at BASELINE configs[3]), not a pickle -- on
+    whatever backend the caller initialised: device tensors over RCCL for GPU jobs, host tensors
+    over gloo in the CPU tests.  Returns the full matrix on rank 0 and None elsewhere."""
     if world == 1:
         return local
+    import torch
     import torch.distributed as dist
-    parts = [None] * world if rank == 0 else None
-    dist.gather_object(np.ascontiguousarray(local), parts, dst=0, group=group)
+    cols = local.shape[1]
+    per = -(-n_frames // world) if n_frames else 0
+    lo, hi = shard_range(n_frames, rank, world)
+    if local.shape[0] != hi - lo:
+        raise RuntimeError(f"rank {rank} holds {local.shape[0]} rows for [{lo}, {hi})")
+    on_gpu = "nccl" in str(dist.get_backend(group)).lower()
+    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    mine = torch.zeros((per, cols), dtype=torch.float32, device=dev)
+    if hi > lo:
+        mine[:hi - lo].copy_(torch.from_numpy(np.ascontiguousarray(local, dtype=np.float32)))
+    parts = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+    dist.gather(mine, parts, dst=0, group=group)
     if rank != 0:
         return None
-    out = np.empty((n_frames, local.shape[1]), dtype=local.dtype)
+    out = np.empty((n_frames, cols), dtype=np.float32)
     for r, blk in enumerate(parts):
-        lo, hi = shard_range(n_frames, r, world)
-        if blk.shape[0] != hi - lo:
-            raise RuntimeError(f"rank {r} returned {blk.shape[0]} rows for [{lo}, {hi})")
-        out[lo:hi] = blk
+        a, b = shard_range(n_frames, r, world)
+        if b > a:
+            out[a:b] = blk[:b - a].cpu().numpy()
     return out
 
 

@@ -230,6 +230,16 @@ def _pmc_traffic(frames_per_launch: int, frame_size: int):
     return best, src
 
 
+def _parity_block():
+    """Replayed from the committed sweep (tests/manual/parity_sweep.py on the GPU box, builder-run), NOT measured
+    in this run -- the live parity gate is `pytest -m gpu`."""
+    for name in ("r3_parity_summary.json", "r2_parity_summary.json"):
+        d = _committed_json(name)
+        if d is not None:
+            return {"source": f"profiles/{name} (committed; replayed, not measured in this run)", **d}
+    return None
+
+
 def _committed_json(name: str):
     p = REPO / "profiles" / name
     try:
@@ -238,33 +248,77 @@ def _committed_json(name: str):
         return None
 
 
-def h2d_path(dev, frame_size: int = FRAME_SIZE):
-    """The real-data upload path (run_extraction's engine) on a configs[0]-shaped complex128
-    container held the way scipy.io.loadmat returns it (Fortran order): gather -> pinned ->
-    HBM -> round to complex64 -> kernel -> D2H of the (F x 18) result.  Reported beside the
-    headline, never as `value`."""
+def _fortran_container(n_snr, n_frames, N, seed=7):
+    """A complex128 (n_snr, n_frames, N) array in Fortran order, as scipy.io.loadmat returns the reference's
+    variables; random bits, tiled from a 64 MB block (the upload rate does not depend on the values)."""
     import numpy as np
-    import torch
+    rng = np.random.default_rng(seed)
+    total = n_snr * n_frames * N
+    block = (rng.standard_normal(min(total, 1 << 22)) + 1j * rng.standard_normal(min(total, 1 << 22)))
+    flat = np.empty(total, dtype=np.complex128)
+    for a in range(0, total, block.size):
+        flat[a:a + block.size] = block[:min(block.size, total - a)]
+    return flat.reshape((n_snr, n_frames, N), order="F")
+
+
+def h2d_path(dev, frame_size: int = FRAME_SIZE, big: bool = True):
+    """The real-data upload path (run_extraction's engine, amcx_ctx_features18_strided_host) on complex128
+    containers held the way scipy.io.loadmat returns them (Fortran order, pageable memory): host threads
+    stage sample planes into pinned slots and round them to complex64 -> H2D -> device transposition ->
+    feature kernel -> D2H of the (F x 18) result.  Reported beside the headline, never as `value`."""
+    import shutil
+    import tempfile
+    import numpy as np
     from amcpy_amd.feature_extraction import FrameRows, HipEngine
     n_mods, n_snr, n_frames, N = CPU_SAMPLE[0], CPU_SAMPLE[1], CPU_SAMPLE[2], frame_size
-    rng = np.random.default_rng(7)
-    parsed = np.asfortranarray((rng.standard_normal((n_snr, n_frames, N)) +
-                                1j * rng.standard_normal((n_snr, n_frames, N))))
-    eng = HipEngine(N, dev.index, chunk_bytes=64 << 20)
-    rows = FrameRows(parsed, n_snr, n_frames)
-    eng(rows)                                             # warm: pinned + device slots, kernels
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(n_mods):                               # six modulations, as run_extraction loops
-        eng(rows)
-    wall = time.perf_counter() - t0
-    frames = n_mods * n_snr * n_frames
-    nbytes = frames * N * 16
-    return {"GBps": nbytes / wall / 1e9, "frames_per_s": frames / wall, "seconds": wall,
-            "what": f"HipEngine on {n_mods} x ({n_snr}, {n_frames}, {N}) complex128 Fortran-ordered arrays "
-                    f"(BASELINE configs[0] as loadmat returns it): threaded gather -> pinned -> H2D -> round to "
-                    f"complex64 on the GPU -> kernel -> D2H; {eng.stats.get('gather_threads')} gather threads, "
-                    f"{eng.stats.get('chunks')} chunk(s) per modulation; loadmat/savemat not included"}
+
+    def timed(eng, rows, reps):
+        eng(rows)                                         # warm: pinned + device slots, kernels
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            eng(rows)
+        wall = time.perf_counter() - t0
+        F = rows.shape[0]
+        return {"GBps": reps * F * N * 16 / wall / 1e9, "pcie_GBps": reps * eng.stats["pcie_bytes"] / wall / 1e9,
+                "frames_per_s": reps * F / wall, "seconds": wall, "chunks_per_call": eng.stats["chunks"],
+                "staging_threads": eng.stats["gather_threads"],
+                "caller_staging_s": eng.stats["seconds_staging"], "caller_waiting_s": eng.stats["seconds_waiting"]}
+
+    small = FrameRows(_fortran_container(n_snr, n_frames, N), n_snr, n_frames)
+    rec = timed(HipEngine(N, dev.index), small, n_mods)      # six modulations, as run_extraction loops
+    rec["what"] = (f"HipEngine on {n_mods} x ({n_snr}, {n_frames}, {N}) complex128 Fortran-ordered arrays (BASELINE "
+                   f"configs[0] as loadmat returns it), GBps = container bytes / wall: planes staged + rounded to "
+                   f"complex64 by host threads -> pinned -> H2D -> device transposition -> kernel -> D2H; "
+                   f"loadmat/savemat not included")
+    rec["round_on_device"] = timed(HipEngine(N, dev.index, round_on_device=True), small, n_mods)
+    rec["round_on_device"]["what"] = "same, doubles sent over PCIe as they are and rounded by the device kernel"
+    if big:
+        rows = FrameRows(_fortran_container(N_SNR, N_FRAMES, N), N_SNR, N_FRAMES)
+        rec["configs1_modulation"] = timed(HipEngine(N, dev.index), rows, 2)
+        rec["configs1_modulation"]["what"] = (f"one BASELINE configs[1] modulation, ({N_SNR}, {N_FRAMES}, {N}) complex128 "
+                                              f"Fortran-ordered = {N_SNR * N_FRAMES * N * 16 / 1e9:.2f} GB, twice")
+        del rows
+    # the whole drop-in on configs[0]: .mat in (memory-mapped, not decoded), six .mat out
+    try:
+        import scipy.io
+        from amcpy_amd.config import Config, Paths, SignalConfig
+        from amcpy_amd.feature_extraction import run_extraction
+        root = Path(tempfile.mkdtemp(prefix="amcx_bench_", dir="/dev/shm" if Path("/dev/shm").is_dir() else None))
+        try:
+            cfg = Config(paths=Paths(root=root), signals=SignalConfig(snr_values={0: "0", 1: "10"}, num_frames=n_frames,
+                                                                     frame_size=N))
+            cfg.paths.ensure_dirs()
+            scipy.io.savemat(str(cfg.paths.mat_data / cfg.paths.mat_filename),
+                             {cfg.signals.mat_info[m]: np.asarray(small.parsed) for m in cfg.signals.modulations_with_noise})
+            run_extraction(cfg, device=dev.index, verbose=False)
+            t0 = time.perf_counter()
+            run_extraction(cfg, device=dev.index, verbose=False)
+            rec["run_extraction_configs0_seconds"] = time.perf_counter() - t0
+        finally:
+            shutil.rmtree(root, ignore_errors=True)
+    except Exception as exc:                               # reported, never fatal to the headline
+        rec["run_extraction_configs0_seconds"] = f"failed: {exc!r}"
+    return rec
 
 
 def _valu_note_r1(frames_per_s: float):
@@ -295,7 +349,7 @@ def _valu_note(frames_per_s: float):
         return _valu_note_r1(frames_per_s)
     per_frame = b.get("valu_instr_per_frame")
     out = {"bound": b.get("bound", "board power, then VALU issue"), "valu_instr_per_frame": per_frame,
-           "source": "profiles/r2_wave_budget.json"}
+           "source": "profiles/r2_wave_budget.json (committed; replayed, not measured in this run)"}
     if per_frame:
         out["achieved_Gwaveinstr_per_s"] = per_frame * frames_per_s / 1e9
     for k in ("in_kernel_clock_GHz", "in_kernel_clock_zeros_GHz", "simd_cycles_per_frame",
@@ -314,10 +368,17 @@ def _ensure_library(local_rank: int):
             b.build(force=False, verbose=False)          # rebuilds only if sources are newer (build.stale)
         elif not b.LIB.exists():
             raise SystemExit("libamcx.so is missing and hipcc is not available")
+        b.LIB.with_suffix(".ready").touch()
         return
+    # other ranks: wait until local rank 0 has finished (a stale library must not be loaded while it is
+    # being replaced): rank 0 touches the stamp file when its build() has returned
     deadline = time.time() + 300
-    while not b.LIB.exists() and time.time() < deadline:     # appears atomically (build.py renames)
-        time.sleep(1.0)
+    stamp = b.LIB.with_suffix(".ready")
+    while time.time() < deadline:
+        if b.LIB.exists() and stamp.exists() and stamp.stat().st_mtime >= b.LIB.stat().st_mtime and not b.stale():
+            return
+        time.sleep(0.5)
+    raise SystemExit("libamcx.so was not (re)built by local rank 0 within 300 s")
 
 
 def _config_label(frame_size, n_frames, n_mods, world):
@@ -336,8 +397,10 @@ def _config_label(frame_size, n_frames, n_mods, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=700,
+                    help="untimed steps first; the default (~2.5 s of launches) lets the board's power cap settle "
+                         "the clock before timing (profiles/r2_sustained.txt)")
     ap.add_argument("--frames", type=int, default=N_FRAMES, help="frames per (mod, SNR) block")
     ap.add_argument("--mods", type=int, default=N_MODS,
                     help="modulations per GPU (configs[4]: 24 over 8 GPUs = 3 with --frame-size 1024)")
@@ -351,6 +414,12 @@ def main():
     ap.add_argument("--cpu-procs", type=int, default=None)
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="timed CPU work per worker after warm-up")
     ap.add_argument("--no-h2d", action="store_true", help="skip the real-data upload-path measurement")
+    ap.add_argument("--no-h2d-big", action="store_true", help="skip the 3.5 GB configs[1]-sized modulation of it")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for the timing barrier / MAX (gloo: rehearsals where RCCL cannot "
+                         "run, e.g. two ranks sharing one GPU)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal: ranks take device local_rank %% device_count instead of one GPU each")
     args = ap.parse_args()
     FS = args.frame_size
 
@@ -374,8 +443,9 @@ def main():
     from amcpy_amd import _lib, synth
     from amcpy_amd.features import features18
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % max(1, torch.cuda.device_count()) if args.share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     use_dist = world > 1 or "RANK" in os.environ        # launched by torch.distributed.run
     # stdout carries exactly one JSON line: RCCL prints a version banner to fd 1 when the
     # communicator comes up, so everything until the final print goes to stderr instead
@@ -385,7 +455,10 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     # ---- resident shard: (mods, snr, frames, N) complex64 arena in HBM --------
     n_mods = args.mods
@@ -420,19 +493,39 @@ def main():
     wall = time.perf_counter() - t0
     launch_ms = [a.elapsed_time(b) for a, b in ev]
     if use_dist:
-        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        t = torch.tensor([wall], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
 
-    # the same step with the (F x 18) result brought to the host: launch + kernels + D2H, wall clock
-    host_out = torch.empty(out.shape, dtype=torch.float32, pin_memory=True)
-    step(); host_out.copy_(out); torch.cuda.synchronize()
+    # the same step with the (F x 18) result brought to the host every step: two result buffers, the copy of
+    # step k on a second stream while step k+1 computes (46 MB at ~28 GB/s hides behind a 3.5 ms launch)
+    outs = [out, torch.empty_like(out)]
+    hosts = [torch.empty(out.shape, dtype=torch.float32, pin_memory=True) for _ in range(2)]
+    main_stream, copy_stream = torch.cuda.current_stream(), torch.cuda.Stream(device=dev)
+    computed = [torch.cuda.Event() for _ in range(2)]
+    copied = [torch.cuda.Event() for _ in range(2)]
+
+    def step_with_d2h(k):
+        b = k & 1
+        main_stream.wait_event(copied[b])                 # the copy that last read this buffer is done
+        features18(arena, out=outs[b], variant=args.variant)
+        computed[b].record(main_stream)
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(computed[b])
+            hosts[b].copy_(outs[b], non_blocking=True)
+            copied[b].record(copy_stream)
+
+    for k in range(4):
+        step_with_d2h(k)
+    torch.cuda.synchronize()
     t1 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        host_out.copy_(out, non_blocking=True)
+    for k in range(args.steps):
+        step_with_d2h(k)
     torch.cuda.synchronize()
     wall_d2h_ms = (time.perf_counter() - t1) / args.steps * 1e3
+    assert torch.equal(hosts[(args.steps - 1) & 1].view(torch.int32), out.cpu().view(torch.int32)), \
+        "double-buffered D2H delivered a different result"
+    del outs, hosts
 
     # sanity: the timed output is finite
     assert torch.isfinite(out[0, N_SNR // 2, :64]).all(), "non-finite features in the timed output"
@@ -456,7 +549,9 @@ def main():
 
     h2d = None
     if rank == 0 and world == 1 and not args.no_h2d:
-        h2d = h2d_path(dev)
+        del arena
+        torch.cuda.empty_cache()
+        h2d = h2d_path(dev, big=not args.no_h2d_big)
 
     if use_dist:
         dist.barrier()
@@ -467,6 +562,7 @@ def main():
     total_frames = frames_per_launch * world * args.steps
     value = total_frames / wall
     mean_launch_s = sum(launch_ms) / len(launch_ms) * 1e-3
+    srt = sorted(launch_ms)
     alg_bytes = (8 * FS + 72) * frames_per_launch
     traffic, traffic_src = _pmc_traffic(frames_per_launch, FS)
     achieved = alg_bytes / mean_launch_s / 1e9
@@ -489,12 +585,15 @@ def main():
             "frac": achieved / HBM_PEAK_GBPS,
             "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_ms": mean_launch_s * 1e3,
+            # the spread tells a slow box (all three shift) from a disturbed run (max far from median)
+            "launch_ms_min": srt[0], "launch_ms_median": srt[len(srt) // 2], "launch_ms_max": srt[-1],
+            "frac_at_min": alg_bytes / (srt[0] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             "measured_read_peak_GBps": read_peak,
             "secondary": _valu_note(value / world) if FS == FRAME_SIZE else None,
         },
         "wall_incl_d2h_ms": wall_d2h_ms,
         "h2d": h2d,
-        "parity": _committed_json("r2_parity_summary.json"),
+        "parity": _parity_block(),
         "cpu_baseline": cpu,
         "cpu_baseline_reference_shaped": cpu_ref_shaped,
     }

@@ -42,6 +42,13 @@
  *     fp32 ulp of +-pi, -inf = outside the fp32 range -- and the kernels amcx_range_wave_kernel
  *     or amcx_range_fixup_kernel, then amcx_fixup_kernel, rewrite them.  A consumer on ANOTHER
  *     stream that reads `out_dev` between the launches sees those marks; order it after the whole call (event / stream sync), as usual.
+ *   - DEVICE OWNERSHIP: the entry points that take device pointers launch on the calling thread's
+ *     CURRENT HIP device.  The buffers and the stream must belong to it: on a multi-GPU node call
+ *     hipSetDevice(d) (torch.cuda.set_device / `with torch.cuda.device(d)`) first.  A pointer
+ *     that lives on another device is refused with AMCX_EINVAL (checked with
+ *     hipPointerGetAttributes; a stream cannot be checked: passing another device's stream is a
+ *     HIP launch error, AMCX_EHIP).  The host-buffer entries take a device index and switch to it
+ *     themselves for the duration of the call.
  *   - re-entrant and thread-safe; launches are asynchronous on `hip_stream`
  *     (a hipStream_t, NULL = default stream); completion = caller's stream sync.
  *     The device entry points allocate nothing and never synchronise, so after one
@@ -56,7 +63,13 @@
 extern "C" {
 #endif
 
-#define AMCX_ABI_VERSION 1
+/* ABI version policy: the number goes up by one whenever entry points or constants are ADDED;
+ * nothing that exists is ever removed or changes meaning under the same library name, so a binding
+ * written against version v works with every library whose amcx_abi_version() >= v (and must
+ * refuse an older one).  History: 1 = round 1-2 (features18, host / context entries, post kernels);
+ * 2 = strided containers (amcx_ctx_features18_strided_host, amcx_stage_host, amcx_pack_planes_c64,
+ * amcx_ctx_configure, amcx_ctx_upload_stats), device-ownership rule below made explicit. */
+#define AMCX_ABI_VERSION 2
 #define AMCX_NUM_FEATURES 18
 
 /* error codes */
@@ -161,6 +174,90 @@ int amcx_ctx_features18_c128_host(amcx_ctx* ctx, const void* iq_host, int64_t n_
  * AMCX_ENOTSUP / AMCX_EINVAL.
  */
 int amcx_kernel_name(int32_t frame_size, int32_t variant, char* buf, int32_t buf_len);
+
+/*
+ * The real-data path: all 18 features of every frame of a HOST container indexed
+ * [snr][frame][sample] with ARBITRARY element strides -- what the reference slices frame by frame
+ * out of the array scipy.io.loadmat returned (feature_extraction.py:46-48,64-72: Fortran-ordered,
+ * complex128, rows longer than frame_size).  Frame g = snr * n_frames + frame, the order the
+ * reference enqueues them in; out_host[g * out_row_stride + j] = feature j + 1.
+ *
+ *   kind      AMCX_SRC_C64 / AMCX_SRC_C128: `re` points at interleaved (re, im) float32 / float64,
+ *             `im` is ignored.  AMCX_SRC_F32_SPLIT / AMCX_SRC_F64_SPLIT: `re` and `im` are two
+ *             separate real arrays with the same strides (how a MATLAB v5 file stores a complex
+ *             variable; im == NULL: a real signal).  Doubles are rounded to float32 to nearest even
+ *             (== numpy astype), by the staging threads on their way to pinned memory.
+ *   strides   in ELEMENTS of the source (complex elements for the interleaved kinds), all >= 0.
+ *             One of them must be 1:
+ *               stride_sample == 1 (C order)        rows go up in chunks of whole frames and the
+ *                                                   kernel runs on chunk k while chunk k+1 uploads;
+ *               stride_snr == 1 or stride_frame == 1 (Fortran order, as loadmat returns it)
+ *                                                   contiguous sample planes go up as they lie and
+ *                                                   a device kernel transposes them to frame-major
+ *                                                   (amcx_pack_planes_c64); the feature kernel runs
+ *                                                   once, after the last plane.
+ *             Otherwise AMCX_ENOTSUP (make a contiguous copy first).
+ *
+ * Pageable memory is fine (that is the point): a pool of host threads copies runs into three pinned
+ * slots while the copy engine drains them -- ~55 GB/s of PCIe, i.e. ~110 GB/s of complex128 source.
+ * Blocks until out_host is complete.  One context per thread.
+ */
+#define AMCX_SRC_C64 0
+#define AMCX_SRC_C128 1
+#define AMCX_SRC_F32_SPLIT 2
+#define AMCX_SRC_F64_SPLIT 3
+int amcx_ctx_features18_strided_host(amcx_ctx* ctx, const void* re, const void* im, int32_t kind,
+                                     int64_t n_snr, int64_t n_frames, int32_t frame_size,
+                                     int64_t stride_snr, int64_t stride_frame, int64_t stride_sample,
+                                     float* out_host, int64_t out_row_stride, int32_t variant);
+
+/*
+ * The host half on its own (no device involved; works without a GPU): stage `n_units` units of the
+ * container, starting at `first_unit`, into `dst` as packed complex64, with `threads` host threads.
+ * A unit is a frame (row-major containers: dst[unit][sample]) or a sample plane (plane-major:
+ * dst[unit][position], position order as amcx_pack_planes_c64's inner_snr says); *plane_major and
+ * *inner_snr report which (either may be NULL).  For callers that run their own copy engine -- and
+ * how the staging and rounding logic is tested where there is no GPU.
+ */
+int amcx_stage_host(const void* re, const void* im, int32_t kind, int64_t n_snr, int64_t n_frames,
+                    int32_t frame_size, int64_t stride_snr, int64_t stride_frame, int64_t stride_sample,
+                    int64_t first_unit, int64_t n_units, void* dst, int64_t dst_bytes, int32_t threads,
+                    int32_t* plane_major, int32_t* inner_snr);
+
+/*
+ * Tuning of a context's upload path: threads = staging threads including the caller's (0 = keep;
+ * default min(8, hardware threads); the reference's SignalConfig.num_threads maps here),
+ * slot_bytes = size of one pinned staging slot (0 = keep; default 32 MiB; three are allocated),
+ * round_on_device != 0: complex128 goes over PCIe as it is and is rounded by the device kernel
+ * (twice the link bytes, no host arithmetic; -1 = keep).
+ */
+int amcx_ctx_configure(amcx_ctx* ctx, int32_t threads, int64_t slot_bytes, int32_t round_on_device);
+
+/* what the last strided call of this context moved, and where its host time went */
+typedef struct amcx_upload_stats {
+  int64_t frames;
+  int64_t source_bytes;     /* bytes of the container that were read */
+  int64_t pcie_bytes;       /* bytes that crossed the link host -> device */
+  int32_t chunks;
+  int32_t threads;
+  int32_t plane_major;      /* 1: planes + device transposition, 0: rows */
+  int32_t reserved;
+  double seconds;           /* whole call */
+  double seconds_staging;   /* caller thread inside the staging copies */
+  double seconds_waiting;   /* caller thread blocked on a pinned slot still being uploaded */
+} amcx_upload_stats;
+int amcx_ctx_upload_stats(const amcx_ctx* ctx, amcx_upload_stats* out);
+
+/*
+ * The device half of the plane-major path, for callers that do their own uploads: slab_dev holds
+ * n_planes sample planes, plane r = sample n0 + r of every position j < n_snr * n_frames at
+ * slab_dev[r * plane_stride + j] (complex64 if src_kind == AMCX_SRC_C64, complex128 rounded here if
+ * AMCX_SRC_C128).  inner_snr != 0: j = frame * n_snr + snr (Fortran order); 0: j = snr * n_frames +
+ * frame.  Writes frames_dev[g * row_stride_elems + n0 + r], g = snr * n_frames + frame.
+ */
+int amcx_pack_planes_c64(const void* slab_dev, int32_t src_kind, int32_t n_planes, int64_t plane_stride,
+                         int64_t n_snr, int64_t n_frames, int32_t inner_snr, void* frames_dev,
+                         int64_t row_stride_elems, int32_t n0, void* hip_stream);
 
 /*
  * Streaming-read ceiling probe: sums n_bytes of device memory with 16-byte

@@ -851,12 +851,14 @@ def test_plain_c_client_computes_the_same_features(tmp_path):
 
 
 def test_upload_pipeline_many_chunks_equals_one_launch():
-    """HipEngine with chunks far smaller than the data (dozens of trips round its two pinned / device
-    slots, ragged last chunk), from a Fortran-ordered complex128 container with rows longer than the
-    frame, from a complex64 memmap-like array, and twice in a row (slots reused across calls): every
-    row equals the one-launch result on the same frames, bit for bit."""
+    """HipEngine (amcx_ctx_features18_strided_host) with pinned slots far smaller than the data (dozens of
+    trips round its three pinned / two device slots, ragged last chunk): from a Fortran-ordered complex128
+    container with more frames and longer rows than the configuration uses (sample planes + device
+    transposition), from the same container in C order (rows), as two real arrays (a memory-mapped .mat),
+    rounded on the host or on the device, from a complex64 array, and twice in a row (slots reused across
+    calls): every row equals the one-launch result on the same frames, bit for bit."""
     torch = _torch()
-    from amcpy_amd.feature_extraction import FrameRows, HipEngine
+    from amcpy_amd.feature_extraction import FrameRows, HipEngine, SplitComplex
     from amcpy_amd.features import features18
     rng = np.random.default_rng(17)
     n_snr, n_frames, L, N = 3, 211, 300, 256
@@ -864,19 +866,39 @@ def test_upload_pipeline_many_chunks_equals_one_launch():
     parsed = np.asfortranarray(full)                                  # as scipy.io.loadmat returns it
     flat = full[:, :n_frames, :N].reshape(-1, N)
     want128 = features18(torch.from_numpy(flat).cuda().to(torch.complex64)).cpu().numpy()
-    eng = HipEngine(N, chunk_bytes=37 * N * 16, threads=4)            # 37 frames per chunk: 18 chunks, the last ragged
+    F = n_snr * n_frames
+    eng = HipEngine(N, chunk_bytes=7 * F * 8, threads=4)              # 7 planes per slot: ramp 1, 1, 1, 3, then 7s
     rows = FrameRows(parsed, n_snr, n_frames)
     for _ in range(2):
         got = eng(rows)
-        assert eng.stats["chunks"] == 18 and got.shape == (n_snr * n_frames, 18)
+        assert eng.stats["chunks"] >= 30 and eng.stats["plane_major"] == 1 and got.shape == (F, 18)
+        assert eng.stats["pcie_bytes"] == F * N * 8 and eng.stats["source_bytes"] == F * N * 16
         assert np.array_equal(got, want128, equal_nan=True)
-    part = eng(rows.slice(100, 433))                                  # a rank's contiguous range
+    part = eng(rows.slice(100, 433))                                  # a rank's contiguous range: three rectangles
     assert np.array_equal(part, want128[100:433], equal_nan=True)
+    dev_round = HipEngine(N, chunk_bytes=5 * F * 16, threads=2, round_on_device=True)
+    assert np.array_equal(dev_round(rows), want128, equal_nan=True) and dev_round.stats["pcie_bytes"] == F * N * 16
+    split = SplitComplex(np.asfortranarray(full.real), np.asfortranarray(full.imag))        # as matfile.py maps it
+    assert np.array_equal(eng(FrameRows(split, n_snr, n_frames)), want128, equal_nan=True)
+    # C order: rows go up in chunks of whole frames, the kernel runs per chunk
+    row_eng = HipEngine(N, chunk_bytes=37 * N * 8, threads=3)
+    got = row_eng(FrameRows(full, n_snr, n_frames))
+    assert row_eng.stats["plane_major"] == 0 and row_eng.stats["chunks"] >= 18
+    assert np.array_equal(got, want128, equal_nan=True)
+    assert np.array_equal(HipEngine(N, chunk_bytes=29 * N * 24, round_on_device=True)(FrameRows(full, n_snr, n_frames)),
+                          want128, equal_nan=True)
     x64 = flat.astype(np.complex64)
     want64 = features18(torch.from_numpy(x64).cuda()).cpu().numpy()
     got64 = HipEngine(N, chunk_bytes=50 * N * 8)(x64)                 # complex64 goes up as it is
     assert np.array_equal(got64, want64, equal_nan=True)
-    assert np.array_equal(want64, want128, equal_nan=True)            # GPU rounding of doubles == numpy's astype
+    assert np.array_equal(want64, want128, equal_nan=True)            # host / GPU rounding of doubles == numpy's astype
+    assert np.array_equal(eng(x64[::-1]), want64[::-1], equal_nan=True)       # negative stride: copied first
+    # a layout with no contiguous axis, and an integer container: one host copy, then the row path
+    strided = np.asfortranarray(np.repeat(full, 2, axis=0))[::2]
+    assert np.array_equal(eng(FrameRows(strided[:, :, :], n_snr, n_frames)), want128, equal_nan=True)
+    ints = np.round(full.real * 100).astype(np.int16)
+    want_int = features18(torch.from_numpy(ints[:, :n_frames, :N].reshape(-1, N).astype(np.complex64)).cuda()).cpu().numpy()
+    assert np.array_equal(eng(FrameRows(np.asfortranarray(ints), n_snr, n_frames)), want_int, equal_nan=True)
     assert HipEngine(N)(x64[:0]).shape == (0, 18)
 
 

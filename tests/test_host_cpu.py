@@ -276,7 +276,7 @@ def test_config_mirror_equals_reference_defaults():
 def test_frame_rows_gathers_fortran_ordered_containers():
     """loadmat returns Fortran-ordered arrays; FrameRows must deliver the snr-major flattening of
     parsed[:n_snr, :n_frames, :N] chunk by chunk without a full reshape copy."""
-    from amcpy_amd.feature_extraction import FrameRows, _gather_parallel
+    from amcpy_amd.feature_extraction import FrameRows
     rng = np.random.default_rng(3)
     full = (rng.standard_normal((3, 300, 40)) + 1j * rng.standard_normal((3, 300, 40)))
     parsed = np.asfortranarray(full)                      # (n_snr+1, n_frames+..., L) as loadmat gives it
@@ -286,8 +286,12 @@ def test_frame_rows_gathers_fortran_ordered_containers():
     assert rows.shape == (n_snr * n_frames, 40) and np.array_equal(rows.to_array(), want)
     for (g0, g1) in [(0, 1), (255, 265), (100, 520), (0, 520)]:      # chunks that straddle an snr row
         dst = np.empty((g1 - g0, N), dtype=np.complex128)
-        _gather_parallel(rows, dst, g0, g1, N, threads=4)
+        rows.gather(dst, g0, g1, N)
         assert np.array_equal(dst, want[g0:g1, :N])
+        # the rectangles the native engine is called on tile the range in order
+        tiles = list(rows.slice(g0, g1).blocks())
+        flat = [s * n_frames + k for s0, s1, k0, k1 in tiles for s in range(s0, s1) for k in range(k0, k1)]
+        assert flat == list(range(g0, g1)) and len(tiles) <= 3
     part = rows.slice(250, 400)                           # a rank's contiguous range
     dst = np.empty((150, N), dtype=np.complex64)          # narrowing cast on the way is allowed
     part.gather(dst, 0, 150, N)
@@ -328,7 +332,7 @@ _EXTRACT_WORKER = textwrap.dedent('''
 
 def test_two_rank_run_extraction_rank0_decodes_and_publishes(tmp_path):
     """run_extraction with two ranks over gloo: rank 0 loads the .mat (once per variable) and
-    publishes packed frames through shared memory, both ranks compute their shard, rank 0 writes
+    publishes each modulation through shared memory in the memory order it has, both ranks compute their shard, rank 0 writes
     files equal to the single-process result; the shared files are removed afterwards."""
     import glob
     import scipy.io
@@ -349,7 +353,7 @@ def test_two_rank_run_extraction_rank0_decodes_and_publishes(tmp_path):
         return (base[:, None] * np.arange(1, 19)[None, :]).astype(np.float32)
 
     fe.run_extraction(cfg1, compute=compute, verbose=False)
-    before = set(glob.glob(str(fe._shared_dir() / "amcx_frames_*")))
+    before = set(glob.glob(str(fe._shared_dir(0) / "amcx_frames_*")))
     script = tmp_path / "extract_worker.py"
     script.write_text(_EXTRACT_WORKER)
     port = _free_port()
@@ -362,7 +366,7 @@ def test_two_rank_run_extraction_rank0_decodes_and_publishes(tmp_path):
     outs = [p.communicate(timeout=180)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "EXTRACT_OK 0 6 66" in outs[0] and "EXTRACT_OK 1 0 60" in outs[1], outs
-    assert set(glob.glob(str(fe._shared_dir() / "amcx_frames_*"))) == before, "shared frame files left behind"
+    assert set(glob.glob(str(fe._shared_dir(0) / "amcx_frames_*"))) == before, "shared frame files left behind"
     for m in cfg.signals.modulations_with_noise:
         a = scipy.io.loadmat(str(cfg1.paths.calculated_features / f"{m}_features.mat"))
         b = scipy.io.loadmat(str(cfg.paths.calculated_features / f"{m}_features.mat"))
@@ -393,7 +397,7 @@ def test_iq_pair_dataset_framing(tmp_path):
     """extract_iq_pairs: an (F, L, 2) float32 dataset (RadioML layout, reference old/dataset.py:50-56) is
     re-viewed as complex64 frames chunk by chunk; works on anything sliceable (here: a memmap and a
     minimal h5py.Dataset look-alike); the engine is stubbed."""
-    from amcpy_amd.feature_extraction import extract_iq_pairs, extract_radioml_hdf5, _PairRows
+    from amcpy_amd.feature_extraction import extract_iq_pairs, extract_radioml_hdf5, _pairs_as_complex
     rng = np.random.default_rng(2)
     pairs = rng.standard_normal((50, 64, 2)).astype(np.float32)
     want = pairs[..., 0] + 1j * pairs[..., 1]
@@ -420,10 +424,9 @@ def test_iq_pair_dataset_framing(tmp_path):
         out = extract_iq_pairs(ds, 32, first_frame=5, max_frames=20, compute=compute)
         assert out.shape == (20, 18) and out.dtype == np.float32
         assert seen[0].dtype == np.complex64 and np.array_equal(seen[0], want[5:25, :32])
-    rows = _PairRows(FakeDataset(), 10, 40)
-    dst = np.empty((7, 64), dtype=np.complex64)
-    rows.gather(dst, 3, 10, 64)
-    assert np.array_equal(dst, want[13:20])
+    view = _pairs_as_complex(pairs[13:20])
+    assert view.base is not None and np.array_equal(view, want[13:20])          # a view, not a copy
+    assert np.array_equal(_pairs_as_complex(np.asfortranarray(pairs[13:20])), want[13:20])
     assert extract_iq_pairs(pairs, compute=compute, first_frame=60).shape == (0, 18)
     with pytest.raises(ValueError):
         extract_iq_pairs(pairs[..., :1], compute=compute)
@@ -434,3 +437,192 @@ def test_iq_pair_dataset_framing(tmp_path):
     except ImportError:
         with pytest.raises(ImportError, match="h5py"):
             extract_radioml_hdf5(tmp_path / "missing.hdf5")
+
+
+# ----------------------------------------------------------------------------
+# round 3: the memory-mapped .mat reader, the native staging threads, collective-safe failures
+# ----------------------------------------------------------------------------
+def test_mat_reader_returns_views_equal_to_loadmat(tmp_path):
+    """amcpy_amd/matfile.py on level-5 files as scipy.io.savemat writes them (the reference's input,
+    feature_extraction.py:46-48): complex128 / complex64 / real variables, compressed or not, come
+    back as Fortran-ordered views of the mapping (no decode) equal to what loadmat returns; what the
+    fast reader does not take on falls through to scipy; a missing variable is a KeyError."""
+    import scipy.io
+    from amcpy_amd.feature_extraction import SplitComplex
+    from amcpy_amd.matfile import _Unsupported, load_variable, read_variable_v5
+    rng = np.random.default_rng(21)
+    c128 = rng.standard_normal((3, 5, 40)) + 1j * rng.standard_normal((3, 5, 40))
+    box = {"signal_bpsk": c128, "signal_qpsk": c128.astype(np.complex64) * 2, "just_real": c128.real.copy(),
+           "ints": np.arange(24, dtype=np.int16).reshape(2, 3, 4), "text": "hello"}
+    for compress in (False, True):
+        path = tmp_path / f"box_{int(compress)}.mat"
+        scipy.io.savemat(str(path), box, do_compression=compress)
+        ref = scipy.io.loadmat(str(path))
+        for key in ("signal_bpsk", "signal_qpsk"):
+            got = load_variable(path, key)
+            assert isinstance(got, SplitComplex) and got.shape == (3, 5, 40) and got.dtype == ref[key].dtype
+            assert got.real.flags.f_contiguous and not got.real.flags.writeable and not got.real.flags.owndata
+            assert np.array_equal(got[:, :, :], ref[key]) and np.array_equal(got[1, 2:4, :7], ref[key][1, 2:4, :7])
+        real = load_variable(path, "just_real")
+        assert isinstance(real, np.ndarray) and real.dtype == np.float64 and np.array_equal(real, ref["just_real"])
+        with pytest.raises(_Unsupported):
+            read_variable_v5(path, "ints")                       # int16 storage: not the fast reader's business
+        assert np.array_equal(load_variable(path, "ints"), ref["ints"])           # ... scipy's
+        with pytest.raises(KeyError):
+            load_variable(path, "signal_nope")
+    junk = tmp_path / "junk.mat"
+    junk.write_bytes(b"not a mat file at all" * 20)
+    with pytest.raises(Exception):
+        load_variable(junk, "x")
+    with pytest.raises(FileNotFoundError):
+        load_variable(tmp_path / "absent.mat", "x")
+
+
+def _stage(arr_re, arr_im, kind, S, K, N, strides, first, count, threads=3):
+    import ctypes as C
+    from amcpy_amd import _lib
+    lib = _lib.load()
+    F = S * K
+    pm, inner = C.c_int32(-1), C.c_int32(-1)
+    probe = lib.amcx_stage_host(arr_re.ctypes.data, None if arr_im is None else arr_im.ctypes.data, kind, S, K, N,
+                                *strides, 0, 0, None, 0, threads, C.byref(pm), C.byref(inner))
+    _lib.check(probe)
+    unit = F if pm.value else N
+    dst = np.full((count, unit), np.nan + 1j * np.nan, dtype=np.complex64)
+    _lib.check(lib.amcx_stage_host(arr_re.ctypes.data, None if arr_im is None else arr_im.ctypes.data, kind, S, K, N,
+                                   *strides, first, count, dst.ctypes.data, dst.nbytes, threads, C.byref(pm), C.byref(inner)))
+    return dst, pm.value, inner.value
+
+
+def test_native_staging_of_strided_containers():
+    """amcx_stage_host (the host half of amcx_ctx_features18_strided_host; needs no GPU): sample planes
+    of a Fortran-ordered container with more snr rows / frames / samples than the configuration uses,
+    rows of a C-ordered one, split real / imaginary arrays, float32 and float64 -- every staged chunk
+    equals numpy's own slicing + astype(complex64) (round to nearest even), whatever the thread count."""
+    from amcpy_amd import _lib
+    rng = np.random.default_rng(5)
+    S_tot, K_tot, L = 4, 37, 300
+    S, K, N = 3, 33, 256
+    full = rng.standard_normal((S_tot, K_tot, L)) * 1e3 + 1j * rng.standard_normal((S_tot, K_tot, L))
+    want = full[:S, :K, :N].astype(np.complex64)                     # numpy's rounding of the doubles
+    es = lambda a: [st // a.itemsize for st in a.strides]
+    # Fortran order (what loadmat returns): planes, snr the inner axis -> position j = k * S + s
+    f = np.asfortranarray(full)
+    for first, count in [(0, 1), (5, 17), (250, 6), (0, N)]:
+        for threads in (1, 3, 8):
+            got, pm, inner = _stage(f, None, _lib.SRC_C128, S, K, N, es(f), first, count, threads)
+            assert (pm, inner) == (1, 1)
+            ref = want[:, :, first:first + count].transpose(2, 1, 0).reshape(count, K * S)
+            assert np.array_equal(got, ref)
+    # the same container as complex64, and as two real arrays (a MATLAB v5 file's storage)
+    f64 = np.asfortranarray(full.astype(np.complex64))
+    got, pm, inner = _stage(f64, None, _lib.SRC_C64, S, K, N, es(f64), 3, 40)
+    assert np.array_equal(got, f64[:S, :K, 3:43].transpose(2, 1, 0).reshape(40, K * S))
+    re, im = np.asfortranarray(full.real), np.asfortranarray(full.imag)
+    got, pm, inner = _stage(re, im, _lib.SRC_F64_SPLIT, S, K, N, es(re), 100, 50)
+    assert np.array_equal(got, want[:, :, 100:150].transpose(2, 1, 0).reshape(50, K * S))
+    got, _, _ = _stage(re, None, _lib.SRC_F64_SPLIT, S, K, N, es(re), 100, 50)          # a real signal
+    assert np.array_equal(got, want.real[:, :, 100:150].transpose(2, 1, 0).reshape(50, K * S).astype(np.complex64))
+    re32, im32 = re.astype(np.float32), im.astype(np.float32)
+    got, _, _ = _stage(re32, im32, _lib.SRC_F32_SPLIT, S, K, N, es(re32), 0, 9)
+    assert np.array_equal(got, (re32 + 1j * im32)[:S, :K, :9].transpose(2, 1, 0).reshape(9, K * S))
+    # (L, S, K) in C order seen as (S, K, L): the frame axis is the inner one -> position j = s * K + k
+    t = np.ascontiguousarray(full.transpose(2, 0, 1)).transpose(1, 2, 0)
+    got, pm, inner = _stage(t, None, _lib.SRC_C128, S, K, N, es(t), 7, 20)
+    assert (pm, inner) == (1, 0) and np.array_equal(got, want[:, :, 7:27].transpose(2, 0, 1).reshape(20, S * K))
+    # C order: rows, unit = frame g = s * K + k
+    got, pm, _ = _stage(full, None, _lib.SRC_C128, S, K, N, es(full), 30, 40)
+    assert pm == 0 and np.array_equal(got, want.reshape(S * K, N)[30:70])
+    # no contiguous axis at all: refused, the Python layer copies
+    odd = full[:, :, ::2]
+    with pytest.raises(_lib.AmcxError) as ei:
+        _stage(odd[::1, ::2], None, _lib.SRC_C128, 2, 10, 128, es(odd[::1, ::2]), 0, 1)
+    assert ei.value.code == _lib.ENOTSUP
+    with pytest.raises(ValueError):
+        _stage(f, None, _lib.SRC_C128, S, K, N, es(f), N - 2, 5)      # past the last plane
+
+
+def test_publish_container_keeps_memory_order_and_checks_room(tmp_path, monkeypatch):
+    """Rank 0 publishes the used part of a modulation in the order it lies in memory (no host
+    transposition), and refuses BEFORE mapping when the shared directory has no room (a sparse
+    tmpfs file written past capacity is a SIGBUS)."""
+    from amcpy_amd import feature_extraction as fe
+    rng = np.random.default_rng(8)
+    full = np.asfortranarray(rng.standard_normal((3, 9, 20)) + 1j * rng.standard_normal((3, 9, 20)))
+    path = fe._publish_container(full, 2, 7, 16, threads=3)
+    try:
+        back = np.load(path, mmap_mode="r")
+        assert back.shape == (2, 7, 16) and back.flags.f_contiguous and np.array_equal(back, full[:2, :7, :16])
+    finally:
+        path.unlink()
+    c = np.ascontiguousarray(full)
+    path = fe._publish_container(c, 2, 7, 16, threads=1)
+    try:
+        back = np.load(path, mmap_mode="r")
+        assert back.flags.c_contiguous and np.array_equal(back, c[:2, :7, :16])
+    finally:
+        path.unlink()
+    with pytest.raises(OSError, match="free to publish"):
+        fe._shared_dir(1 << 60)
+
+
+_FAILING_WORKER = textwrap.dedent('''
+    import os, sys
+    import numpy as np
+    import torch.distributed as dist
+    sys.path.insert(0, os.environ["AMCX_REPO"])
+    from pathlib import Path
+    from amcpy_amd.config import Config, Paths, SignalConfig
+    from amcpy_amd import feature_extraction as fe
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = []
+    def compute(block):
+        calls.append(block.shape)
+        if rank == 1 and len(calls) == 2:         # the second modulation dies on rank 1 only
+            raise FloatingPointError("injected engine failure")
+        return np.zeros((block.shape[0], 18), dtype=np.float32)
+    cfg = Config(paths=Paths(root=Path(os.environ["AMCX_ROOT"])),
+                 signals=SignalConfig(snr_values={0: "0", 1: "10", 2: "20"}, num_frames=7, frame_size=16))
+    try:
+        fe.run_extraction(cfg, compute=compute, verbose=False)
+    except RuntimeError as exc:
+        print("RAISED", rank, exc)
+        dist.destroy_process_group()
+        sys.exit(3)
+    print("NO ERROR", rank)
+''')
+
+
+def test_two_rank_failure_raises_on_every_rank(tmp_path):
+    """An engine that raises on rank 1 only: both ranks report the same error and exit non-zero within
+    the timeout (no rank is left inside a collective), the first modulation's file exists, no shared
+    file is left behind.  The reference's threads swallow such failures (feature_extraction.py:33-39,74)."""
+    import glob
+    import scipy.io
+    from amcpy_amd.config import Config, Paths, SignalConfig
+    from amcpy_amd import feature_extraction as fe
+    rng = np.random.default_rng(12)
+    cfg = Config(paths=Paths(root=tmp_path),
+                 signals=SignalConfig(snr_values={0: "0", 1: "10", 2: "20"}, num_frames=7, frame_size=16))
+    cfg.paths.ensure_dirs()
+    scipy.io.savemat(str(cfg.paths.mat_data / cfg.paths.mat_filename),
+                     {cfg.signals.mat_info[m]: (rng.standard_normal((3, 9, 20)) + 1j * rng.standard_normal((3, 9, 20)))
+                      for m in cfg.signals.modulations_with_noise})
+    before = set(glob.glob(str(fe._shared_dir(0) / "amcx_frames_*")))
+    script = tmp_path / "failing_worker.py"
+    script.write_text(_FAILING_WORKER)
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   AMCX_REPO=str(REPO), AMCX_ROOT=str(tmp_path), PYTHONDONTWRITEBYTECODE="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    assert [p.returncode for p in procs] == [3, 3], "\n".join(outs)
+    for r in range(2):
+        assert f"RAISED {r}" in outs[r] and "rank 1: FloatingPointError: injected engine failure" in outs[r], outs[r]
+    assert (cfg.paths.calculated_features / "BPSK_features.mat").exists()
+    assert not (cfg.paths.calculated_features / "QPSK_features.mat").exists()
+    assert set(glob.glob(str(fe._shared_dir(0) / "amcx_frames_*"))) == before, "shared frame files left behind"
