@@ -24,7 +24,8 @@ class UploadStats(C.Structure):
     """amcx_upload_stats (include/amcx.h)."""
     _fields_ = [("frames", C.c_int64), ("source_bytes", C.c_int64), ("pcie_bytes", C.c_int64),
                 ("chunks", C.c_int32), ("threads", C.c_int32), ("plane_major", C.c_int32), ("reserved", C.c_int32),
-                ("seconds", C.c_double), ("seconds_staging", C.c_double), ("seconds_waiting", C.c_double)]
+                ("seconds", C.c_double), ("seconds_staging", C.c_double), ("seconds_waiting", C.c_double),
+                ("seconds_prepare", C.c_double), ("seconds_tail", C.c_double)]
 
 
 # every symbol include/amcx.h declares: (restype, argtypes)

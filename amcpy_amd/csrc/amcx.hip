@@ -231,6 +231,7 @@ struct amcx_ctx {
   void* d_frames = nullptr; size_t frames_cap = 0;   // plane-major sources: the frame-major complex64 image
   hipEvent_t up_done[3] = {nullptr, nullptr, nullptr};
   hipEvent_t slab_free[2] = {nullptr, nullptr};
+  float* out_pin = nullptr; size_t out_pin_cap = 0;   // the result lands in pinned memory first
   amcx_upload_stats stats = {};
 };
 
@@ -364,6 +365,16 @@ int strided_prepare(amcx_ctx* c, size_t slot, size_t dslot, size_t frames_bytes,
     }
     c->pin_cap = kPinSlots * slot;
   }
+  if (c->out_pin_cap < out_bytes) {
+    if (c->out_pin) { (void)hipHostFree(c->out_pin); c->out_pin = nullptr; c->out_pin_cap = 0; }
+    const size_t want = out_bytes + out_bytes / 4 + 4096;
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->out_pin), want, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      c->out_pin = nullptr;
+      return AMCX_ENOMEM;
+    }
+    c->out_pin_cap = want;
+  }
   int rc = ctx_reserve(&c->d_slab, &c->slab_cap, 2 * dslot);
   if (rc == AMCX_OK && frames_bytes) rc = ctx_reserve(&c->d_frames, &c->frames_cap, frames_bytes);
   if (rc == AMCX_OK) rc = ctx_reserve(reinterpret_cast<void**>(&c->d_out), &c->out_cap, out_bytes);
@@ -412,11 +423,17 @@ int ctx_run_strided(amcx_ctx* c, const void* re, const void* im, int32_t kind, i
   st.source_bytes = F * (int64_t)N * (int64_t)src_esz * ((kind >= AMCX_SRC_F32_SPLIT && src.im) ? 2 : 1);
 
   hipError_t e = hipSuccess;
+  const double t_loop = wall_now();
   const int64_t units_per_slot = (int64_t)(slot / ((size_t)unit * esz));
   int64_t u = 0;
   for (int ch = 0; u < n_units && rc == AMCX_OK; ++ch) {
-    // the first chunks are small so that the link starts early: 1/16, 1/8, 1/4, 1/2 of a slot, then whole slots
-    int64_t take = ch < 4 ? units_per_slot >> (4 - ch) : units_per_slot;
+    // the first chunks are small so that the link starts early and staging overlaps it from the start:
+    // 2, 2, 4, 4, 8, 8 ... MiB staged, up to whole slots (a 16 MB modulation of BASELINE configs[0] is five chunks)
+    int64_t take = units_per_slot;
+    if (ch < 12) {
+      const int64_t ramp = (int64_t)((size_t(2) << 20 << (ch / 2)) / ((size_t)unit * esz));
+      if (ramp < take) take = ramp;
+    }
     if (take < 1) take = 1;
     if (take > n_units - u) take = n_units - u;
     const int ps = ch % kPinSlots, ds = ch & 1;
@@ -472,14 +489,29 @@ int ctx_run_strided(amcx_ctx* c, const void* re, const void* im, int32_t kind, i
   }
   if (rc == AMCX_OK && e == hipSuccess && !rows)
     rc = amcx_features18_c64_ex(c->d_frames, F, N, N, c->d_out, AMCX_NUM_FEATURES, c->stream, v);
+  const double t_tail = wall_now();
+  st.seconds_prepare = t_loop - t_start;
+  // the result comes back into pinned memory (a copy into the caller's pageable rows would be staged by the
+  // runtime, ~100 us for 72 KB) and is spread over the caller's row stride by the host
   if (rc == AMCX_OK && e == hipSuccess)
-    e = hipMemcpy2DAsync(out_host, sizeof(float) * (size_t)out_row_stride, c->d_out, sizeof(float) * AMCX_NUM_FEATURES,
-                         sizeof(float) * AMCX_NUM_FEATURES, (size_t)F, hipMemcpyDeviceToHost, c->stream);
+    e = hipMemcpyAsync(c->out_pin, c->d_out, sizeof(float) * AMCX_NUM_FEATURES * (size_t)F, hipMemcpyDeviceToHost, c->stream);
   if (rc == AMCX_OK && e != hipSuccess) rc = hip_fail(e, "amcx_ctx_features18_strided_host");
-  // success or not, nothing of this call is in flight when it returns
-  hipError_t e1 = hipStreamSynchronize(c->copy_stream), e2 = hipStreamSynchronize(c->stream);
+  // success or not, nothing of this call is in flight when it returns (every upload is ordered before the
+  // compute stream's last kernel by an event, so on success that stream alone says so)
+  hipError_t e2 = hipStreamSynchronize(c->stream);
+  hipError_t e1 = (rc == AMCX_OK && e2 == hipSuccess) ? hipSuccess : hipStreamSynchronize(c->copy_stream);
   if (rc == AMCX_OK && (e1 != hipSuccess || e2 != hipSuccess))
     rc = hip_fail(e1 != hipSuccess ? e1 : e2, "amcx_ctx_features18_strided_host (sync)");
+  if (rc == AMCX_OK) {
+    if (out_row_stride == AMCX_NUM_FEATURES) {
+      memcpy(out_host, c->out_pin, sizeof(float) * AMCX_NUM_FEATURES * (size_t)F);
+    } else {
+      for (int64_t g = 0; g < F; ++g)
+        memcpy(out_host + (size_t)g * (size_t)out_row_stride, c->out_pin + (size_t)g * AMCX_NUM_FEATURES,
+               sizeof(float) * AMCX_NUM_FEATURES);
+    }
+  }
+  st.seconds_tail = wall_now() - t_tail;
   st.seconds = wall_now() - t_start;
   c->stats = st;
   return rc;
@@ -522,6 +554,7 @@ int amcx_ctx_destroy(amcx_ctx* c) {
   if (c->d_slab) (void)hipFree(c->d_slab);
   if (c->d_frames) (void)hipFree(c->d_frames);
   if (c->pin) (void)hipHostFree(c->pin);
+  if (c->out_pin) (void)hipHostFree(c->out_pin);
   delete c;                                     // joins the staging threads
   return AMCX_OK;
 }

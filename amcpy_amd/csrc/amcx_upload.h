@@ -16,6 +16,10 @@
 
 #include <stdint.h>
 #include <string.h>
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <emmintrin.h>
+#define AMCX_STAGE_SSE2 1
+#endif
 
 #include <condition_variable>
 #include <functional>
@@ -117,23 +121,71 @@ struct RunMap {
   int64_t offset(int64_t i) const { return (i / cnt_b) * stride_a + (i % cnt_b) * stride_b; }
 };
 
+// The two conversions that carry the real-data path, written out for SSE2 (baseline x86-64): doubles are
+// rounded with cvtpd2ps (round to nearest even under the default MXCSR, as numpy's astype and the GPU's
+// conversion do) and the result leaves with non-temporal stores -- a pinned slot is written once and read
+// by the copy engine, so keeping it out of the caches saves the read-for-ownership of every line (a third of
+// the traffic of a plain store loop).
+#ifdef AMCX_STAGE_SSE2
+// dst[i] = (float) src[i], n doubles (n even: whole complex elements)
+inline void round_doubles(float* dst, const double* src, int64_t n) {
+  int64_t i = 0;
+  if ((reinterpret_cast<uintptr_t>(dst) & 15) == 8 && n >= 2) {      // one complex element up to 16-byte alignment
+    dst[0] = (float)src[0]; dst[1] = (float)src[1];
+    i = 2;
+  }
+  if ((reinterpret_cast<uintptr_t>(dst + i) & 15) == 0) {
+    for (; i + 8 <= n; i += 8) {
+      const __m128 a = _mm_movelh_ps(_mm_cvtpd_ps(_mm_loadu_pd(src + i)), _mm_cvtpd_ps(_mm_loadu_pd(src + i + 2)));
+      const __m128 b = _mm_movelh_ps(_mm_cvtpd_ps(_mm_loadu_pd(src + i + 4)), _mm_cvtpd_ps(_mm_loadu_pd(src + i + 6)));
+      _mm_stream_ps(dst + i, a);
+      _mm_stream_ps(dst + i + 4, b);
+    }
+  }
+  for (; i < n; ++i) dst[i] = (float)src[i];
+}
+// dst[i] = ((float) re[i], (float) im[i]), n complex elements
+inline void round_interleave_doubles(float* dst, const double* re, const double* im, int64_t n) {
+  int64_t i = 0;
+  if ((reinterpret_cast<uintptr_t>(dst) & 15) == 8 && n >= 1) {
+    dst[0] = (float)re[0]; dst[1] = (float)im[0];
+    i = 1;
+  }
+  if ((reinterpret_cast<uintptr_t>(dst + 2 * i) & 15) == 0) {
+    for (; i + 4 <= n; i += 4) {
+      const __m128 r = _mm_movelh_ps(_mm_cvtpd_ps(_mm_loadu_pd(re + i)), _mm_cvtpd_ps(_mm_loadu_pd(re + i + 2)));
+      const __m128 q = _mm_movelh_ps(_mm_cvtpd_ps(_mm_loadu_pd(im + i)), _mm_cvtpd_ps(_mm_loadu_pd(im + i + 2)));
+      _mm_stream_ps(dst + 2 * i, _mm_unpacklo_ps(r, q));
+      _mm_stream_ps(dst + 2 * i + 4, _mm_unpackhi_ps(r, q));
+    }
+  }
+  for (; i < n; ++i) { dst[2 * i] = (float)re[i]; dst[2 * i + 1] = (float)im[i]; }
+}
+inline void stage_fence() { _mm_sfence(); }       // non-temporal stores are globally visible before the copy is queued
+#else
+inline void round_doubles(float* dst, const double* src, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) dst[i] = (float)src[i];
+}
+inline void round_interleave_doubles(float* dst, const double* re, const double* im, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) { dst[2 * i] = (float)re[i]; dst[2 * i + 1] = (float)im[i]; }
+}
+inline void stage_fence() {}
+#endif
+
 // count elements starting at source element `off` -> dst.  as_c128: complex128 copied as it is
 // (16 bytes per element, rounded later on the device); otherwise dst is complex64.
 inline void stage_elems(char* dst, const Source& s, int64_t off, int64_t count, bool as_c128) {
+  float* const q = reinterpret_cast<float*>(dst);
   switch (s.kind) {
     case kSrcC64:
       memcpy(dst, s.re + off * 8, (size_t)count * 8);
       return;
-    case kSrcC128: {
-      if (as_c128) { memcpy(dst, s.re + off * 16, (size_t)count * 16); return; }
-      const double* __restrict__ p = reinterpret_cast<const double*>(s.re) + 2 * off;
-      float* __restrict__ q = reinterpret_cast<float*>(dst);
-      for (int64_t i = 0; i < 2 * count; ++i) q[i] = (float)p[i];
+    case kSrcC128:
+      if (as_c128) memcpy(dst, s.re + off * 16, (size_t)count * 16);
+      else round_doubles(q, reinterpret_cast<const double*>(s.re) + 2 * off, 2 * count);
       return;
-    }
     case kSrcF32Split: {
       const float* __restrict__ a = reinterpret_cast<const float*>(s.re) + off;
-      float* __restrict__ q = reinterpret_cast<float*>(dst);
       if (s.im != nullptr) {
         const float* __restrict__ b = reinterpret_cast<const float*>(s.im) + off;
         for (int64_t i = 0; i < count; ++i) { q[2 * i] = a[i]; q[2 * i + 1] = b[i]; }
@@ -143,11 +195,9 @@ inline void stage_elems(char* dst, const Source& s, int64_t off, int64_t count, 
       return;
     }
     default: {
-      const double* __restrict__ a = reinterpret_cast<const double*>(s.re) + off;
-      float* __restrict__ q = reinterpret_cast<float*>(dst);
+      const double* a = reinterpret_cast<const double*>(s.re) + off;
       if (s.im != nullptr) {
-        const double* __restrict__ b = reinterpret_cast<const double*>(s.im) + off;
-        for (int64_t i = 0; i < count; ++i) { q[2 * i] = (float)a[i]; q[2 * i + 1] = (float)b[i]; }
+        round_interleave_doubles(q, a, reinterpret_cast<const double*>(s.im) + off, count);
       } else {
         for (int64_t i = 0; i < count; ++i) { q[2 * i] = (float)a[i]; q[2 * i + 1] = 0.f; }
       }
@@ -178,6 +228,7 @@ inline void stage_runs(Pool& pool, char* dst, const Source& s, const RunMap& m, 
       stage_elems(dst + (size_t)e * esz, s, m.offset(run0 + r) + within, n, as_c128);
       e += n;
     }
+    stage_fence();
   };
   pool.run((int)((total + per - 1) / per), job);
 }

@@ -200,7 +200,8 @@ class HipEngine:
         ctx.run_strided(re_ptr + base_elems * item, None if im_ptr is None else im_ptr + base_elems * item,
                         kind, n_snr, n_frames, self.N, strides, out)
         st = ctx.upload_stats()
-        for k in ("frames", "source_bytes", "pcie_bytes", "chunks", "seconds_staging", "seconds_waiting"):
+        for k in ("frames", "source_bytes", "pcie_bytes", "chunks", "seconds_staging", "seconds_waiting",
+                  "seconds_prepare", "seconds_tail", "seconds"):
             self.stats[k] = self.stats.get(k, 0) + st[k]
         self.stats["gather_threads"], self.stats["plane_major"] = st["threads"], st["plane_major"]
 
@@ -241,6 +242,7 @@ class HipEngine:
             n = (s1 - s0) * (k1 - k0)
             self._run_block(src, s0 * ss + k0 * sk, s1 - s0, k1 - k0, (ss, sk, sn), out[row:row + n])
             row += n
+        self.stats["seconds_native"] = self.stats.pop("seconds", 0.0)
         self.stats["seconds"] = time.perf_counter() - t0
         self.stats["bytes_uploaded"] = self.stats.get("pcie_bytes", 0)
         return out

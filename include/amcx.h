@@ -245,6 +245,8 @@ typedef struct amcx_upload_stats {
   double seconds;           /* whole call */
   double seconds_staging;   /* caller thread inside the staging copies */
   double seconds_waiting;   /* caller thread blocked on a pinned slot still being uploaded */
+  double seconds_prepare;   /* before the first chunk: (re)allocation of slots and scratch */
+  double seconds_tail;      /* after the last chunk was queued: feature kernel, result copy, sync */
 } amcx_upload_stats;
 int amcx_ctx_upload_stats(const amcx_ctx* ctx, amcx_upload_stats* out);
 

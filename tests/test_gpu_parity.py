@@ -883,7 +883,7 @@ def test_upload_pipeline_many_chunks_equals_one_launch():
     # C order: rows go up in chunks of whole frames, the kernel runs per chunk
     row_eng = HipEngine(N, chunk_bytes=37 * N * 8, threads=3)
     got = row_eng(FrameRows(full, n_snr, n_frames))
-    assert row_eng.stats["plane_major"] == 0 and row_eng.stats["chunks"] >= 18
+    assert row_eng.stats["plane_major"] == 0 and row_eng.stats["chunks"] >= 16
     assert np.array_equal(got, want128, equal_nan=True)
     assert np.array_equal(HipEngine(N, chunk_bytes=29 * N * 24, round_on_device=True)(FrameRows(full, n_snr, n_frames)),
                           want128, equal_nan=True)
