@@ -188,16 +188,13 @@ int amcx_features18_c64_ex(const void* iq_dev, int64_t n_frames, int32_t frame_s
                                      out_row_stride, stream, cu_count());
     if (e != hipSuccess) return hip_fail(e, "wave kernel launch");
     // frames the fp32 kernel flagged as outside its range (f5 = -inf): the range pass of the same wave machine
-    // on a power-of-two pre-scaled copy (N = 1024, 2048, 4096), or the block kernel's fp64-sum routine (other N);
-    // then frames with a phase step within an angle rounding of +-pi (f5 < 0): exact f5 / f9 (amcx_fixup_kernel.h)
-    const bool wave_range = amcx::wave_has_range_pass(frame_size);
-    if (wave_range) {
+    // on a power-of-two pre-scaled copy (N = 1024, 2048, 4096), or the block kernel's fp64-sum routine (other N).
+    // (Frames with a phase step within an angle rounding of +-pi are finished inside the wave kernels.)
+    if (amcx::wave_has_range_pass(frame_size))
       e = amcx::launch_wave_range(iq, n_frames, frame_size, row_stride_elems, out_dev, out_row_stride, stream, cu_count());
-      if (e != hipSuccess) return hip_fail(e, "range pass launch");
-    }
-    e = amcx::launch_fixup(iq, n_frames, frame_size, row_stride_elems, out_dev, out_row_stride, stream,
-                           cu_count(), !wave_range);
-    if (e != hipSuccess) return hip_fail(e, "fix-up kernel launch");
+    else
+      e = amcx::launch_range_fixup(iq, n_frames, frame_size, row_stride_elems, out_dev, out_row_stride, stream, cu_count());
+    if (e != hipSuccess) return hip_fail(e, "range pass launch");
     return AMCX_OK;
   }
   return launch_block(iq, n_frames, frame_size, row_stride_elems, out_dev, out_row_stride, stream);

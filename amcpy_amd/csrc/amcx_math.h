@@ -68,10 +68,10 @@ __device__ __forceinline__ float wrapped_step(float th_next, float th) {
 
 // |step| > pi - kTieBand: rounding of the two fp32 angles (<= 1e-6 together) may
 // have decided the sign of the wrapped step.  The fp64 reference resolves such a
-// step from the 17th digit; the throughput kernel only FLAGS the frame (it stores
-// -f5, and f5 >= 0) and amcx_fixup_kernel recomputes f5/f9 of flagged frames
-// with exact_step below.  About 1 frame in 400 is flagged at low SNR; every frame
-// of noiseless axis-aligned data is.
+// step from the 17th digit; the throughput kernel's sweep only FLAGS the frame (the
+// finaliser sees -f5, and f5 >= 0) and the finaliser recomputes f5/f9 of flagged frames
+// with exact_step below (wave_exact_frequency).  About 1 frame in 400 is flagged at low
+// SNR; every frame of noiseless axis-aligned data is.
 constexpr float kTieBand = 2.0e-6f;
 
 // Wrapped step p -> q with an exact tie decision: sign(sin(step)) = sign(Re p Im q -
@@ -120,7 +120,7 @@ struct FrameSums {
 // holds most of its energy (then a sum overflows and is_outside_fp32_range sees the inf), and at
 // 1e-10 they are still 8 orders above the smallest normal float.  Frames outside -- and frames
 // any of whose sums is not finite -- are flagged (f5 = -inf) and recomputed with fp64 sums by
-// amcx_fixup_kernel: the reference evaluates in complex128 (features.py:46-58) and is finite
+// the range pass: the reference evaluates in complex128 (features.py:46-58) and is finite
 // over the whole complex64 range, overflowing only in its float32 store.
 constexpr double kRangeLoPower = 1.0e-10, kRangeHiPower = 1.0e10;
 
@@ -227,7 +227,7 @@ __device__ inline void finalize_features(const FrameSums& s, int N, float* __res
   // ---- frequency phi = w / 2pi over N-1 values: f5, f9
   frequency_features(s.Kw, s.swd1, s.swd2, s.swd3, s.swd4, N, out[4], out[8]);
 
-  if (s.pi_tie) out[4] = -out[4];   // picked up by amcx_fixup_kernel
+  if (s.pi_tie) out[4] = -out[4];   // picked up by the wave finaliser (wave_exact_frequency)
 
   // ---- mixed moments (complex as (re, im) pairs)
   if (zero_frame) {   // the guard's kTinyPower must not leak into |C20| ... |C63| of a zero frame

@@ -705,6 +705,46 @@ __device__ __forceinline__ float fft_back(const LaneAddr& la) {
 }
 
 // ---------------------------------------------------------------------------
+// f5 / f9 of ONE frame with the sign of every phase step within kTieBand of +-pi decided exactly
+// (exact_step, amcx_math.h), by the whole wave: the slow path behind the statistics sweep's tie flag.
+// It runs inside the finaliser -- on ~0.3 % of frames, after the frame's registers are dead -- as a
+// ROLLED loop over the frame re-read from memory (L2 / Infinity Cache: the wave read it microseconds
+// ago): lane l takes steps l, l + 64, ...; both samples of a step are loaded by the lane itself, so
+// nothing crosses lanes until the two fp64 reductions.  Two sweeps (mean step, then centred powers), as
+// the reference's np.std / scipy kurtosis do on the float64 array (features.py:88-91,110-113).  In the
+// hot loop this cost 60-760 spilled VGPRs (round 1); as a separate launch it cost a 4-byte-per-frame scan
+// of the result matrix plus 29 us per 639 k frames (round 2).  sc: the power of two the range pass
+// multiplies the frame by (1 in the throughput kernel).
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+template <int N>
+__device__ __forceinline__ void wave_exact_frequency(const float2* __restrict__ src, float sc, int lane,
+                                                     float& f5, float& f9) {
+  auto step = [&](int n) {
+    const float2 p = src[n], q = src[n + 1];
+    const float pr = p.x * sc, pi = p.y * sc, qr = q.x * sc, qi = q.y * sc;
+    const float ap = __builtin_amdgcn_sqrtf(__builtin_fmaf(pr, pr, __builtin_fmaf(pi, pi, kTinyPower)));
+    const float aq = __builtin_amdgcn_sqrtf(__builtin_fmaf(qr, qr, __builtin_fmaf(qi, qi, kTinyPower)));
+    return exact_step(fast_angle(qr, qi, aq), fast_angle(pr, pi, ap), pr, pi, qr, qi);
+  };
+  double s1 = 0.0;
+#pragma unroll 1
+  for (int n = lane; n < N - 1; n += 64) s1 += (double)step(n);
+  const double Kw = wave_sum_f64(s1) / (double)(N - 1);
+  double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
+#pragma unroll 1
+  for (int n = lane; n < N - 1; n += 64) {
+    const double d = (double)step(n) - Kw, d2 = d * d;
+    c0 += d; c1 += d2; c2 += d2 * d; c3 += d2 * d2;
+  }
+  frequency_features(Kw, wave_sum_f64(c0), wave_sum_f64(c1), wave_sum_f64(c2), wave_sum_f64(c3), N, f5, f9);
+}
+
+// ---------------------------------------------------------------------------
 // RANGE = false: the throughput kernel.  RANGE = true: the range pass behind it (amcx_range_wave_kernel):
 // the same machine over only the frames the throughput kernel flagged as outside its fp32 range
 // (f5 = -inf), each multiplied by an exact power of two first -- 2^-ex, ex the even-rounded exponent of
@@ -1197,6 +1237,10 @@ __device__ __forceinline__ void wave_body(
     // ---- batch finalisation: lane g turns the sums in stash row g into 18 features ----
     auto finalise = [&](int count) {
       lds_wave_fence();
+      float feat[18];
+      long long f = 0;
+      [[maybe_unused]] float sc = 1.0f;
+      bool tie = false;
       if (lane < count) {
         const float* row = stash + (lane * C::kFlushes + (C::kFlushes - 1)) * kStashStride;   // the frame's last row
         auto sm = [&](int k) -> double {           // sum k of the frame: its stash rows added in fp64
@@ -1216,17 +1260,35 @@ __device__ __forceinline__ void wave_body(
         F.swd1 = sm(23); F.swd2 = sm(24); F.swd3 = sm(25); F.swd4 = sm(26);
         F.gmax_raw = row[27]; F.Kt = row[28]; F.Kw = row[29]; F.Ka = row[30];
         F.pi_tie = row[31] != 0.0f;
-        float feat[18];
-        long long f;
         if constexpr (RANGE) {
           const int code = (int)row[kNumSums + 5];              // (ex + 128) * 64 + index within the block
-          finalize_features<true>(F, N, feat, (code >> 6) - 128);
+          const int ex = (code >> 6) - 128;
+          finalize_features<true>(F, N, feat, ex);
+          sc = __builtin_bit_cast(float, (127 - ex) << 23);     // the 2^-ex the frame was multiplied by
           f = f0 + (code & 63);
         } else {
           finalize_features(F, N, feat);
           if (is_outside_fp32_range(F, N)) feat[4] = -__builtin_inff();   // all 18 redone by the range pass
           f = f0 + lane;
         }
+        // flagged by the sweep (f5 came back negated) and neither NaN nor on its way to the range pass
+        tie = __builtin_signbitf(feat[4]) && feat[4] == feat[4] && feat[4] != -__builtin_inff();
+      }
+      // frames with a phase step within an fp32 rounding of +-pi: f5 and f9 again, the wave on one frame at a time
+      unsigned long long ties = __builtin_amdgcn_ballot_w64(tie);
+      while (ties != 0) {
+        const int idx = __builtin_ctzll(ties);
+        ties &= ties - 1;
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(f & 0xffffffffLL), idx);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)f >> 32), idx);
+        const long long ft = (long long)(((unsigned long long)hi << 32) | lo);
+        float sct = 1.0f;
+        if constexpr (RANGE) sct = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc), idx));
+        float f5x, f9x;
+        wave_exact_frequency<N>(iq + ft * row_stride, sct, lane, f5x, f9x);
+        if (lane == idx) { feat[4] = f5x; feat[8] = f9x; }
+      }
+      if (lane < count) {
         float* dst = out + f * out_stride;
 #pragma unroll
         for (int j = 0; j < 18; ++j) dst[j] = feat[j];
