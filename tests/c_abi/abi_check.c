@@ -34,6 +34,29 @@ int main(int argc, char** argv) {
   CHECK(strstr(name, "wave_kernel<2048>") != NULL);
   CHECK(amcx_kernel_name(1000, AMCX_VARIANT_AUTO, name, (int32_t)sizeof name) == AMCX_OK);
   CHECK(strstr(name, "block_kernel") != NULL);
+  /* version-2 additions: the strided-container entries validate before touching a device, and the staging half
+   * works without one */
+  CHECK(amcx_ctx_features18_strided_host(NULL, NULL, NULL, AMCX_SRC_C64, 1, 1, 64, 64, 64, 1, NULL, 18, AMCX_VARIANT_AUTO) == AMCX_EINVAL);
+  CHECK(amcx_ctx_configure(NULL, 1, 0, -1) == AMCX_EINVAL);
+  CHECK(amcx_pack_planes_c64(NULL, AMCX_SRC_C64, -1, 0, 1, 1, 1, NULL, 1, 0, NULL) == AMCX_EINVAL);
+  CHECK(amcx_pack_planes_c64(NULL, AMCX_SRC_C64, 0, 4, 2, 2, 1, NULL, 8, 0, NULL) == AMCX_OK);
+  {
+    /* a 2 x 3 x 4 container in Fortran order (snr fastest), doubles: planes come out position-major, rounded */
+    double src[2 * 2 * 3 * 4];
+    float staged[2 * 6 * 2];
+    int32_t plane_major = -1, inner_snr = -1;
+    for (int i = 0; i < 2 * 2 * 3 * 4; ++i) src[i] = 0.1 * i + 1e-9;
+    CHECK(amcx_stage_host(src, NULL, AMCX_SRC_C128, 2, 3, 4, 1, 2, 6, 1, 2, staged, sizeof staged, 2,
+                          &plane_major, &inner_snr) == AMCX_OK);
+    CHECK(plane_major == 1 && inner_snr == 1);
+    for (int r = 0; r < 2; ++r)
+      for (int j = 0; j < 6; ++j) {
+        CHECK(staged[2 * (r * 6 + j)] == (float)src[2 * ((1 + r) * 6 + j)]);
+        CHECK(staged[2 * (r * 6 + j) + 1] == (float)src[2 * ((1 + r) * 6 + j) + 1]);
+      }
+    CHECK(amcx_stage_host(src, NULL, AMCX_SRC_C128, 2, 3, 4, 2, 4, 12, 0, 1, staged, sizeof staged, 1, NULL, NULL) == AMCX_ENOTSUP);
+    CHECK(amcx_stage_host(src, NULL, AMCX_SRC_C128, 2, 3, 4, 1, 2, 6, 3, 2, staged, sizeof staged, 1, NULL, NULL) == AMCX_EINVAL);
+  }
   if (argc < 4 || strcmp(argv[1], "compute") != 0) {
     /* without a GPU the host-buffer entries must refuse, not compute */
     if (amcx_device_count() <= 0) {
@@ -60,6 +83,13 @@ int main(int argc, char** argv) {
   CHECK(amcx_ctx_create(0, &ctx) == AMCX_OK && ctx != NULL);
   for (int rep = 0; rep < 3; ++rep)
     CHECK(amcx_ctx_features18_c64_host(ctx, x, 1, n, n, looped, 18, AMCX_VARIANT_AUTO) == AMCX_OK);
+  /* the same frame as a 1 x 1 x n container with a unit sample stride: the row path of the strided entry */
+  float strided[18];
+  amcx_upload_stats st;
+  CHECK(amcx_ctx_configure(ctx, 2, 1 << 20, -1) == AMCX_OK);
+  CHECK(amcx_ctx_features18_strided_host(ctx, x, NULL, AMCX_SRC_C64, 1, 1, n, 0, n, 1, strided, 18, AMCX_VARIANT_AUTO) == AMCX_OK);
+  CHECK(amcx_ctx_upload_stats(ctx, &st) == AMCX_OK && st.frames == 1 && st.pcie_bytes == 8 * (int64_t)n && st.plane_major == 0);
+  CHECK(memcmp(once, strided, sizeof once) == 0);
   CHECK(amcx_ctx_destroy(ctx) == AMCX_OK);
   CHECK(memcmp(once, looped, sizeof once) == 0);
   for (int j = 0; j < 18; ++j) printf("%.9g\n", once[j]);

@@ -76,6 +76,8 @@ def _assert_parity(got, golden_f64, frames, what, large_sample=False):
     print(f"[{what}] frames beyond the unfloored criterion: {int(over.sum())} of {len(over)}"
           f" (worst {scaled.max():.2e})")
     assert over.mean() <= 1e-3, f"{what}: {int(over.sum())} of {len(over)} frames beyond 1e-5 of max(|value|, S)"
+    # ... and no frame at all may be far out: a new class of outliers must not hide in the 0.1 % allowance
+    assert scaled.max() <= 10 * TOL, f"{what}: feature {int(worst.argmax()) + 1} off by {scaled.max():.3e} (cap 1e-4)"
     S_floor = np.maximum(S, SUM_FLOOR * orc.conditioning_scales(frames, absolute=True))
     _, scaled_f = orc.parity_errors(got, golden_f64.astype(np.float32), S_floor)
     assert scaled_f.max() <= TOL, f"{what}: feature {int(scaled_f.max(axis=0).argmax()) + 1} off by {scaled_f.max():.3e}"
@@ -986,3 +988,68 @@ def _check_ends_of_float32(got, gold32, S, names, what):
     i, j = np.unravel_index(scaled.argmax(), scaled.shape)
     print(f"\n[ends of float32, {what}] worst scaled rel per feature:", " ".join(f"{v:.1e}" for v in scaled.max(axis=0)))
     assert scaled.max() <= TOL, (what, names[i], j + 1, got[i, j], gold32[i, j])
+
+
+# ----------------------------------------------------------------------------
+# round 3
+# ----------------------------------------------------------------------------
+@pytest.mark.parametrize("N", [1024, 2048, 4096])
+def test_no_worse_than_the_references_own_complex64_path(N):
+    """BASELINE's "within 1e-5 relative fp32" cannot hold in plain relative terms for the cumulants that
+    cancel (ids 10, 12-18): the REFERENCE ITSELF, run on the same complex64 samples, misses its own
+    complex128 result by up to 8.5e-3 there.  The fixtures hold both reference
+    outputs for every frame -- golden64 (complex128 evaluation, the baseline of record) and golden32
+    (features.py on the complex64 array as it is) -- so the claim "no worse than the reference's complex64
+    path" is checked frame by frame: the kernel's distance from golden64 is within the scaled 1e-5, or
+    within twice the reference's own complex64-to-complex128 gap on that frame."""
+    g = load_npz(f"frames_n{N}.npz")
+    x, g64, g32 = g["iq"], g["golden64"].astype(np.float64), g["golden32"].astype(np.float64)
+    S = orc.conditioning_scales(x.astype(np.complex128))
+    ids = [9, 11, 12, 13, 14, 15, 16, 17]                       # feature ids 10, 12 .. 18, zero-based
+    for variant in VARIANTS_POW2:
+        got = _run(x, variant).astype(np.float64)
+        err = np.abs(got - g64)[:, ids]
+        ref_gap = np.abs(g32 - g64)[:, ids]
+        allowed = np.maximum(TOL * np.maximum(np.abs(g64[:, ids]), S[:, ids]), 2.0 * ref_gap)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            plain_hip = (err / np.abs(g64[:, ids])).max(axis=0)
+            plain_ref = (ref_gap / np.abs(g64[:, ids])).max(axis=0)
+        print(f"\n[N={N} {variant}] ids 10,12..18 worst plain rel, kernel   :", " ".join(f"{v:.1e}" for v in plain_hip))
+        print(f"[N={N} {variant}] ids 10,12..18 worst plain rel, ref c64  :", " ".join(f"{v:.1e}" for v in plain_ref))
+        bad = np.argwhere(err > allowed)
+        assert bad.size == 0, (variant, [(int(i), ids[j] + 1, got[i, ids[j]], g64[i, ids[j]], g32[i, ids[j]]) for i, j in bad[:5]])
+
+
+def test_bench_two_ranks_on_one_gpu(tmp_path):
+    """bench.py's N > 1 branch before the driver runs it on a real node: two ranks under
+    torch.distributed.run, launched exactly as the driver does, rehearsed on the box's one GPU (gloo for
+    the barrier / MAX since RCCL refuses two ranks on one device; --share-gpu maps both ranks to it).
+    Exactly one JSON line reaches stdout, it says n_gpus 2, and value x wall equals the frames both
+    ranks processed."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    repo = Path(__file__).resolve().parents[1]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONDONTWRITEBYTECODE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(repo / "bench.py"),
+           "--gpus", "2", "--steps", "3", "--warmup", "2", "--frames", "64", "--dist-backend", "gloo", "--share-gpu"]
+    r = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    per_rank = 6 * 26 * 64
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 2 and rec["scaling"] == "weak"
+    assert rec["config"]["frames_per_gpu_per_step"] == per_rank and rec["cpu_baseline"] is None and rec["h2d"] is None
+    total = rec["value"] * rec["ms_per_step"] * 1e-3 * rec["steps"]
+    assert abs(total - 2 * per_rank * 3) < 1e-3 * total, (total, rec["value"], rec["ms_per_step"])
+    assert rec["roofline"]["launch_ms_min"] <= rec["roofline"]["launch_ms_median"] <= rec["roofline"]["launch_ms_max"]
+    # and a mismatch between --gpus and the launch is refused, not silently run as one rank
+    bad = subprocess.run([sys.executable, str(repo / "bench.py"), "--gpus", "2", "--no-cpu-baseline"], env=env,
+                         cwd=str(tmp_path), capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "torch.distributed.run" in (bad.stdout + bad.stderr)
