@@ -357,7 +357,11 @@ struct Stats {
       sAAP = __builtin_fmaf(AA, P, sAAP);
       sX4P = __builtin_fmaf(X4, P, sX4P);
       sABP = __builtin_fmaf(AP, Bh, sABP);
+#ifdef AMCX_ABL_NOSQRT   // diagnostic upper bound (tools/wave_clock.hip): the envelope's v_sqrt_f32 removed, results wrong on purpose
+      av[b] = __builtin_fmaf(P, 0.61f, 0.2f);
+#else
       av[b] = __builtin_amdgcn_sqrtf(P);
+#endif
       sa += av[b];
       th[b] = fast_angle(re, im, av[b]);
     });
@@ -724,23 +728,39 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 template <int N>
 __device__ __forceinline__ void wave_exact_frequency(const float2* __restrict__ src, float sc, int lane,
                                                      float& f5, float& f9) {
-  auto step = [&](int n) {
-    const float2 p = src[n], q = src[n + 1];
-    const float pr = p.x * sc, pi = p.y * sc, qr = q.x * sc, qi = q.y * sc;
-    const float ap = __builtin_amdgcn_sqrtf(__builtin_fmaf(pr, pr, __builtin_fmaf(pi, pi, kTinyPower)));
-    const float aq = __builtin_amdgcn_sqrtf(__builtin_fmaf(qr, qr, __builtin_fmaf(qi, qi, kTinyPower)));
-    return exact_step(fast_angle(qr, qi, aq), fast_angle(pr, pi, ap), pr, pi, qr, qi);
+  // lane l takes steps l + 64 j; four of them per trip so that their eight loads are in flight together (a
+  // rolled loop of dependent L2 round trips would hold the wave ~45 000 cycles per frame).  The frame's last
+  // sample has no step: lane 63's last one is computed on a clamped neighbour and weighted 0.
+  constexpr int kPer = N / 64, U = kPer < 4 ? kPer : 4, kTrips = kPer / U;     // N = 128: two steps per lane
+  static_assert(kPer >= 1 && kPer % U == 0, "frame sizes are powers of two >= 128");
+  auto sweep = [&](auto&& use) {
+#pragma unroll 1
+    for (int t = 0; t < kTrips; ++t) {
+      float2 p[U], q[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int n = lane + 64 * (U * t + u);
+        p[u] = src[n];
+        q[u] = src[n + 1 < N ? n + 1 : N - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int n = lane + 64 * (U * t + u);
+        const float pr = p[u].x * sc, pi = p[u].y * sc, qr = q[u].x * sc, qi = q[u].y * sc;
+        const float ap = __builtin_amdgcn_sqrtf(__builtin_fmaf(pr, pr, __builtin_fmaf(pi, pi, kTinyPower)));
+        const float aq = __builtin_amdgcn_sqrtf(__builtin_fmaf(qr, qr, __builtin_fmaf(qi, qi, kTinyPower)));
+        use(exact_step(fast_angle(qr, qi, aq), fast_angle(pr, pi, ap), pr, pi, qr, qi), n < N - 1);
+      }
+    }
   };
   double s1 = 0.0;
-#pragma unroll 1
-  for (int n = lane; n < N - 1; n += 64) s1 += (double)step(n);
+  sweep([&](float w, bool on) { s1 += on ? (double)w : 0.0; });
   const double Kw = wave_sum_f64(s1) / (double)(N - 1);
   double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
-#pragma unroll 1
-  for (int n = lane; n < N - 1; n += 64) {
-    const double d = (double)step(n) - Kw, d2 = d * d;
+  sweep([&](float w, bool on) {
+    const double d = on ? (double)w - Kw : 0.0, d2 = d * d;
     c0 += d; c1 += d2; c2 += d2 * d; c3 += d2 * d2;
-  }
+  });
   frequency_features(Kw, wave_sum_f64(c0), wave_sum_f64(c1), wave_sum_f64(c2), wave_sum_f64(c3), N, f5, f9);
 }
 

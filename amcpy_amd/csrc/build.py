@@ -37,14 +37,15 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = True) -
     LIB_DIR.mkdir(exist_ok=True)
     tmp_lib = LIB.with_name(f"{LIB.name}.{os.getpid()}.tmp")     # linked aside, renamed when complete
     cmd = [HIPCC, *FLAGS, *map(str, SOURCES), "-o", str(tmp_lib)]
-    if save_temps:
-        tmp = HERE / "build"
-        tmp.mkdir(exist_ok=True)
-        cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
+    cwd = HERE
+    if save_temps:                       # the intermediate files (.s, .bc, ...) land in csrc/build/, which is git- and gpurun-ignored
+        cwd = HERE / "build"
+        cwd.mkdir(exist_ok=True)
+        cmd += ["-save-temps=cwd", "-Rpass-analysis=kernel-resource-usage"]
     if verbose:
         print("+", " ".join(cmd), file=sys.stderr)
     try:
-        subprocess.run(cmd, check=True, cwd=str(HERE))
+        subprocess.run(cmd, check=True, cwd=str(cwd))
         os.replace(tmp_lib, LIB)
     finally:
         if tmp_lib.exists():

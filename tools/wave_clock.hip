@@ -114,6 +114,12 @@ int main(int argc, char** argv) {
   printf("# build: FFT removed (AMCX_ABL_NOFFT)\n");
 #elif defined(AMCX_ABL_NOSTATS)
   printf("# build: statistics sweep removed (AMCX_ABL_NOSTATS)\n");
+#elif defined(AMCX_ABL_NORCP) && defined(AMCX_ABL_NOSQRT)
+  printf("# build: both per-sample transcendentals removed (AMCX_ABL_NORCP + AMCX_ABL_NOSQRT)\n");
+#elif defined(AMCX_ABL_NORCP)
+  printf("# build: v_rcp_f32 of the half-angle quotient removed (AMCX_ABL_NORCP)\n");
+#elif defined(AMCX_ABL_NOSQRT)
+  printf("# build: v_sqrt_f32 of the envelope removed (AMCX_ABL_NOSQRT)\n");
 #else
   printf("# build: product instruction stream\n");
 #endif
