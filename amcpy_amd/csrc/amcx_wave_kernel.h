@@ -714,8 +714,8 @@ __device__ __forceinline__ float fft_back(const LaneAddr& la) {
 // It runs inside the finaliser -- on ~0.3 % of frames, after the frame's registers are dead -- as a
 // ROLLED loop over the frame re-read from memory (L2 / Infinity Cache: the wave read it microseconds
 // ago): lane l takes steps l, l + 64, ...; both samples of a step are loaded by the lane itself, so
-// nothing crosses lanes until the two fp64 reductions.  Two sweeps (mean step, then centred powers), as
-// the reference's np.std / scipy kurtosis do on the float64 array (features.py:88-91,110-113).  In the
+// nothing crosses lanes until the fp64 reductions (reference: np.std / scipy kurtosis of the float64
+// frequency array, features.py:88-91,110-113).  In the
 // hot loop this cost 60-760 spilled VGPRs (round 1); as a separate launch it cost a 4-byte-per-frame scan
 // of the result matrix plus 29 us per 639 k frames (round 2).  sc: the power of two the range pass
 // multiplies the frame by (1 in the throughput kernel).
@@ -726,41 +726,39 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 }
 
 template <int N>
-__device__ __forceinline__ void wave_exact_frequency(const float2* __restrict__ src, float sc, int lane,
+__device__ __forceinline__ void wave_exact_frequency(const float2* __restrict__ src, float sc, float Kw_f, int lane,
                                                      float& f5, float& f9) {
-  // lane l takes steps l + 64 j; four of them per trip so that their eight loads are in flight together (a
-  // rolled loop of dependent L2 round trips would hold the wave ~45 000 cycles per frame).  The frame's last
-  // sample has no step: lane 63's last one is computed on a clamped neighbour and weighted 0.
-  constexpr int kPer = N / 64, U = kPer < 4 ? kPer : 4, kTrips = kPer / U;     // N = 128: two steps per lane
+  // lane l takes steps l + 64 j, eight of them per trip so that their sixteen loads are in flight together:
+  // the frame comes back from L2 / Infinity Cache / HBM under the full streaming load of the chip, ~2 us a
+  // round trip, and a rolled loop of dependent round trips held the wave 120 us per frame.  ONE sweep: the
+  // sums are taken in fp64 about the shift the statistics sweep used (the mean of the frame's first 64 steps),
+  // which frequency_features turns into central moments -- in fp64 a shift within a few standard deviations of
+  // the mean costs nothing.  The frame's last sample has no step: lane 63's last one is computed on a clamped
+  // neighbour and weighted 0.
+  constexpr int kPer = N / 64, U = kPer < 8 ? kPer : 8, kTrips = kPer / U;     // N = 128: two steps per lane
   static_assert(kPer >= 1 && kPer % U == 0, "frame sizes are powers of two >= 128");
-  auto sweep = [&](auto&& use) {
-#pragma unroll 1
-    for (int t = 0; t < kTrips; ++t) {
-      float2 p[U], q[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int n = lane + 64 * (U * t + u);
-        p[u] = src[n];
-        q[u] = src[n + 1 < N ? n + 1 : N - 1];
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int n = lane + 64 * (U * t + u);
-        const float pr = p[u].x * sc, pi = p[u].y * sc, qr = q[u].x * sc, qi = q[u].y * sc;
-        const float ap = __builtin_amdgcn_sqrtf(__builtin_fmaf(pr, pr, __builtin_fmaf(pi, pi, kTinyPower)));
-        const float aq = __builtin_amdgcn_sqrtf(__builtin_fmaf(qr, qr, __builtin_fmaf(qi, qi, kTinyPower)));
-        use(exact_step(fast_angle(qr, qi, aq), fast_angle(pr, pi, ap), pr, pi, qr, qi), n < N - 1);
-      }
-    }
-  };
-  double s1 = 0.0;
-  sweep([&](float w, bool on) { s1 += on ? (double)w : 0.0; });
-  const double Kw = wave_sum_f64(s1) / (double)(N - 1);
+  const double Kw = (double)Kw_f;
   double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
-  sweep([&](float w, bool on) {
-    const double d = on ? (double)w - Kw : 0.0, d2 = d * d;
-    c0 += d; c1 += d2; c2 += d2 * d; c3 += d2 * d2;
-  });
+#pragma unroll 1
+  for (int t = 0; t < kTrips; ++t) {
+    float2 p[U], q[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int n = lane + 64 * (U * t + u);
+      p[u] = src[n];
+      q[u] = src[n + 1 < N ? n + 1 : N - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int n = lane + 64 * (U * t + u);
+      const float pr = p[u].x * sc, pi = p[u].y * sc, qr = q[u].x * sc, qi = q[u].y * sc;
+      const float ap = __builtin_amdgcn_sqrtf(__builtin_fmaf(pr, pr, __builtin_fmaf(pi, pi, kTinyPower)));
+      const float aq = __builtin_amdgcn_sqrtf(__builtin_fmaf(qr, qr, __builtin_fmaf(qi, qi, kTinyPower)));
+      const float w = exact_step(fast_angle(qr, qi, aq), fast_angle(pr, pi, ap), pr, pi, qr, qi);
+      const double d = n < N - 1 ? (double)w - Kw : 0.0, d2 = d * d;
+      c0 += d; c1 += d2; c2 += d2 * d; c3 += d2 * d2;
+    }
+  }
   frequency_features(Kw, wave_sum_f64(c0), wave_sum_f64(c1), wave_sum_f64(c2), wave_sum_f64(c3), N, f5, f9);
 }
 
@@ -1260,6 +1258,7 @@ __device__ __forceinline__ void wave_body(
       float feat[18];
       long long f = 0;
       [[maybe_unused]] float sc = 1.0f;
+      float kw_shift = 0.f;
       bool tie = false;
       if (lane < count) {
         const float* row = stash + (lane * C::kFlushes + (C::kFlushes - 1)) * kStashStride;   // the frame's last row
@@ -1280,6 +1279,7 @@ __device__ __forceinline__ void wave_body(
         F.swd1 = sm(23); F.swd2 = sm(24); F.swd3 = sm(25); F.swd4 = sm(26);
         F.gmax_raw = row[27]; F.Kt = row[28]; F.Kw = row[29]; F.Ka = row[30];
         F.pi_tie = row[31] != 0.0f;
+        kw_shift = row[29];
         if constexpr (RANGE) {
           const int code = (int)row[kNumSums + 5];              // (ex + 128) * 64 + index within the block
           const int ex = (code >> 6) - 128;
@@ -1296,6 +1296,9 @@ __device__ __forceinline__ void wave_body(
       }
       // frames with a phase step within an fp32 rounding of +-pi: f5 and f9 again, the wave on one frame at a time
       unsigned long long ties = __builtin_amdgcn_ballot_w64(tie);
+#ifdef AMCX_ABL_NOTIEFIX   // diagnostic (tools/wave_clock.hip): flagged frames keep their fp32 f5 / f9 (negated): what does the fix cost?
+      ties = 0;
+#endif
       while (ties != 0) {
         const int idx = __builtin_ctzll(ties);
         ties &= ties - 1;
@@ -1304,8 +1307,9 @@ __device__ __forceinline__ void wave_body(
         const long long ft = (long long)(((unsigned long long)hi << 32) | lo);
         float sct = 1.0f;
         if constexpr (RANGE) sct = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc), idx));
+        const float kwt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, kw_shift), idx));
         float f5x, f9x;
-        wave_exact_frequency<N>(iq + ft * row_stride, sct, lane, f5x, f9x);
+        wave_exact_frequency<N>(iq + ft * row_stride, sct, kwt, lane, f5x, f9x);
         if (lane == idx) { feat[4] = f5x; feat[8] = f9x; }
       }
       if (lane < count) {
