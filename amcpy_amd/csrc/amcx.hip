@@ -208,14 +208,13 @@ int amcx_features18_c64(const void* iq_dev, int64_t n_frames, int32_t frame_size
 }
 
 // ---- host-buffer entry points over a reusable context --------------------------------------
-// The context owns a stream and device scratch that only ever grows, so a loop of per-frame
-// calls (the reference's usage pattern, features.py:214-232 called once per queue item) pays
-// two small copies and the launches, not hipMalloc/hipFree/stream creation per call.
+// The context owns two streams, pinned staging slots and device scratch that only ever grow, so a
+// loop of per-frame calls (the reference's usage pattern, features.py:214-232 called once per queue
+// item) pays two small copies and the launches, not hipMalloc/hipFree/stream creation per call, and
+// a whole container goes up through the staged, overlapped path (ctx_run_strided).
 struct amcx_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
-  void* d_in = nullptr;   size_t in_cap = 0;     // uploaded rows (complex64 or complex128)
-  void* d_c64 = nullptr;  size_t c64_cap = 0;    // complex128 rows rounded to complex64
   float* d_out = nullptr; size_t out_cap = 0;
   // strided containers (amcx_ctx_features18_strided_host): staging pool, three pinned slots, a second stream
   amcx::Pool pool;
@@ -260,60 +259,6 @@ struct DeviceGuard {
   ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
-int ctx_run(amcx_ctx* c, const void* iq_host, bool is_c128, int64_t n_frames, int32_t frame_size,
-            int64_t row_stride_elems, float* out_host, int64_t out_row_stride, int32_t variant) {
-  if (c == nullptr) return AMCX_EINVAL;
-  if (n_frames < 0 || row_stride_elems < frame_size || out_row_stride < AMCX_NUM_FEATURES)
-    return AMCX_EINVAL;
-  const int v = resolve_variant(frame_size, variant);
-  if (v < 0) return v;
-  if (n_frames == 0) return AMCX_OK;
-  if (iq_host == nullptr || out_host == nullptr) return AMCX_EINVAL;
-  DeviceGuard guard;
-  AMCX_HIP(guard.enter(c->device));
-  const size_t elem = is_c128 ? 16 : 8;
-  const size_t row_in = (size_t)frame_size * elem;
-  // rows are packed on the device (row stride == frame_size), so rows longer than frame_size
-  // (feature_extraction.py:68) cost no HBM or PCIe bytes; at most ~512 MiB go up at a time
-  int64_t per = (int64_t)((512ull << 20) / row_in);
-  if (per < 1) per = 1;
-  if (per > n_frames) per = n_frames;
-  int rc = ctx_reserve(&c->d_in, &c->in_cap, row_in * (size_t)per);
-  if (rc == AMCX_OK && is_c128) rc = ctx_reserve(&c->d_c64, &c->c64_cap, (size_t)frame_size * 8 * (size_t)per);
-  if (rc == AMCX_OK)
-    rc = ctx_reserve(reinterpret_cast<void**>(&c->d_out), &c->out_cap,
-                     sizeof(float) * AMCX_NUM_FEATURES * (size_t)per);
-  if (rc != AMCX_OK) return rc;
-  const char* src = static_cast<const char*>(iq_host);
-  hipError_t e = hipSuccess;
-  for (int64_t f0 = 0; f0 < n_frames; f0 += per) {
-    const int64_t nf = (n_frames - f0) < per ? (n_frames - f0) : per;
-    e = hipMemcpy2DAsync(c->d_in, row_in, src + (size_t)f0 * (size_t)row_stride_elems * elem,
-                         (size_t)row_stride_elems * elem, row_in, (size_t)nf, hipMemcpyHostToDevice, c->stream);
-    if (e != hipSuccess) break;
-    const void* d_frames = c->d_in;
-    if (is_c128) {
-      hipLaunchKernelGGL(amcx::amcx_c128_to_c64_kernel, dim3(2048), dim3(256), 0, c->stream,
-                         static_cast<const double2*>(c->d_in), (long long)nf, (int)frame_size,
-                         (long long)frame_size, static_cast<float2*>(c->d_c64));
-      e = hipGetLastError();
-      if (e != hipSuccess) break;
-      d_frames = c->d_c64;
-    }
-    rc = amcx_features18_c64_ex(d_frames, nf, frame_size, frame_size, c->d_out, AMCX_NUM_FEATURES, c->stream, v);
-    if (rc != AMCX_OK) break;
-    e = hipMemcpy2DAsync(out_host + (size_t)f0 * (size_t)out_row_stride, sizeof(float) * (size_t)out_row_stride,
-                         c->d_out, sizeof(float) * AMCX_NUM_FEATURES, sizeof(float) * AMCX_NUM_FEATURES,
-                         (size_t)nf, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // the scratch is reused by the next chunk / call
-    if (e != hipSuccess) break;
-  }
-  if (rc == AMCX_OK && e != hipSuccess) rc = hip_fail(e, "amcx_ctx_features18 host entry");
-  // a failure must not leave copies into out_host or kernels on the scratch in flight behind the error code
-  if (rc != AMCX_OK) (void)hipStreamSynchronize(c->stream);
-  return rc;
-}
-
 // ---- strided host containers ----------------------------------------------------------------------
 constexpr int kPinSlots = 3;
 
@@ -344,12 +289,12 @@ double wall_now() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-int strided_prepare(amcx_ctx* c, size_t slot, size_t dslot, size_t frames_bytes, size_t out_bytes) {
+int strided_prepare(amcx_ctx* c, size_t slot, size_t dslot, size_t frames_bytes, size_t out_bytes, bool threaded) {
   if (c->threads == 0) {
     unsigned hw = std::thread::hardware_concurrency();
     c->threads = (int)(hw == 0 ? 4 : hw > 8 ? 8 : hw);
   }
-  c->pool.resize(c->threads);
+  if (threaded) c->pool.resize(c->threads);      // the staging threads start with the first call that has work for them
   if (c->copy_stream == nullptr) AMCX_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
   for (auto& ev : c->up_done) if (ev == nullptr) AMCX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   for (auto& ev : c->slab_free) if (ev == nullptr) AMCX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -400,6 +345,8 @@ int ctx_run_strided(amcx_ctx* c, const void* re, const void* im, int32_t kind, i
   const int64_t unit = rows ? N : F;                      // staged elements per chunk unit (a frame / a plane)
   const int64_t n_units = rows ? F : N;
   size_t slot = c->slot_bytes;
+  const size_t total_staged = (size_t)unit * esz * (size_t)n_units;
+  if (slot > total_staged) slot = total_staged;                   // a per-frame call pins kilobytes, not 3 x 32 MiB
   if (slot < (size_t)unit * esz) slot = (size_t)unit * esz;       // a slot holds at least one frame / one plane
   if (slot > (size_t(4) << 30)) return AMCX_ENOMEM;               // > 4 GiB per plane: split the call by snr
   slot = (slot + 4095) & ~size_t(4095);
@@ -409,14 +356,18 @@ int ctx_run_strided(amcx_ctx* c, const void* re, const void* im, int32_t kind, i
   const double t_start = wall_now();
   // rows of complex128 rounded on the device: each device slot is followed by room for its rounded rows
   const size_t dslot = (rows && as_c128) ? slot + slot / 2 : slot;
-  int rc = strided_prepare(c, slot, dslot, rows ? 0 : (size_t)F * N * 8, sizeof(float) * AMCX_NUM_FEATURES * (size_t)F);
+  const bool threaded = total_staged >= (size_t(1) << 20);        // below 1 MiB a condition-variable wake costs more than the copy
+  int rc = strided_prepare(c, slot, dslot, rows ? 0 : (size_t)F * N * 8, sizeof(float) * AMCX_NUM_FEATURES * (size_t)F,
+                           threaded);
   if (rc != AMCX_OK) return rc;
+  amcx::Pool inline_pool;                                          // size 1: stage_runs runs on the caller
   amcx::Source src;
   src.re = static_cast<const char*>(re);
   src.im = (kind >= AMCX_SRC_F32_SPLIT) ? static_cast<const char*>(im) : nullptr;
   src.kind = kind;
   amcx_upload_stats st = {};
-  st.frames = F; st.threads = c->pool.size(); st.plane_major = rows ? 0 : 1;
+  amcx::Pool& pool = threaded ? c->pool : inline_pool;
+  st.frames = F; st.threads = pool.size(); st.plane_major = rows ? 0 : 1;
   st.source_bytes = F * (int64_t)N * (int64_t)src_esz * ((kind >= AMCX_SRC_F32_SPLIT && src.im) ? 2 : 1);
 
   hipError_t e = hipSuccess;
@@ -447,7 +398,7 @@ int ctx_run_strided(amcx_ctx* c, const void* re, const void* im, int32_t kind, i
       const double t0 = wall_now();
       // rows: run = frame g; planes: a plane is map.cnt_b runs
       const int64_t per_unit = rows ? 1 : map.cnt_b;
-      amcx::stage_runs(c->pool, pinned, src, map, u * per_unit, (u + take) * per_unit, as_c128);
+      amcx::stage_runs(pool, pinned, src, map, u * per_unit, (u + take) * per_unit, as_c128);
       st.seconds_staging += wall_now() - t0;
     }
     if (ch >= 2) { e = hipStreamWaitEvent(c->copy_stream, c->slab_free[ds], 0); if (e != hipSuccess) break; }
@@ -514,6 +465,16 @@ int ctx_run_strided(amcx_ctx* c, const void* re, const void* im, int32_t kind, i
   return rc;
 }
 
+// the row-major host entries (amcx_ctx_features18_c64_host / _c128_host and their one-shot forms): a single-snr
+// container whose frames are row_stride_elems apart -- the row path of the strided engine
+int ctx_run(amcx_ctx* c, const void* iq_host, bool is_c128, int64_t n_frames, int32_t frame_size,
+            int64_t row_stride_elems, float* out_host, int64_t out_row_stride, int32_t variant) {
+  if (c == nullptr) return AMCX_EINVAL;
+  if (n_frames < 0 || row_stride_elems < frame_size || out_row_stride < AMCX_NUM_FEATURES) return AMCX_EINVAL;
+  return ctx_run_strided(c, iq_host, nullptr, is_c128 ? AMCX_SRC_C128 : AMCX_SRC_C64, 1, n_frames, frame_size, 0,
+                         row_stride_elems, 1, out_host, out_row_stride, variant);
+}
+
 }  // namespace
 
 extern "C" {
@@ -545,8 +506,6 @@ int amcx_ctx_destroy(amcx_ctx* c) {
   if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
   for (auto ev : c->up_done) if (ev) (void)hipEventDestroy(ev);
   for (auto ev : c->slab_free) if (ev) (void)hipEventDestroy(ev);
-  if (c->d_in) (void)hipFree(c->d_in);
-  if (c->d_c64) (void)hipFree(c->d_c64);
   if (c->d_out) (void)hipFree(c->d_out);
   if (c->d_slab) (void)hipFree(c->d_slab);
   if (c->d_frames) (void)hipFree(c->d_frames);

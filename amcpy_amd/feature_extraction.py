@@ -26,12 +26,14 @@ What is different underneath:
   container is ever made on the host and the ``[0:frame_size]`` slice of a frame
   (feature_extraction.py:68) is just the first ``frame_size`` planes;
 * with several ranks (one process per GPU of one node, ``torch.distributed``
-  initialised by the caller) rank 0 alone decodes the container and publishes
-  each modulation -- the part the configuration uses, in the order it lies in
-  memory -- as a memory-mapped file in shared memory; every rank uploads its own
-  contiguous frame range from it over its own PCIe link, and rank 0 gathers the
-  (F x 18) rows and writes the files (amcpy_amd/sharding.py).  No collective
-  touches the IQ data;
+  initialised by the caller) a variable the fast reader can map (an
+  uncompressed level-5 variable of doubles or singles) is mapped by every rank
+  for itself -- the page cache is shared, nothing is decoded or copied; anything
+  else is decoded by rank 0 alone, which publishes the part the configuration
+  uses, in the order it lies in memory, as a memory-mapped file in shared
+  memory.  Either way every rank uploads its own contiguous frame range over its
+  own PCIe link, and rank 0 gathers the (F x 18) rows and writes the files
+  (amcpy_amd/sharding.py).  No collective touches the IQ data;
 * a failure raises, on every rank: the reference's worker threads swallow
   exceptions and leave zero rows behind (feature_extraction.py:33-39), and its
   parent ignores the children's exit codes (:96-97).
@@ -78,6 +80,7 @@ class SplitComplex:
         if real.dtype not in (np.float32, np.float64):
             raise TypeError(f"split containers hold float32 or float64, got {real.dtype}")
         self.real, self.imag = real, imag
+        self.source = None            # "mapped": views of a memory-mapped file every process can map for itself
         self.shape, self.ndim = real.shape, real.ndim
         self.dtype = np.dtype(np.complex64 if real.dtype == np.float32 else np.complex128)
 
@@ -497,10 +500,14 @@ def run_extraction(cfg: Config, *, compute=None, device: Optional[int] = None, v
         else:
             import torch.distributed as dist
             shared_host = _same_host(world)
+            mapped = {}                                 # rank 0: variables its reader thread has already mapped
 
             def decode_and_publish(mod):                # rank 0's reader thread
                 parsed = _load_variable(mat_path, cfg.signals.mat_info[mod])
                 n_snr, n_frames, _ = _check_container(parsed, cfg)
+                if getattr(parsed, "source", None) == "mapped":
+                    mapped[mod] = parsed                # every rank maps the variable itself: nothing to publish
+                    return "", n_snr, n_frames
                 path = _publish_container(parsed, n_snr, n_frames, N, threads)
                 published.append(path)
                 return str(path), n_snr, n_frames
@@ -534,10 +541,15 @@ def run_extraction(cfg: Config, *, compute=None, device: Optional[int] = None, v
                 # 2. this rank's frame range; a failure is kept until every rank has reported
                 local, failure = None, None
                 try:
-                    if shared_host:
-                        parsed = np.load(shared, mmap_mode="r")
-                    else:
+                    if not shared_host:
                         parsed, n_snr, n_frames = fut.result()
+                    elif shared:
+                        parsed = np.load(shared, mmap_mode="r")
+                    else:                               # mapped straight from the container, by every rank
+                        parsed = mapped.pop(mod, None) if rank == 0 else None
+                        if parsed is None:
+                            parsed = _load_variable(mat_path, key)
+                        _check_container(parsed, cfg)
                     F = n_snr * n_frames
                     lo, hi = shard_range(F, rank, world)
                     local = run(FrameRows(parsed, n_snr, n_frames, lo, hi))
@@ -548,7 +560,7 @@ def run_extraction(cfg: Config, *, compute=None, device: Optional[int] = None, v
                 # (the all-gather is also the point after which nobody maps the shared file any more)
                 statuses = [None] * world
                 dist.all_gather_object(statuses, failure)
-                if shared_host and rank == 0:
+                if shared_host and rank == 0 and shared:
                     Path(shared).unlink(missing_ok=True)
                     published.remove(Path(shared))
                 bad = [(r, s) for r, s in enumerate(statuses) if s is not None]

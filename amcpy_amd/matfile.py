@@ -94,8 +94,9 @@ def _peek_name(comp: memoryview) -> Optional[str]:
 
 
 def read_variable_v5(path, key: str):
-    """The variable ``key`` of a little-endian level-5 MAT file as views of its memory mapping:
-    ``(real, imag)`` Fortran-ordered float32 / float64 arrays (``imag`` None for a real variable).
+    """The variable ``key`` of a little-endian level-5 MAT file: ``(real, imag, how)`` with Fortran-ordered
+    float32 / float64 arrays (``imag`` None for a real variable) that are views of the file's memory mapping
+    (``how == "mapped"``) or, for a compressed variable, of its inflated bytes (``"inflated"``).
     Raises ``_Unsupported`` for what the module docstring lists, ``KeyError`` if there is no such variable."""
     with open(path, "rb") as fh:
         size = fh.seek(0, 2)
@@ -118,13 +119,13 @@ def read_variable_v5(path, key: str):
                 cls, cplx, dims, _, data_pos = _matrix_header(body, d2, d2 + n2)
                 if cls not in (MX_DOUBLE, MX_SINGLE):
                     raise _Unsupported(f"array class {cls}")
-                return _numeric_parts(body, data_pos, d2 + n2, dims, cplx)
+                return _numeric_parts(body, data_pos, d2 + n2, dims, cplx) + ("inflated",)
         elif t == MI_MATRIX and n >= 48:
             cls, cplx, dims, name, data_pos = _matrix_header(mm, d, d + n)
             if name == key:
                 if cls not in (MX_DOUBLE, MX_SINGLE):
                     raise _Unsupported(f"array class {cls}")
-                return _numeric_parts(mm, data_pos, d + n, dims, cplx)
+                return _numeric_parts(mm, data_pos, d + n, dims, cplx) + ("mapped",)
         if nxt <= pos:
             raise _Unsupported("corrupt element tag")
         pos = nxt
@@ -132,12 +133,15 @@ def read_variable_v5(path, key: str):
 
 
 def load_variable(mat_path, key: str):
-    """One variable of the container: a :class:`SplitComplex` / real ndarray over the memory-mapped
-    file when the fast reader applies, otherwise what ``scipy.io.loadmat`` returns for it."""
+    """One variable of the container: a :class:`SplitComplex` over the memory-mapped file (its ``source``
+    says ``"mapped"``, or ``"inflated"`` for a compressed variable) when the fast reader applies, otherwise
+    what ``scipy.io.loadmat`` returns for it."""
     from .feature_extraction import SplitComplex
     try:
-        real, imag = read_variable_v5(Path(mat_path), key)
-        return SplitComplex(real, imag) if imag is not None else real
+        real, imag, how = read_variable_v5(Path(mat_path), key)
+        out = SplitComplex(real, imag)
+        out.source = how
+        return out
     except _Unsupported:
         pass
     except (struct.error, ValueError, zlib.error):             # a malformed file: let scipy name the problem

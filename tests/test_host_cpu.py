@@ -322,18 +322,22 @@ _EXTRACT_WORKER = textwrap.dedent('''
     cfg = Config(paths=Paths(root=Path(os.environ["AMCX_ROOT"])),
                  signals=SignalConfig(snr_values={0: "0", 1: "10", 2: "20"}, num_frames=7, frame_size=16))
     fe.run_extraction(cfg, compute=compute, verbose=False)
-    # rank 0 alone decodes the container; every rank computes only its contiguous share
-    assert (len(loads) == 6) == (rank == 0), (rank, loads)
-    assert all(s[1] == 16 for s in seen) and sum(s[0] for s in seen) in (6 * 11, 6 * 10), seen
+    # a compressed container: rank 0 alone decodes it (and publishes); an uncompressed one is mapped by every
+    # rank for itself; either way every rank computes only its contiguous share
+    direct = os.environ["AMCX_MODE"] == "direct"
+    assert len(loads) == (6 if rank == 0 or direct else 0), (rank, loads)
+    assert all(s[1] == (20 if direct else 16) for s in seen) and sum(s[0] for s in seen) in (6 * 11, 6 * 10), seen
     print("EXTRACT_OK", rank, len(loads), sum(s[0] for s in seen))
     dist.destroy_process_group()
 ''')
 
 
-def test_two_rank_run_extraction_rank0_decodes_and_publishes(tmp_path):
-    """run_extraction with two ranks over gloo: rank 0 loads the .mat (once per variable) and
-    publishes each modulation through shared memory in the memory order it has, both ranks compute their shard, rank 0 writes
-    files equal to the single-process result; the shared files are removed afterwards."""
+@pytest.mark.parametrize("mode", ["publish", "direct"])
+def test_two_rank_run_extraction_rank0_decodes_and_publishes(tmp_path, mode):
+    """run_extraction with two ranks over gloo.  "publish": a compressed container -- rank 0 decodes each
+    variable once and publishes it through shared memory in the memory order it has.  "direct": an
+    uncompressed one -- every rank maps the variable from the file itself, nothing is published.  Both ranks
+    compute their shard, rank 0 writes files equal to the single-process result; no shared file is left."""
     import glob
     import scipy.io
     from amcpy_amd.config import Config, Paths, SignalConfig
@@ -346,7 +350,7 @@ def test_two_rank_run_extraction_rank0_decodes_and_publishes(tmp_path):
                  for m in cfg.signals.modulations_with_noise}
     for c in (cfg, cfg1):
         c.paths.ensure_dirs()
-        scipy.io.savemat(str(c.paths.mat_data / c.paths.mat_filename), container)
+        scipy.io.savemat(str(c.paths.mat_data / c.paths.mat_filename), container, do_compression=(mode == "publish"))
 
     def compute(block):
         base = np.abs(np.asarray(block)[:, :16]).sum(axis=1, dtype=np.float64)
@@ -360,12 +364,12 @@ def test_two_rank_run_extraction_rank0_decodes_and_publishes(tmp_path):
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   AMCX_REPO=str(REPO), AMCX_ROOT=str(tmp_path / "two"), PYTHONDONTWRITEBYTECODE="1")
+                   AMCX_REPO=str(REPO), AMCX_ROOT=str(tmp_path / "two"), AMCX_MODE=mode, PYTHONDONTWRITEBYTECODE="1")
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=180)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
-    assert "EXTRACT_OK 0 6 66" in outs[0] and "EXTRACT_OK 1 0 60" in outs[1], outs
+    assert "EXTRACT_OK 0 6 66" in outs[0] and f"EXTRACT_OK 1 {6 if mode == 'direct' else 0} 60" in outs[1], outs
     assert set(glob.glob(str(fe._shared_dir(0) / "amcx_frames_*"))) == before, "shared frame files left behind"
     for m in cfg.signals.modulations_with_noise:
         a = scipy.io.loadmat(str(cfg1.paths.calculated_features / f"{m}_features.mat"))
@@ -464,7 +468,9 @@ def test_mat_reader_returns_views_equal_to_loadmat(tmp_path):
             assert got.real.flags.f_contiguous and not got.real.flags.writeable and not got.real.flags.owndata
             assert np.array_equal(got[:, :, :], ref[key]) and np.array_equal(got[1, 2:4, :7], ref[key][1, 2:4, :7])
         real = load_variable(path, "just_real")
-        assert isinstance(real, np.ndarray) and real.dtype == np.float64 and np.array_equal(real, ref["just_real"])
+        assert isinstance(real, SplitComplex) and real.imag is None and real.real.dtype == np.float64
+        assert np.array_equal(real.real, ref["just_real"]) and np.array_equal(real[:2], ref["just_real"][:2])
+        assert real.source == got.source == ("inflated" if compress else "mapped")
         with pytest.raises(_Unsupported):
             read_variable_v5(path, "ints")                       # int16 storage: not the fast reader's business
         assert np.array_equal(load_variable(path, "ints"), ref["ints"])           # ... scipy's
