@@ -10,6 +10,7 @@
 
 #include "amcx_block_kernel.h"
 #include "amcx_wave_kernel.h"
+#include "amcx_quad_kernel.h"
 #include "amcx_fixup_kernel.h"
 #include "amcx_post_kernels.h"
 #include "amcx_pack_kernel.h"
@@ -184,8 +185,10 @@ int amcx_features18_c64_ex(const void* iq_dev, int64_t n_frames, int32_t frame_s
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
   const float2* iq = static_cast<const float2*>(iq_dev);
   if (v == AMCX_VARIANT_WAVE) {
-    hipError_t e = amcx::launch_wave(iq, n_frames, frame_size, row_stride_elems, out_dev,
-                                     out_row_stride, stream, cu_count());
+    // N = 8192: four waves per frame (amcx_quad_kernel.h); every other wave size: one wave per frame
+    hipError_t e = frame_size == amcx::quad::kN
+        ? amcx::quad::launch_quad(iq, n_frames, row_stride_elems, out_dev, out_row_stride, stream, cu_count())
+        : amcx::launch_wave(iq, n_frames, frame_size, row_stride_elems, out_dev, out_row_stride, stream, cu_count());
     if (e != hipSuccess) return hip_fail(e, "wave kernel launch");
     // frames the fp32 kernel flagged as outside its range (f5 = -inf): the range pass of the same wave machine
     // on a power-of-two pre-scaled copy (N = 1024, 2048, 4096), or the block kernel's fp64-sum routine (other N).

@@ -1,0 +1,445 @@
+// N = 8192: FOUR wavefronts per frame, each holding one quarter of it in registers.
+//
+// A 64 KiB frame does not fit one wave's registers.  Rounds 1-2 gave the frame to ONE wave anyway
+// (amcx_features18_wave_kernel<8192>): it streamed the frame three times -- statistics sweep, even
+// bins, odd bins -- and because 2048 waves x 64 KiB is 8x what the L2s hold, the second and third
+// visits came over the fabric: 3.44x the algorithmic bytes at the memory-side counters, 75 spilled
+// VGPRs, 28 M frames/s (profiles/r2_n8192_*).  Here every byte is read from HBM once:
+//
+//   * a workgroup is a QUAD of four waves, one per SIMD, two workgroups per CU; wave q loads quarter q of the
+//     frame (samples [2048 q, 2048 q + 2048), the N = 2048 kernel's register layout) and runs the N = 2048
+//     statistics sweep on it -- its own shifts (re-centred in fp64 by the finaliser), plus the one phase step
+//     that crosses into the next quarter;
+//   * the quad exchanges its quarters through LDS for a radix-4 decimation-in-frequency stage:
+//       X[4k + r] = FFT_2048( y_r ),   y_r[n] = W_8192^(r n) * sum_q x[n + 2048 q] (-i)^(r q)
+//     wave r forms y_r in place of its quarter (r is a compile-time constant of the code path a wave takes, so
+//     the (-i)^(rq) are sign flips and swaps and the row twiddles W_64^(r i) are immediates) and runs the
+//     N = 2048 register FFT on it (fft_peak<16>, amcx_wave_kernel.h); the frame's spectral peak is the maximum
+//     over the four waves.  The exchange goes in two rounds of eight rows (32 KiB each: one ds_write_b128 /
+//     three ds_read_b128 per row and wave, linear and conflict-free), so that the area -- which is also the
+//     four waves' FFT scratch -- stays at 34 KiB and TWO independent workgroups fit a CU: a first version with
+//     one 64 KiB round kept both quads of an 8-wave workgroup in step behind shared barriers and left the waves
+//     parked for 32 % of their cycles (9 % in the barrier-free N = 4096 kernel);
+//   * the mean envelope crosses the quad through four floats of LDS (the envelope's second sweep is about the
+//     exact mean, features.py:82-85).  Four s_barrier per frame, each among four waves;
+//   * the next frame's quarter is requested before the current frame's FFT and lands during it;
+//   * after four frames the wave holding quarter 0 turns the 4 x 4 stash rows into features in fp64 (one frame
+//     per lane) while the others go on: the stash is double-buffered.
+//
+// LDS per workgroup: 16.3 KB of FFT tables + 34 KiB exchange / scratch + 8.4 KB stash = 59.5 KB; 256 VGPRs:
+// two 256-thread workgroups per CU, 2 waves per SIMD, as the N = 4096 kernel.  No global workspace, no
+// inter-workgroup communication.
+#pragma once
+
+#include "amcx_wave_kernel.h"
+
+namespace amcx {
+namespace quad {
+
+using namespace wave;
+
+constexpr int kN = 8192, kQuarter = 2048, kRowsQ = 16;
+constexpr int kWavesPerQuad = 4, kThreads = 64 * kWavesPerQuad, kWGsPerCU = 2;
+constexpr int kBatch = 4;                                   // frames a quad finalises together
+using C2 = Cfg<2048>;                                        // the register FFT every wave runs
+constexpr int kTabBytes = C2::kT2Bytes + C2::kT3Bytes;
+constexpr int kRoundRows = kRowsQ / 2;                       // rows of a quarter exchanged per round
+constexpr int kRegionBytes = 8704;                           // a wave's part of the area: 8 rows of 1 KiB in a round, its FFT exchange buffer afterwards
+constexpr int kFrameBytes = kWavesPerQuad * kRegionBytes;
+constexpr int kStashRow = kStashStride;                      // floats per (frame, quarter)
+constexpr int kStashFloats = kBatch * kWavesPerQuad * kStashRow;       // one buffer of one quad
+constexpr int kOffFrames = kTabBytes;
+constexpr int kOffStash = kOffFrames + kFrameBytes;
+constexpr int kOffMu = kOffStash + 2 * kStashFloats * 4;
+constexpr int kLdsBytes = kOffMu + kWavesPerQuad * 4;
+static_assert(kWGsPerCU * kLdsBytes <= 163840, "two workgroups per CU");
+static_assert(kExchangeBytes <= kRegionBytes && kRoundRows * 1024 <= kRegionBytes, "a wave's region holds a round's rows and its FFT exchange buffer");
+
+// (r, i) *= W_64^J, J = 0..63
+template <int J>
+__device__ __forceinline__ void mul_w64_any(float& r, float& i) {
+  if constexpr (J < 32) {
+    mul_w64<J>(r, i);
+  } else {
+    mul_w64<J - 32>(r, i);
+    r = -r; i = -i;
+  }
+}
+
+// acc += v * (-i)^K, K = 0..3
+template <int K>
+__device__ __forceinline__ void add_rot(float& ar, float& ai, float vr, float vi) {
+  if constexpr (K == 0) { ar += vr; ai += vi; }
+  else if constexpr (K == 1) { ar += vi; ai -= vr; }        // * (-i): (re, im) -> (im, -re)
+  else if constexpr (K == 2) { ar -= vr; ai -= vi; }
+  else { ar -= vi; ai += vr; }                              // * (+i)
+}
+
+// the quarter in xr / xi (this wave's own: quarter RQ) -> y_RQ in place, the other three quarters from `fb`
+template <int RQ, int ROW0>
+__device__ __forceinline__ void radix4_stage(float (&xr)[2 * kRowsQ], float (&xi)[2 * kRowsQ], const char* fb, int lane,
+                                             const float4 lw) {
+  static_for<kRoundRows>([&](auto ii) {
+    constexpr int i = ROW0 + decltype(ii)::value;
+    float t0r = xr[2 * i], t0i = xi[2 * i], t1r = xr[2 * i + 1], t1i = xi[2 * i + 1];      // own term: (-i)^(RQ*RQ) applied below
+    float a0r = 0.f, a0i = 0.f, a1r = 0.f, a1i = 0.f;
+    static_for<4>([&](auto qq) {
+      constexpr int q = decltype(qq)::value;
+      constexpr int K = (RQ * q) & 3;
+      if constexpr (q == RQ) {
+        add_rot<K>(a0r, a0i, t0r, t0i);
+        add_rot<K>(a1r, a1i, t1r, t1i);
+      } else {
+        const float4 v = *reinterpret_cast<const float4*>(fb + q * kRegionBytes + (i - ROW0) * 1024 + lane * 16);
+        add_rot<K>(a0r, a0i, v.x, v.y);
+        add_rot<K>(a1r, a1i, v.z, v.w);
+      }
+    });
+    if constexpr (RQ != 0) {
+      // W_8192^(RQ n), n = 128 i + 2 l + b:  W_64^(RQ i) (an immediate) times W_8192^(RQ (2l + b)) (this lane's lw)
+      mul_w64_any<(RQ * i) & 63>(a0r, a0i);
+      mul_w64_any<(RQ * i) & 63>(a1r, a1i);
+      xr[2 * i] = __builtin_fmaf(a0r, lw.x, -(a0i * lw.y));
+      xi[2 * i] = __builtin_fmaf(a0r, lw.y, a0i * lw.x);
+      xr[2 * i + 1] = __builtin_fmaf(a1r, lw.z, -(a1i * lw.w));
+      xi[2 * i + 1] = __builtin_fmaf(a1r, lw.w, a1i * lw.z);
+    } else {
+      xr[2 * i] = a0r; xi[2 * i] = a0i; xr[2 * i + 1] = a1r; xi[2 * i + 1] = a1i;
+    }
+  });
+}
+
+// wave reduction of a frame-quarter's 27 per-lane sums into one stash row: two swap levels, then four
+// DPP steps inside the 16-lane rows (the form the wave kernel uses, amcx_wave_kernel.h)
+__device__ __forceinline__ void reduce_store(float (&r28)[28], float* row, int lane) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\t"
+      "v_permlane32_swap_b32 %4, %5\n\tv_permlane32_swap_b32 %6, %7\n\t"
+      "v_permlane32_swap_b32 %8, %9\n\tv_permlane32_swap_b32 %10, %11\n\t"
+      "v_permlane32_swap_b32 %12, %13\n\tv_permlane32_swap_b32 %14, %15\n\t"
+      "v_permlane32_swap_b32 %16, %17\n\tv_permlane32_swap_b32 %18, %19\n\t"
+      "v_permlane32_swap_b32 %20, %21\n\tv_permlane32_swap_b32 %22, %23\n\t"
+      "v_permlane32_swap_b32 %24, %25\n\tv_permlane32_swap_b32 %26, %27"
+      : "+v"(r28[0]), "+v"(r28[1]), "+v"(r28[2]), "+v"(r28[3]), "+v"(r28[4]), "+v"(r28[5]),
+        "+v"(r28[6]), "+v"(r28[7]), "+v"(r28[8]), "+v"(r28[9]), "+v"(r28[10]), "+v"(r28[11]),
+        "+v"(r28[12]), "+v"(r28[13]), "+v"(r28[14]), "+v"(r28[15]), "+v"(r28[16]), "+v"(r28[17]),
+        "+v"(r28[18]), "+v"(r28[19]), "+v"(r28[20]), "+v"(r28[21]), "+v"(r28[22]), "+v"(r28[23]),
+        "+v"(r28[24]), "+v"(r28[25]), "+v"(r28[26]), "+v"(r28[27]));
+  float r14[14];
+  static_for<14>([&](auto jj) {
+    constexpr int j = decltype(jj)::value;
+    r14[j] = r28[2 * j] + r28[2 * j + 1];
+  });
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\t"
+      "v_permlane16_swap_b32 %4, %5\n\tv_permlane16_swap_b32 %6, %7\n\t"
+      "v_permlane16_swap_b32 %8, %9\n\tv_permlane16_swap_b32 %10, %11\n\t"
+      "v_permlane16_swap_b32 %12, %13"
+      : "+v"(r14[0]), "+v"(r14[1]), "+v"(r14[2]), "+v"(r14[3]), "+v"(r14[4]), "+v"(r14[5]),
+        "+v"(r14[6]), "+v"(r14[7]), "+v"(r14[8]), "+v"(r14[9]), "+v"(r14[10]), "+v"(r14[11]),
+        "+v"(r14[12]), "+v"(r14[13]));
+  float r7[7];
+  static_for<7>([&](auto jj) {
+    constexpr int j = decltype(jj)::value;
+    float v = r14[2 * j] + r14[2 * j + 1];
+    v += dpp<kQuadXor1>(v);
+    v += dpp<kQuadXor2>(v);
+    v += dpp<kRowHalfMirror>(v);
+    v += dpp<kRowMirror>(v);
+    r7[j] = v;
+  });
+  if ((lane & 15) == 0) {                    // one lane per 16-lane row: rows hold sums 4j + {0, 2, 1, 3}
+    const int rsel = lane >> 4;
+    float* dst = row + (((rsel & 1) << 1) | (rsel >> 1));
+    static_for<7>([&](auto jj) {
+      constexpr int j = decltype(jj)::value;
+      dst[4 * j] = r7[j];
+    });
+  }
+}
+
+// sum over the quarters of sum (v - K0)^k, k = 1..4, from each quarter's sums about its own shift K_q
+// (n_q values each): (v - K0) = (v - K_q) + d,  d = K_q - K0
+struct Recentred {
+  double s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+  __device__ __forceinline__ void add(double n, double d, double q1, double q2, double q3 = 0, double q4 = 0) {
+    const double d2 = d * d;
+    s1 += q1 + n * d;
+    s2 += q2 + 2.0 * d * q1 + n * d2;
+    s3 += q3 + 3.0 * d * q2 + 3.0 * d2 * q1 + n * d2 * d;
+    s4 += q4 + 4.0 * d * q3 + 6.0 * d2 * q2 + 4.0 * d2 * d * q1 + n * d2 * d2;
+  }
+};
+
+__global__ __launch_bounds__(kThreads, 2) void amcx_features18_quad_kernel(
+    const float2* __restrict__ iq, long long n_frames, long long row_stride,
+    float* __restrict__ out, long long out_stride) {
+  extern __shared__ float4 amcx_quad_smem[];
+  char* smem = reinterpret_cast<char*>(amcx_quad_smem);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int q = __builtin_amdgcn_readfirstlane(tid >> 6);   // quarter of the frame this wave takes = residue r it produces
+  char* t2 = smem;
+  char* t3 = smem + C2::kT2Bytes;
+  char* fb = smem + kOffFrames;                             // exchange area / FFT scratch, one region per wave
+  float* stash_q = reinterpret_cast<float*>(smem + kOffStash);
+  float* mu_part = reinterpret_cast<float*>(smem + kOffMu);
+
+  // ---- tables of the 2048-point register FFT (as amcx_wave_kernel.h builds them for N = 2048) ----
+  auto w_nf = [](int e) {
+    float sn, cs;
+    sincospif((float)(e & (C2::kFftN - 1)) * (2.0f / (float)C2::kFftN), &sn, &cs);
+    return make_float2(cs, -sn);
+  };
+  constexpr int R = C2::kFftRows;                           // 16
+  for (int e = tid; e < 8 * C2::kPhases * 15; e += kThreads) {
+    const int slot = e / 15, i = e % 15;
+    const int k1 = 2 * (slot & 7) + (slot >> 3);
+    const int sidx = i < 1 ? 0 : i < 3 ? 1 : i < 7 ? 2 : 3;
+    const int k = i - ((1 << sidx) - 1), Lp = 2 << sidx, d = 16 / Lp;
+    reinterpret_cast<float2*>(t2)[e] = w_nf(8 * k1 * d + k * (C2::kFftN / Lp));
+  }
+  for (int e = tid; e < C2::kPhases * 2 * 7 * 64; e += kThreads) {
+    const int ln = e & 63, i = (e >> 6) % 7, c = e / (7 * 64);
+    const int k1 = 2 * (ln >> 3) + (c >> 1), k2 = (ln & 7) + 8 * (c & 1);
+    const int sidx = i < 1 ? 0 : i < 3 ? 1 : 2;
+    const int k = i - ((1 << sidx) - 1), Lp = 2 << sidx, d = 8 / Lp;
+    reinterpret_cast<float2*>(t3)[e] = w_nf((R * k2 + k1) * d + k * (C2::kFftN / Lp));
+  }
+  // this lane's twiddles of the radix-4 stage: W_8192^(q (2 l + b)), b = 0, 1
+  float4 lw;
+  {
+    float s0, c0, s1, c1;
+    sincospif((float)(q * (2 * lane)) * (2.0f / (float)kN), &s0, &c0);
+    sincospif((float)(q * (2 * lane + 1)) * (2.0f / (float)kN), &s1, &c1);
+    lw = make_float4(c0, -s0, c1, -s1);
+  }
+  __syncthreads();
+
+  const int kkL = lane >> 3, n3L = lane & 7;
+  char* ex = fb + q * kRegionBytes;                         // this wave's region: a round's rows, then its FFT exchange buffer
+  LaneAddr la;
+  la.t1c = nullptr; la.t2c = nullptr;
+  la.tw2 = t2 + kkL * kTw2Stride;
+  la.tw3 = t3 + lane * 8;
+  la.ex1_w = ex + lane * 8;
+  la.ex1_r = ex + (kkL * kEx1StrideKK + (n3L & 1) * kEx1StrideB + (n3L >> 1)) * 8;
+  la.ex2_w = ex + lane * 8;
+  la.ex2_r = ex + (n3L * kEx2StrideK2 + kkL * 8) * 8;
+
+  // ---- work: batches of kBatch frames; workgroup w owns a contiguous run of them ----
+  const long long n_batches = (n_frames + kBatch - 1) / kBatch;
+  const long long per_wg = (n_batches + gridDim.x - 1) / gridDim.x;
+  const long long b0 = (long long)blockIdx.x * per_wg;
+  long long b1 = b0 + per_wg;
+  if (b1 > n_batches) b1 = n_batches;
+  const int n_iters = (int)(b1 > b0 ? b1 - b0 : 0);
+
+  // the wave with quarter 0: the batch whose stash rows are complete once the next barrier has been passed
+  long long pend_f0 = 0;
+  int pend_n = 0, pend_buf = 0;
+  auto finalise = [&](long long f_first, int count, const float* stash) {
+    float feat[18];
+    bool tie = false;
+    float kw0 = 0.f;
+    if (lane < count) {
+      const float* rows = stash + lane * kWavesPerQuad * kStashRow;
+      auto sm = [&](int k) -> double {                      // shift-free sums: the four quarters added in fp64
+        return ((double)rows[k] + (double)rows[kStashRow + k]) + ((double)rows[2 * kStashRow + k] + (double)rows[3 * kStashRow + k]);
+      };
+      FrameSums F;
+      F.sA = sm(0); F.sBh = sm(1); F.sP = sm(2); F.sAA = sm(3); F.sX4 = sm(4); F.sAB = sm(5);
+      F.sAP = sm(6); F.sBP = sm(7); F.sAAA = sm(8); F.sABB = sm(9); F.sAAB = sm(10);
+      F.sBBB = sm(11); F.sAAP = sm(12); F.sX4P = sm(13); F.sABP = sm(14);
+      F.sa = sm(15); F.sad1 = sm(16); F.sad2 = sm(17); F.sad4 = sm(18);
+      // shifted sums: re-centred about quarter 0's shifts
+      F.Kt = rows[28]; F.Kw = rows[29]; F.Ka = rows[30];
+      kw0 = rows[29];
+      Recentred th, ab, ws;
+      float pk = 0.f;
+      bool flagged = false;
+#pragma unroll
+      for (int h = 0; h < kWavesPerQuad; ++h) {
+        const float* r = rows + h * kStashRow;
+        th.add((double)kQuarter, (double)r[28] - F.Kt, r[19], r[20]);
+        ab.add((double)kQuarter, (double)r[30] - F.Ka, r[21], r[22]);
+        ws.add(h == kWavesPerQuad - 1 ? (double)(kQuarter - 1) : (double)kQuarter, (double)r[29] - F.Kw, r[23], r[24], r[25], r[26]);
+        pk = __builtin_fmaxf(pk, r[27]);
+        if (!(r[27] == r[27])) pk = r[27];                  // a NaN peak (non-finite sample) must survive the maximum
+        flagged = flagged || r[31] != 0.0f;
+      }
+      F.std1 = th.s1; F.std2 = th.s2; F.sab1 = ab.s1; F.sab2 = ab.s2;
+      F.swd1 = ws.s1; F.swd2 = ws.s2; F.swd3 = ws.s3; F.swd4 = ws.s4;
+      F.gmax_raw = pk;
+      F.pi_tie = flagged;
+      finalize_features(F, kN, feat);
+      if (is_outside_fp32_range(F, kN)) feat[4] = -__builtin_inff();       // redone by amcx_range_fixup_kernel
+      tie = __builtin_signbitf(feat[4]) && feat[4] == feat[4] && feat[4] != -__builtin_inff();
+    }
+    unsigned long long ties = __builtin_amdgcn_ballot_w64(tie);
+    while (ties != 0) {                                     // phase steps within an fp32 ulp of +-pi: exact f5 / f9
+      const int idx = __builtin_ctzll(ties);
+      ties &= ties - 1;
+      const float kwt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, kw0), idx));
+      float f5x, f9x;
+      wave_exact_frequency<kN>(iq + (f_first + idx) * row_stride, 1.0f, kwt, lane, f5x, f9x);
+      if (lane == idx) { feat[4] = f5x; feat[8] = f9x; }
+    }
+    if (lane < count) {
+      float* dst = out + (f_first + lane) * out_stride;
+#pragma unroll
+      for (int j = 0; j < 18; ++j) dst[j] = feat[j];
+    }
+  };
+
+  // frame g of this workgroup's round `it`, if it exists
+  auto frame_at = [&](int it, int g, long long& f) -> bool {
+    f = (b0 + it) * kBatch + g;
+    return it < n_iters && f < n_frames;
+  };
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  // this wave's quarter of frame f, HBM -> registers: 16 x global_load_dwordx4, every byte read once -> non-temporal
+  auto load_quarter = [&](v4f (&v)[kRowsQ], long long f) {
+    const float2* src = iq + f * row_stride + q * kQuarter + 2 * lane;
+    static_for<kRowsQ>([&](auto ii) {
+      constexpr int i = decltype(ii)::value;
+      v[i] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src + 128 * i));
+    });
+  };
+  // rows [ROW0, ROW0 + 8) of the quarter -> this wave's region of the exchange area
+  auto publish_rows = [&](const float (&xr)[2 * kRowsQ], const float (&xi)[2 * kRowsQ], auto row0) {
+    constexpr int ROW0 = decltype(row0)::value;
+    static_for<kRoundRows>([&](auto ii) {
+      constexpr int i = decltype(ii)::value;
+      *reinterpret_cast<float4*>(ex + i * 1024 + lane * 16) =
+          make_float4(xr[2 * (ROW0 + i)], xi[2 * (ROW0 + i)], xr[2 * (ROW0 + i) + 1], xi[2 * (ROW0 + i) + 1]);
+    });
+  };
+  auto radix4_round = [&](float (&xr)[2 * kRowsQ], float (&xi)[2 * kRowsQ], auto row0) {
+    constexpr int ROW0 = decltype(row0)::value;
+    switch (q) {
+      case 0: radix4_stage<0, ROW0>(xr, xi, fb, lane, lw); break;
+      case 1: radix4_stage<1, ROW0>(xr, xi, fb, lane, lw); break;
+      case 2: radix4_stage<2, ROW0>(xr, xi, fb, lane, lw); break;
+      default: radix4_stage<3, ROW0>(xr, xi, fb, lane, lw); break;
+    }
+  };
+  using Row0 = std::integral_constant<int, 0>;
+  using Row8 = std::integral_constant<int, kRoundRows>;
+
+  // The next frame's quarter is requested before this frame's FFT and lands behind it.
+  v4f nxt[kRowsQ];
+  {
+    long long f_first;
+    if (frame_at(0, 0, f_first)) load_quarter(nxt, f_first);
+  }
+
+  for (int it = 0; it < n_iters; ++it) {
+    const long long f0 = (b0 + it) * kBatch;
+    const long long left = n_frames - f0;
+    const int n_here = left < kBatch ? (int)left : kBatch;
+    float* const stash = stash_q + (it & 1) * kStashFloats;
+    for (int g = 0; g < n_here; ++g) {                      // n_here is the same for the quad's four waves: so are the barriers
+      float xr[2 * kRowsQ], xi[2 * kRowsQ];
+      Stats S;
+      // ---- phase A: this wave's quarter (requested a frame ago), statistics sweep, rows 0-7 published ----
+      static_for<kRowsQ>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        xr[2 * i] = nxt[i].x; xi[2 * i] = nxt[i].y; xr[2 * i + 1] = nxt[i].z; xi[2 * i + 1] = nxt[i].w;
+      });
+      // the first sample of the next quarter: the phase step that crosses the quarter boundary
+      float2 nx = make_float2(1.f, 0.f);
+      if (q < 3) nx = iq[(f0 + g) * row_stride + (q + 1) * kQuarter];
+      static_for<kRowsQ>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        float a0, a1;                                       // |x| is taken again in phase B: no room to park 8 KB per wave
+        S.template row<i == 0, i == kRowsQ - 1>(xr[2 * i], xi[2 * i], xr[2 * i + 1], xi[2 * i + 1], lane, a0, a1);
+      });
+      publish_rows(xr, xi, Row0{});
+      if (q < 3) {
+        const float an = __builtin_amdgcn_sqrtf(__builtin_fmaf(nx.x, nx.x, __builtin_fmaf(nx.y, nx.y, kTinyPower)));
+        const float w = wrapped_step(fast_angle(nx.x, nx.y, an), S.th_b1_prev);
+        if (lane == 63) {                                   // lane 63 holds the quarter's last sample (row<.., LAST> gave it a null step)
+          S.step(w);
+          S.wmax = __builtin_fmaxf(S.wmax, __builtin_fabsf(w));
+        }
+      }
+      {
+        const float sa_w = wave_sum_l63(S.sa);
+        if (lane == 63) mu_part[q] = sa_w;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();                                      // (1) rows 0-7 of every quarter and the envelope partial sums are in LDS
+      // ---- phase B: envelope about the exact mean, sums -> stash, radix-4 stage in two rounds ----
+      {
+        const float mu = ((mu_part[0] + mu_part[1]) + (mu_part[2] + mu_part[3])) * (1.0f / (float)kN);
+        static_for<2 * kRowsQ>([&](auto ee) {
+          constexpr int e = decltype(ee)::value;
+          S.envelope(__builtin_amdgcn_sqrtf(__builtin_fmaf(xr[e], xr[e], __builtin_fmaf(xi[e], xi[e], kTinyPower))), mu);
+        });
+        float* const row = stash + (g * kWavesPerQuad + q) * kStashRow;
+        float r28[28] = {S.sA, S.sBh, S.sP, S.sAA, S.sX4, S.sAB, S.sAP, S.sBP, S.sAAA, S.sABB,
+                         S.sAAB, S.sBBB, S.sAAP, S.sX4P, S.sABP, S.sa, S.sad1, S.sad2, S.sad4,
+                         S.st1, S.st2, S.sab1, S.sab2, S.sw1, S.sw2, S.sw3, S.sw4, 0.f};
+        const unsigned long long tie = __builtin_amdgcn_ballot_w64(S.wmax > kPi - kTieBand);
+        reduce_store(r28, row, lane);
+        if (lane == 63) {
+          row[kNumSums + 1] = S.Kt;
+          row[kNumSums + 2] = S.Kw;
+          row[kNumSums + 3] = S.Ka;
+          row[kNumSums + 4] = tie != 0 ? 1.0f : 0.0f;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      radix4_round(xr, xi, Row0{});
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();                                      // (2) round 1 has been read
+      publish_rows(xr, xi, Row8{});
+      __syncthreads();                                      // (3) rows 8-15 of every quarter are in LDS
+      radix4_round(xr, xi, Row8{});
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();                                      // (4) round 2 has been read: a wave's region is its FFT scratch now
+      __builtin_amdgcn_sched_barrier(0);
+      // The next frame's quarter is requested here, before the FFT, and lands behind it -- except when this wave has a
+      // batch to finalise: the fp64 algebra wants ~200 registers, so it runs after the FFT, when y_q is dead, and the
+      // request follows it (one exposed round trip per batch, on one wave; the CU's other workgroup covers it).
+      const bool finalise_now = q == 0 && g == 0 && pend_n > 0;
+      long long f_next;                                     // (it, g + 1), or the first frame of the next round
+      const bool more = g + 1 < n_here ? frame_at(it, g + 1, f_next) : frame_at(it + 1, 0, f_next);
+      if (more && !finalise_now) load_quarter(nxt, f_next);
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- phase C: 2048-point register FFT of y_q, its peak into the stash row ----
+      {
+        const float peak = fft_peak<R>(xr, xi, la);
+        const float pk = wave_max_l63(peak);
+        if (lane == 63) stash[(g * kWavesPerQuad + q) * kStashRow + kNumSums] = pk;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (finalise_now) {                                   // the previous batch: every wave is past its last FFT (barrier 1 of this frame)
+        finalise(pend_f0, pend_n, stash_q + pend_buf * kStashFloats);
+        pend_n = 0;
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) load_quarter(nxt, f_next);
+      }
+    }
+    if (q == 0) { pend_f0 = f0; pend_n = n_here; pend_buf = it & 1; }
+  }
+  __syncthreads();                                          // the last batch's FFT peaks are in the stash
+  if (q == 0 && pend_n > 0) finalise(pend_f0, pend_n, stash_q + pend_buf * kStashFloats);
+}
+
+inline hipError_t launch_quad(const float2* iq, int64_t n_frames, int64_t row_stride, float* out,
+                              int64_t out_stride, hipStream_t stream, int cus) {
+  const int64_t n_batches = (n_frames + kBatch - 1) / kBatch;
+  int64_t grid = (int64_t)cus * kWGsPerCU;                   // persistent: two resident workgroups per CU
+  if (grid > n_batches) grid = n_batches;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(amcx_features18_quad_kernel, dim3((unsigned)grid), dim3(kThreads), kLdsBytes, stream, iq,
+                     (long long)n_frames, (long long)row_stride, out, (long long)out_stride);
+  return hipGetLastError();
+}
+
+}  // namespace quad
+}  // namespace amcx

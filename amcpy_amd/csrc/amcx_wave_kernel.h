@@ -1451,7 +1451,7 @@ inline const char* wave_kernel_name(int frame_size) {
     case 1024: return "amcx_features18_wave_kernel<1024>";
     case 2048: return "amcx_features18_wave_kernel<2048>";
     case 4096: return "amcx_features18_wave_kernel<4096>";
-    case 8192: return "amcx_features18_wave_kernel<8192>";
+    case 8192: return "amcx_features18_quad_kernel";
     default: return "";
   }
 }

@@ -9,7 +9,12 @@ Criterion (tests/test_gpu_parity.py): features 1-9, 11 plain relative; cumulants
 to max(|value|, S), S = sum |terms| of the cumulant's formula.  `beyond_unfloored` counts frames over
 1e-5 on that scale; `worst_floored` uses max(S, 2e-3 * S with every moment replaced by the mean of
 its summands' magnitudes) -- chance cancellation of a whole moment (|mean x^6| 1000x below mean |x|^6)
-otherwise collapses S below what any fp32 accumulation can resolve.  Not part of the test-suite."""
+otherwise collapses S below what any fp32 accumulation can resolve.  At the BASELINE frame sizes every
+fourth frame is also run through the oracle IN COMPLEX64 (features18_frame(dtype=complex64): the
+reference's own arithmetic on the same samples): `ref_c64_plain_per_feature` is that path's worst plain
+relative distance from the complex128 result, `kernel_plain_same_frames` the kernel's on the same frames,
+`kernel_beyond_twice_ref_gap` the frames where the kernel is outside both the scaled 1e-5 and twice the
+reference's gap.  Not part of the test-suite."""
 import json
 import sys
 import time
@@ -34,7 +39,9 @@ for N in (128, 256, 512, 1000, 1024, 1536, 2048, 4096, 8192):
     worst_s = np.zeros(18)
     worst_p = np.zeros(18)
     worst_f = np.zeros(18)
-    n = beyond = 0
+    ref32_gap = np.zeros(18)
+    kern_same = np.zeros(18)
+    n = beyond = n32 = beyond_gap = 0
     t0 = time.time()
     for mi, mod in enumerate(synth.MODS6):
         for si, snr in enumerate(synth.snr_grid(26)):
@@ -50,6 +57,18 @@ for N in (128, 256, 512, 1000, 1024, 1536, 2048, 4096, 8192):
             worst_f = np.maximum(worst_f, f.max(axis=0))
             beyond += int((s > 1e-5).any(axis=1).sum())
             n += per
+            if N in (1024, 2048, 4096):
+                pick = np.arange(0, per, 4)
+                with np.errstate(all="ignore"):
+                    g32 = np.stack([orc.features18_frame(x[i], dtype=np.complex64) for i in pick]).astype(np.float64)
+                    g64 = gold[pick].astype(np.float64)
+                    gap = np.abs(g32 - g64)
+                    err = np.abs(got[pick].astype(np.float64) - g64)
+                    ref32_gap = np.maximum(ref32_gap, np.nan_to_num(gap / np.abs(g64)).max(axis=0))
+                    kern_same = np.maximum(kern_same, np.nan_to_num(err / np.abs(g64)).max(axis=0))
+                    allowed = np.maximum(1e-5 * np.maximum(np.abs(g64), S[pick]), 2.0 * gap)
+                beyond_gap += int((err > allowed).any(axis=1).sum())
+                n32 += len(pick)
     print(f"N={N} frames={n} ({time.time()-t0:.0f}s)  beyond unfloored 1e-5: {beyond}")
     print("  worst scaled :", " ".join(f"{v:.1e}" for v in worst_s), " max", f"{worst_s.max():.2e}")
     print("  worst floored:", " ".join(f"{v:.1e}" for v in worst_f), " max", f"{worst_f.max():.2e}")
@@ -60,5 +79,13 @@ for N in (128, 256, 512, 1000, 1024, 1536, 2048, 4096, 8192):
                                 "worst_plain_ids_1_9_11": float(worst_p[[0, 1, 2, 3, 4, 5, 6, 7, 8, 10]].max()),
                                 "worst_plain_per_feature": [float(v) for v in worst_p],
                                 "worst_scaled_per_feature": [float(v) for v in worst_s]}
+    if n32:
+        print("  ref complex64 path, plain :", " ".join(f"{v:.1e}" for v in ref32_gap), f"({n32} frames)")
+        print("  kernel, same frames, plain:", " ".join(f"{v:.1e}" for v in kern_same),
+              f" beyond scaled 1e-5 AND twice the reference's gap: {beyond_gap}")
+        summary["sizes"][str(N)].update({"frames_also_run_in_complex64": n32,
+                                         "ref_c64_plain_per_feature": [float(v) for v in ref32_gap],
+                                         "kernel_plain_same_frames": [float(v) for v in kern_same],
+                                         "kernel_beyond_twice_ref_gap": beyond_gap})
 if out_json:
     Path(out_json).write_text(json.dumps(summary, indent=1))
