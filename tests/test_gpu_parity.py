@@ -202,25 +202,34 @@ def test_wave_kernel_short_power_of_two_frames():
 
 
 def test_wave_kernel_8192():
-    """N = 8192: two radix-2 splits in front of the 2048-point register FFT, lower half in
-    registers, upper half streamed, second visit for the odd bins; against the oracle and the
-    block kernel (LDS radix-2 FFT, fp64 sums)."""
+    """N = 8192: four waves per frame (amcx_quad_kernel.h) -- quarters in registers, radix-4 exchange through
+    LDS, four 2048-point register FFTs; against the oracle and the block kernel (LDS radix-2 FFT, fp64 sums).
+    Pure tones on bins of every residue mod 4 (each residue is one wave's FFT), frame counts that leave ragged
+    batches and idle workgroups, and every frame bit-identical whatever its position in the batch."""
     from amcpy_amd import synth, _lib
     N = 8192
-    assert _lib.kernel_name(N, _lib.VARIANT_AUTO) == "amcx_features18_wave_kernel<8192>"
+    assert _lib.kernel_name(N, _lib.VARIANT_AUTO) == "amcx_features18_quad_kernel"
     x = np.concatenate([synth.host_block(m, snr, 23, N, seed=N + i)
                         for i, (m, snr) in enumerate((("BPSK", -5.0), ("QPSK", 3.0), ("64QAM", 20.0), ("WGN", 0.0)))])
-    # a pure tone on an odd bin and one on an even bin: both branches of the first split carry the peak
+    # pure tones: residues 3, 0, 1, 2 of the bin index mod 4 -- the peak comes from a different wave each time
     n = np.arange(N)
     x[0] = np.exp(2j * np.pi * 1235 * n / N).astype(np.complex64)
     x[1] = np.exp(2j * np.pi * 2468 * n / N).astype(np.complex64)
+    x[2] = np.exp(2j * np.pi * 4097 * n / N).astype(np.complex64)
+    x[3] = np.exp(2j * np.pi * 8190 * n / N).astype(np.complex64)
     gold = orc.features18_batch(x)
     got = _run(x, "wave")
-    assert abs(got[0, 0] / N - 1.0) < 1e-5 and abs(got[1, 0] / N - 1.0) < 1e-5     # |X|^2 / N = N
-    _assert_parity(got[2:], gold[2:], x[2:], "wave N=8192")
+    assert np.all(np.abs(got[:4, 0] / N - 1.0) < 1e-5)                               # |X|^2 / N = N
+    _assert_parity(got[4:], gold[4:], x[4:], "quad N=8192")
     blk = _run(x, "block")
     _, scaled = orc.parity_errors(got, blk, orc.conditioning_scales(x, absolute=True))
-    assert scaled[:, 0].max() <= 2e-5 and scaled[2:].max() <= 2e-5, scaled.max(axis=0)
+    assert scaled[:, 0].max() <= 2e-5 and scaled[4:].max() <= 2e-5, scaled.max(axis=0)
+    # ragged batches (4 frames each), fewer batches than workgroups, one frame alone: bit-identical rows
+    for count in (1, 2, 3, 5, 7, 41, 92):
+        sub = _run(x[:count], "wave")
+        assert np.array_equal(sub, got[:count], equal_nan=True), count
+    perm = np.random.default_rng(8).permutation(x.shape[0])
+    assert np.array_equal(_run(x[perm], "wave"), got[perm], equal_nan=True)
 
 
 def test_bad_frames_do_not_leak_into_neighbours():
