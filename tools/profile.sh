@@ -7,7 +7,7 @@ TAG=${1:-r1}; shift
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-BENCH="python3 bench.py --no-cpu-baseline --no-h2d --steps 20 --warmup 5 $@"
+BENCH="python3 bench.py --no-cpu-baseline --no-h2d --no-d2h --steps 20 --warmup 5 $@"
 set -x
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/bench_trace.json 2> $OUT/trace.err || exit 1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > /dev/null 2> $OUT/pmc_fetch.err || exit 1

@@ -1,0 +1,19 @@
+#!/bin/bash
+# The round's committed evidence in one gpurun call: rocprofv3 passes at the BASELINE frame sizes (+ 8192), the
+# default bench line with both CPU baselines, every size un-profiled, the in-kernel clock.
+#   bash tools/profile_all.sh r3     -> gpurun_out/prof_r3_n*/, gpurun_out/r3_*.json*
+TAG=${1:-r3}
+for N in 2048 4096 1024 8192; do
+  bash tools/profile.sh ${TAG}_n$N --frame-size $N > gpurun_out/${TAG}_n${N}_profile.log 2>&1 || { echo "profile N=$N failed"; tail -5 gpurun_out/${TAG}_n${N}_profile.log; exit 1; }
+  echo "profiled N=$N"
+done
+bash tools/bench_sizes.sh gpurun_out/${TAG}_bench_all_sizes.jsonl > gpurun_out/${TAG}_bench_all_sizes.txt 2>&1 || exit 1
+cat gpurun_out/${TAG}_bench_all_sizes.txt
+timeout -k 10 400 python3 bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err || { tail -5 gpurun_out/${TAG}_bench_default.err; exit 1; }
+python3 -c "
+import json; d=json.load(open('gpurun_out/${TAG}_bench_default.json')); r=d['roofline']
+print('default bench:', d['value'], d['ms_per_step'], r['frac'], r['launch_ms_min'], r['launch_ms_median'], r['launch_ms_max'], 'd2h', d['wall_incl_d2h_ms'])
+print('h2d', {k: (v if not isinstance(v, dict) else {kk: vv for kk, vv in v.items() if kk != 'what'}) for k, v in d['h2d'].items() if k != 'what'})
+print('cpu', d['cpu_baseline']['value'], d['cpu_baseline']['cores'], d['cpu_baseline_reference_shaped']['value'])"
+for N in 2048 4096 1024; do timeout -k 5 60 ./tools/wave_clock $N 0 0 2.5; timeout -k 5 60 ./tools/wave_clock $N 0 1 2.5; done > gpurun_out/${TAG}_wave_clock.txt 2>&1
+cat gpurun_out/${TAG}_wave_clock.txt
