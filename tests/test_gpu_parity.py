@@ -651,9 +651,8 @@ def test_full_benchmark_shard_properties(n_mods, N, n_frames, label):
 
 
 def test_complex128_host_entry_chunks_and_rounds_on_device():
-    """MATLAB-double containers go up as doubles and are rounded on the GPU exactly as
-    numpy's astype(complex64) would; more than one 512 MiB chunk, rows longer than the
-    frame."""
+    """MATLAB-double containers are rounded to complex64 exactly as numpy's astype would (by the staging
+    threads on their way to pinned memory); hundreds of megabytes in many chunks, rows longer than the frame."""
     from amcpy_amd.features import features18_host
     rng = np.random.default_rng(8)
     F, L, N = 9000, 4100, 4096                       # 590 MB of complex128 -> two chunks
@@ -667,7 +666,7 @@ def test_complex128_host_entry_chunks_and_rounds_on_device():
 def test_launch_is_graph_capturable():
     """The launch path makes no allocation or synchronisation, so after one warm call
     (which sets the kernel's LDS attribute) it can be captured in a HIP graph and
-    replayed (both launches: wave kernel + tie fix-up)."""
+    replayed (both launches: wave kernel + range pass)."""
     torch = _torch()
     from amcpy_amd.features import features18
     from amcpy_amd import synth
