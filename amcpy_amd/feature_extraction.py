@@ -373,15 +373,20 @@ def extract_radioml_hdf5(path, *, key: str = "X", frame_size: Optional[int] = No
 # ----------------------------------------------------------------------------
 # run_extraction
 # ----------------------------------------------------------------------------
-def _prefetched(items: List, fn: Callable):
-    """``(item, future)`` pairs with ``fn(item)`` running on a reader thread ONE item ahead of the
-    consumer: while the caller works on item k, item k+1 is being read / decoded."""
-    with ThreadPoolExecutor(max_workers=1, thread_name_prefix="amcx-reader") as ex:
-        nxt = ex.submit(fn, items[0]) if items else None
+def _prefetched(items: List, fn: Callable, depth: int = 2):
+    """``(item, future)`` pairs with ``fn(item)`` running on reader threads up to ``depth`` items ahead of the
+    consumer: while the caller works on item k, items k+1 .. k+depth are being read / decoded (a memory-mapped
+    variable costs nothing to "read"; a compressed one is a zlib inflate of hundreds of megabytes, which
+    releases the GIL -- MATLAB's default `save` compresses).  At most ``depth + 1`` items are alive."""
+    depth = max(1, int(depth))
+    with ThreadPoolExecutor(max_workers=depth, thread_name_prefix="amcx-reader") as ex:
+        futs = [ex.submit(fn, it) for it in items[:depth]]
         for i, it in enumerate(items):
-            cur = nxt
-            nxt = ex.submit(fn, items[i + 1]) if i + 1 < len(items) else None
+            cur = futs[i]
+            if i + depth < len(items):
+                futs.append(ex.submit(fn, items[i + depth]))
             yield it, cur
+            futs[i] = None                                  # drop the reference: the consumer is done with it
 
 
 def _shared_dir(need_bytes: int) -> Path:

@@ -82,15 +82,15 @@ def _numeric_parts(buf, pos: int, end: int, dims, is_complex: bool):
     return real, imag
 
 
-def _peek_name(comp: memoryview) -> Optional[str]:
-    """Name of the variable inside a miCOMPRESSED element, from the first bytes of its stream."""
+def _peek(comp: memoryview) -> Tuple[Optional[str], int]:
+    """(name of the variable inside a miCOMPRESSED element, its inflated size), from the first bytes of its stream."""
     try:
         head = zlib.decompressobj().decompress(bytes(comp[:512]), 256)
         if len(head) < 64 or struct.unpack_from("<I", head, 0)[0] != MI_MATRIX:
-            return None
-        return _matrix_header(head, 8, len(head))[3]
+            return None, 0
+        return _matrix_header(head, 8, len(head))[3], 8 + struct.unpack_from("<I", head, 4)[0]
     except Exception:
-        return None
+        return None, 0
 
 
 def read_variable_v5(path, key: str):
@@ -111,8 +111,11 @@ def read_variable_v5(path, key: str):
         t, n, d, nxt = _tag(mm, pos)
         if t == MI_COMPRESSED:
             nxt = d + n                                         # compressed elements are not padded
-            if _peek_name(memoryview(mm)[d:d + n]) == key:
-                body = zlib.decompress(memoryview(mm)[d:d + n])
+            name, inflated = _peek(memoryview(mm)[d:d + n])
+            if name == key:
+                # one allocation of the final size instead of a buffer that doubles its way up (zlib releases the GIL:
+                # run_extraction inflates the next variables on reader threads meanwhile)
+                body = zlib.decompress(memoryview(mm)[d:d + n], zlib.MAX_WBITS, max(inflated, 1 << 16))
                 t2, n2, d2, _ = _tag(body, 0)
                 if t2 != MI_MATRIX:
                     raise _Unsupported("compressed element is not a matrix")

@@ -37,3 +37,28 @@ for dtype in (np.complex64, np.complex128):
                             "--snr-values", "0", "10"], cwd=str(REPO), capture_output=True, text=True)
         print(f"{np.dtype(dtype).name:10s} `python -m amcpy_amd extract` as a subprocess: rc {r.returncode}, "
               f"{time.time() - t0:.2f} s wall including interpreter start-up and `import torch`")
+
+# ---- round 3: a container at scale -- 6 modulations x (26, 512, 2048) complex128 = 2.6 GB in the file -------------------
+# How long does the container take to get from the file to the features, against decoding it with scipy alone?
+big = {m: np.asfortranarray(np.tile(blocks[m].astype(np.complex128)[:, :256], (13, 2, 1))) for m in synth.MODS6}   # (26, 512, 2048)
+shm = "/dev/shm" if Path("/dev/shm").is_dir() else None
+for compress in (False, True):
+    with tempfile.TemporaryDirectory(dir=shm) as td:
+        cfg = Config(paths=Paths(root=Path(td)),
+                     signals=SignalConfig(snr_values={i: str(v) for i, v in enumerate(range(-20, 32, 2))}, num_frames=512))
+        cfg.paths.ensure_dirs()
+        path = cfg.paths.mat_data / cfg.paths.mat_filename
+        t0 = time.time()
+        scipy.io.savemat(str(path), {cfg.signals.mat_info[m]: big[m] for m in synth.MODS6}, do_compression=compress)
+        t_save = time.time() - t0
+        size_gb = path.stat().st_size / 1e9
+        t0 = time.time()
+        scipy.io.loadmat(str(path), variable_names=[cfg.signals.mat_info["BPSK"]])
+        t_one = time.time() - t0
+        for label in ("first", "again"):
+            t0 = time.time()
+            run_extraction(cfg, verbose=False)
+            dt = time.time() - t0
+            print(f"{'compressed' if compress else 'uncompressed'} container {size_gb:.2f} GB (savemat took {t_save:.1f} s; scipy.io.loadmat of ONE "
+                  f"of its six variables {t_one:.2f} s): run_extraction {label}: {dt:.2f} s for {6 * 26 * 512} frames "
+                  f"= {6 * 26 * 512 / dt / 1e3:.0f} k frames/s, {6 * 26 * 512 * 2048 * 16 / dt / 1e9:.1f} GB/s of samples, file in -> six files out")
