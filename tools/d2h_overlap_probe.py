@@ -49,3 +49,8 @@ print("kernel ms  :", " ".join(f"{v:.2f}" for v in kd[:40]))
 print("copy ms    :", " ".join(f"{v:.2f}" for v in cd[:40]))
 print("gap ms     :", " ".join(f"{v:.2f}" for v in gap[:40]))
 print(f"kernel mean {sum(kd)/len(kd):.3f} max {max(kd):.3f}; copy mean {sum(cd)/len(cd):.3f} max {max(cd):.3f}; gap mean {sum(gap)/len(gap):.3f} max {max(gap):.3f}")
+print("kernel ms, means of 10:", " ".join(f"{sum(kd[i:i + 10]) / len(kd[i:i + 10]):.2f}" for i in range(0, steps, 10)))
+print("copy   ms, means of 10:", " ".join(f"{sum(cd[i:i + 10]) / len(cd[i:i + 10]):.2f}" for i in range(0, steps, 10)))
+# when does each copy start relative to the end of the launch it copies, and how long after it does the next launch end?
+lag = [k1[i].elapsed_time(c0[i]) for i in range(steps)]
+print("copy start lag behind its launch, means of 10:", " ".join(f"{sum(lag[i:i + 10]) / len(lag[i:i + 10]):.2f}" for i in range(0, steps, 10)))
