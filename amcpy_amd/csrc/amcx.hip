@@ -75,22 +75,26 @@ bool on_another_device(const void* p) {
 // spectral-term variant of the block kernel for this frame size
 int block_mode(int N) {
   if (is_pow2(N)) return amcx::kBlockPow2;
-  return (N >= amcx::kBluesteinMinN && N <= amcx::kBluesteinMaxN) ? amcx::kBlockBluestein : amcx::kBlockDirect;
+  if (N >= amcx::kBluesteinMinN && N <= amcx::kBluesteinMaxN) return amcx::kBlockBluestein;
+  return N > amcx::kBluesteinMaxN ? amcx::kBlockBluesteinBig : amcx::kBlockDirect;
 }
 
 int launch_block(const float2* iq, int64_t n_frames, int32_t N, int64_t row_stride, float* out,
                  int64_t out_stride, hipStream_t stream) {
   const int mode = block_mode(N);
-  const size_t lds = (mode == amcx::kBlockBluestein ? (size_t)16 * amcx::bluestein_length(N) : (size_t)16 * N) +
+  const size_t lds = (mode == amcx::kBlockBluestein      ? (size_t)16 * amcx::bluestein_length(N)
+                      : mode == amcx::kBlockBluesteinBig ? (size_t)8 * amcx::kBluesteinBigM
+                                                         : (size_t)16 * N) +
                      amcx::kBlockScratchBytes + amcx::kBlockTwiddleBytes;
-  auto kern = mode == amcx::kBlockPow2        ? amcx::amcx_features18_block_kernel<amcx::kBlockPow2>
-              : mode == amcx::kBlockBluestein ? amcx::amcx_features18_block_kernel<amcx::kBlockBluestein>
-                                              : amcx::amcx_features18_block_kernel<amcx::kBlockDirect>;
+  auto kern = mode == amcx::kBlockPow2           ? amcx::amcx_features18_block_kernel<amcx::kBlockPow2>
+              : mode == amcx::kBlockBluestein    ? amcx::amcx_features18_block_kernel<amcx::kBlockBluestein>
+              : mode == amcx::kBlockBluesteinBig ? amcx::amcx_features18_block_kernel<amcx::kBlockBluesteinBig>
+                                                 : amcx::amcx_features18_block_kernel<amcx::kBlockDirect>;
   // > 64 KiB of dynamic LDS needs the attribute.  It is set once per (kernel, device) to the most any
   // frame size can ask for, never per launch: two host threads launching different N would otherwise
   // race between one's attribute and the other's launch.
   {
-    static bool attr_set[3][64] = {};
+    static bool attr_set[4][64] = {};
     constexpr int kMaxLds = 16 * AMCX_MAX_FRAME_SIZE + amcx::kBlockScratchBytes + amcx::kBlockTwiddleBytes;
     int dev = 0;
     AMCX_HIP(hipGetDevice(&dev));
@@ -642,6 +646,7 @@ int amcx_kernel_name(int32_t frame_size, int32_t variant, char* buf, int32_t buf
   const char* name = (v == AMCX_VARIANT_WAVE) ? amcx::wave_kernel_name(frame_size)
                      : block_mode(frame_size) == amcx::kBlockPow2      ? "amcx_features18_block_kernel<1>"
                      : block_mode(frame_size) == amcx::kBlockBluestein ? "amcx_features18_block_kernel<2>"
+                     : block_mode(frame_size) == amcx::kBlockBluesteinBig ? "amcx_features18_block_kernel<3>"
                                                                        : "amcx_features18_block_kernel<0>";
   snprintf(buf, (size_t)buf_len, "%s", name);
   return AMCX_OK;

@@ -75,10 +75,15 @@ __device__ __forceinline__ float block_max(float v, double* scratch) {
   return b > 0.f ? __builtin_nanf("") : m;
 }
 
-constexpr int kBlockDirect = 0, kBlockPow2 = 1, kBlockBluestein = 2;   // spectral-term variants
+constexpr int kBlockDirect = 0, kBlockPow2 = 1, kBlockBluestein = 2, kBlockBluesteinBig = 3;   // spectral-term variants
 constexpr int kBluesteinMinN = 65, kBluesteinMaxN = 4096;
+// 4096 < N < 8192, not a power of two: the convolution length is 16384 and two LDS arrays of it would be 256 KB.
+// kBlockBluesteinBig keeps the convolution buffer in LDS (128 KB, one workgroup per CU) and the chirp's spectrum in
+// REGISTERS: thread t multiplies entries t + 256 j, j < 64, and holds exactly those 64 complex values (128 VGPRs)
+// for the kernel's lifetime.
+constexpr int kBluesteinBigM = 16384, kBluesteinBigPerThread = kBluesteinBigM / kBlockThreads;
 constexpr int kBlockScratchBytes = (int)sizeof(double) * kBlockWaves * kMaxReduce;   // 512
-constexpr int kBlockTwiddleBytes = 2 * 64 * 8;                                        // T_lo, T_hi
+constexpr int kBlockTwiddleBytes = (64 + 128) * 8;                                    // T_lo[64], T_hi[128]: exponents < 8192
 
 __host__ __device__ inline int bluestein_length(int n) {          // smallest power of two >= 2n - 1
   int m = 1;
@@ -86,7 +91,7 @@ __host__ __device__ inline int bluestein_length(int n) {          // smallest po
   return m;
 }
 
-// W_M^m = exp(-2 pi i m / M), m < M/2, from two 64-entry tables: T_hi[m >> 6] * T_lo[m & 63]
+// W_M^m = exp(-2 pi i m / M), m < M/2, from two small tables: T_hi[m >> 6] * T_lo[m & 63] (T_hi: up to 128 entries)
 __device__ __forceinline__ float2 twiddle2(const float2* tlo, const float2* thi, int m) {
   const float2 a = thi[m >> 6], b = tlo[m & 63];
   return make_float2(__builtin_fmaf(a.x, b.x, -(a.y * b.y)), __builtin_fmaf(a.x, b.y, a.y * b.x));
@@ -148,7 +153,7 @@ struct BlockLds {
 // Also the slow path behind the wave kernel for frames outside its fp32 range (amcx_fixup_kernel.h).
 template <int MODE>
 __device__ __forceinline__ void block_frame(const float2* __restrict__ src, int N, int M, const BlockLds& L,
-                                            float* __restrict__ out_row) {
+                                            float* __restrict__ out_row, const float2* bh_regs = nullptr) {
   float2* const bh = L.bh;
   float2* const xs = L.xs;
   float2* const at = L.at;
@@ -241,7 +246,7 @@ __device__ __forceinline__ void block_frame(const float2* __restrict__ src, int 
     // (a non-finite sample is caught by the finaliser through the power sum,
     //  so the maximum itself need not carry NaNs)
     float peak = 0.f;
-    if constexpr (MODE == kBlockBluestein) {
+    if constexpr (MODE == kBlockBluestein || MODE == kBlockBluesteinBig) {
       // a_n = x_n w_n in place over the frame, zero padding over the dead (|x|, angle) stash
       for (int n = tid; n < M; n += kBlockThreads) {
         float2 a = make_float2(0.f, 0.f);
@@ -253,9 +258,18 @@ __device__ __forceinline__ void block_frame(const float2* __restrict__ src, int 
       }
       __syncthreads();
       lds_fft_dif(xs, M, tlo, thi);
-      for (int n = tid; n < M; n += kBlockThreads) {              // both spectra are in bit-reversed order
-        const float2 a = xs[n], b = bh[n];
-        xs[n] = make_float2(__builtin_fmaf(a.x, b.x, -(a.y * b.y)), __builtin_fmaf(a.x, b.y, a.y * b.x));
+      if constexpr (MODE == kBlockBluesteinBig) {
+#pragma unroll
+        for (int j = 0; j < kBluesteinBigPerThread; ++j) {        // the chirp's spectrum: this thread's 64 entries, in registers
+          const int n = tid + j * kBlockThreads;
+          const float2 a = xs[n], b = bh_regs[j];
+          xs[n] = make_float2(__builtin_fmaf(a.x, b.x, -(a.y * b.y)), __builtin_fmaf(a.x, b.y, a.y * b.x));
+        }
+      } else {
+        for (int n = tid; n < M; n += kBlockThreads) {            // both spectra are in bit-reversed order
+          const float2 a = xs[n], b = bh[n];
+          xs[n] = make_float2(__builtin_fmaf(a.x, b.x, -(a.y * b.y)), __builtin_fmaf(a.x, b.y, a.y * b.x));
+        }
       }
       __syncthreads();
       lds_ifft_dit(xs, M, tlo, thi);
@@ -321,39 +335,47 @@ __device__ __forceinline__ void block_frame(const float2* __restrict__ src, int 
 }
 
 template <int MODE>
-__global__ __launch_bounds__(kBlockThreads, 2) void amcx_features18_block_kernel(
+__global__ __launch_bounds__(kBlockThreads, MODE == kBlockBluesteinBig ? 1 : 2) void amcx_features18_block_kernel(
     const float2* __restrict__ iq, long long n_frames, int N, long long row_stride,
     float* __restrict__ out, long long out_stride) {
   extern __shared__ float4 amcx_block_smem[];
   float2* const base = reinterpret_cast<float2*>(amcx_block_smem);
-  const int M = MODE == kBlockBluestein ? bluestein_length(N) : 0;
-  float2* bh = base;                                              // Bluestein: FFT of the chirp, M entries
-  float2* xs = base + M;                                          // frame, later FFT workspace (M entries for Bluestein)
+  constexpr bool kChirp = MODE == kBlockBluestein || MODE == kBlockBluesteinBig;
+  const int M = MODE == kBlockBluestein ? bluestein_length(N) : MODE == kBlockBluesteinBig ? kBluesteinBigM : 0;
+  float2* bh = base;                                              // Bluestein: FFT of the chirp, M entries (Big: in registers)
+  float2* xs = MODE == kBlockBluestein ? base + M : base;         // frame, later FFT workspace (M entries for Bluestein)
   float2* at = xs + N;                                            // (|x|, angle), later twiddles / workspace
-  double* scratch = reinterpret_cast<double*>(MODE == kBlockBluestein ? xs + M : at + N);   // kBlockWaves * kMaxReduce doubles
+  double* scratch = reinterpret_cast<double*>(kChirp ? xs + M : at + N);   // kBlockWaves * kMaxReduce doubles
   float2* tlo = reinterpret_cast<float2*>(reinterpret_cast<char*>(scratch) + kBlockScratchBytes);
   float2* thi = tlo + 64;
   const int tid = threadIdx.x;
+  [[maybe_unused]] float2 bh_regs[MODE == kBlockBluesteinBig ? kBluesteinBigPerThread : 1];
 
-  if constexpr (MODE == kBlockBluestein) {
+  if constexpr (kChirp) {
     // once per workgroup: two-level twiddles of the M-point FFT and the chirp's spectrum
-    if (tid < 128) {
-      const int k = tid & 63;
+    if (tid < 192) {
+      const int k = tid < 64 ? tid : tid - 64;
       float sn, cs;
       sincospif((float)(tid < 64 ? k : 64 * k) * (2.0f / (float)M), &sn, &cs);
-      tlo[tid] = make_float2(cs, -sn);                            // tlo[k] = W_M^k, thi[k] = W_M^(64 k)
+      tlo[tid] = make_float2(cs, -sn);                            // tlo[k] = W_M^k (k < 64), thi[k] = W_M^(64 k) (k < 128)
     }
+    float2* const spec = MODE == kBlockBluesteinBig ? xs : bh;    // Big: built in the convolution buffer, then taken into registers
     for (int n = tid; n < M; n += kBlockThreads) {
       const int d = n < N ? n : (M - n < N ? M - n : -1);         // conj(w) is even in n: wrap it around
-      bh[n] = d >= 0 ? chirp(d, N, 1.0f) : make_float2(0.f, 0.f);
+      spec[n] = d >= 0 ? chirp(d, N, 1.0f) : make_float2(0.f, 0.f);
     }
     __syncthreads();
-    lds_fft_dif(bh, M, tlo, thi);
+    lds_fft_dif(spec, M, tlo, thi);
+    if constexpr (MODE == kBlockBluesteinBig) {
+#pragma unroll
+      for (int j = 0; j < kBluesteinBigPerThread; ++j) bh_regs[j] = spec[tid + j * kBlockThreads];
+      __syncthreads();                                            // the buffer is the frames' from here on
+    }
   }
 
   BlockLds L{bh, xs, at, scratch, tlo, thi};
   for (long long f = blockIdx.x; f < n_frames; f += gridDim.x)
-    block_frame<MODE>(iq + f * row_stride, N, M, L, out + f * out_stride);
+    block_frame<MODE>(iq + f * row_stride, N, M, L, out + f * out_stride, bh_regs);
 }
 
 }  // namespace amcx

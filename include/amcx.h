@@ -91,11 +91,10 @@ extern "C" {
 /* kernel variants (amcx_features18_c64_ex) */
 #define AMCX_VARIANT_AUTO 0     /* fastest kernel that supports frame_size */
 #define AMCX_VARIANT_BLOCK 1    /* one 256-thread workgroup per frame, frame staged in LDS,
-                                   radix-2 LDS FFT (power of two), Bluestein chirp-z FFT
-                                   (65..4096) or direct O(N^2) fp64 DFT (N <= 64, and the
-                                   non-powers of two 4097..8191, whose chirp would need 256 KB
-                                   of LDS: ~100x slower per frame than Bluestein at 4096 --
-                                   zero-pad such frames to 8192 if that is acceptable); fp64
+                                   radix-2 LDS FFT (power of two), Bluestein chirp-z FFT (every
+                                   other N >= 65: both spectra in LDS up to 4096; 4097..8191 a
+                                   16384-point convolution with the chirp's spectrum held in
+                                   registers) or direct O(N^2) fp64 DFT (N <= 64); fp64
                                    accumulation; 2 <= frame_size <= AMCX_MAX_FRAME_SIZE */
 #define AMCX_VARIANT_WAVE 2     /* one wavefront per frame, frame held in registers,
                                    register radix-16/8 FFT with LDS exchanges, followed by the

@@ -277,14 +277,16 @@ def test_results_do_not_depend_on_batch_position():
 def test_generic_sizes_block_kernel():
     """Frame sizes outside the fast set -- the reference accepts any N (np.fft.fft): tiny and
     odd lengths (direct DFT, N <= 64), non powers of two through Bluestein's chirp-z FFT
-    (65 <= N <= 4096, primes and both ends of the range included), the direct DFT again for
-    4096 < N < 8192, and the radix-2 LDS FFT for the powers of two the wave kernel leaves."""
+    (65 <= N <= 4096 with both spectra in LDS; 4097 <= N <= 8191 with a 16384-point convolution whose chirp
+    spectrum lives in registers; primes and both ends of the ranges included), and the radix-2 LDS FFT for
+    the powers of two the wave kernel leaves."""
     from amcpy_amd import _lib
     assert _lib.kernel_name(64) == "amcx_features18_block_kernel<1>"
     assert _lib.kernel_name(65) == _lib.kernel_name(4095) == "amcx_features18_block_kernel<2>"
-    assert _lib.kernel_name(10) == _lib.kernel_name(4097) == "amcx_features18_block_kernel<0>"
+    assert _lib.kernel_name(4097) == _lib.kernel_name(8191) == "amcx_features18_block_kernel<3>"
+    assert _lib.kernel_name(10) == _lib.kernel_name(63) == "amcx_features18_block_kernel<0>"
     rng = np.random.default_rng(3)
-    for N in (3, 7, 10, 64, 65, 100, 127, 1000, 1536, 2047, 3000, 4093, 4095, 4097, 256, 8192):
+    for N in (3, 7, 10, 64, 65, 100, 127, 1000, 1536, 2047, 3000, 4093, 4095, 4097, 5000, 6007, 8191, 256, 8192):
         F = 3
         x = (rng.standard_normal((F, N)) + 1j * rng.standard_normal((F, N))).astype(np.complex64)
         x += np.exp(2j * np.pi * 0.05 * np.arange(N))[None, :].astype(np.complex64)
