@@ -1063,3 +1063,48 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     bad = subprocess.run([sys.executable, str(repo / "bench.py"), "--gpus", "2", "--no-cpu-baseline"], env=env,
                          cwd=str(tmp_path), capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "torch.distributed.run" in (bad.stdout + bad.stderr)
+
+
+def test_strided_engine_on_random_layouts():
+    """amcx_ctx_features18_strided_host on forty random containers: every axis order (the snr, the frame or the
+    sample axis contiguous), padded in every dimension (strides larger than the extents), complex64 / complex128 /
+    split real+imaginary / real-only, ranges that start inside an snr row, slots small enough for many chunks --
+    each result equal, bit for bit, to the one-launch result on a packed complex64 copy of the same frames."""
+    torch = _torch()
+    import itertools
+    from amcpy_amd.feature_extraction import FrameRows, HipEngine, SplitComplex
+    from amcpy_amd.features import features18
+    rng = np.random.default_rng(2026)
+    orders = list(itertools.permutations(range(3)))
+    for case in range(40):
+        S, K = int(rng.integers(1, 6)), int(rng.integers(1, 40))
+        N = int(rng.choice([64, 100, 128, 256, 300]))
+        pad = [int(rng.integers(0, 3)) for _ in range(3)]
+        shape = (S + pad[0], K + pad[1], N + pad[2])
+        order = orders[int(rng.integers(0, len(orders)))]          # memory order: order[0] is the slowest axis
+        full = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)) * 10.0 ** rng.integers(-2, 3)
+        mem = np.ascontiguousarray(full.transpose(order))          # laid out with `order`'s axes from slow to fast
+        arr = mem.transpose(np.argsort(order))                     # ... and viewed as (snr, frame, sample) again
+        assert arr.shape == shape and np.array_equal(arr, full)
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            src = arr.astype(np.complex64, order="K")
+            packed = np.asarray(src)
+        elif kind == 1:
+            src, packed = arr, arr.astype(np.complex64)
+        elif kind == 2:
+            src = SplitComplex(np.ascontiguousarray(arr.real.transpose(order)).transpose(np.argsort(order)),
+                               np.ascontiguousarray(arr.imag.transpose(order)).transpose(np.argsort(order)))
+            packed = arr.astype(np.complex64)
+        else:
+            src = np.ascontiguousarray(arr.real.transpose(order)).transpose(np.argsort(order))     # a real signal
+            packed = arr.real.astype(np.complex64)
+        want_all = features18(torch.from_numpy(np.ascontiguousarray(packed[:S, :K, :N]).reshape(S * K, N)).cuda()).cpu().numpy()
+        lo = int(rng.integers(0, S * K))
+        hi = int(rng.integers(lo, S * K + 1))
+        eng = HipEngine(N, chunk_bytes=int(rng.choice([4096, 20000, 1 << 20])), threads=int(rng.integers(1, 5)),
+                        round_on_device=bool(rng.integers(0, 2)))
+        got = eng(FrameRows(src, S, K, lo, hi))
+        assert got.shape == (hi - lo, 18)
+        assert np.array_equal(got, want_all[lo:hi], equal_nan=True), (case, shape, order, kind, lo, hi, N)
+        eng.close()
