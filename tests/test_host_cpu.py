@@ -632,3 +632,55 @@ def test_two_rank_failure_raises_on_every_rank(tmp_path):
     assert (cfg.paths.calculated_features / "BPSK_features.mat").exists()
     assert not (cfg.paths.calculated_features / "QPSK_features.mat").exists()
     assert set(glob.glob(str(fe._shared_dir(0) / "amcx_frames_*"))) == before, "shared frame files left behind"
+
+
+def test_native_staging_on_random_layouts():
+    """amcx_stage_host on sixty random containers (no GPU): every axis order, padded in every dimension, complex64 /
+    complex128 / split / real-only, random unit ranges and thread counts -- each staged chunk equals numpy's slicing
+    + astype(complex64) in the order the layout report says (rows; planes with the snr or the frame axis inside)."""
+    import itertools
+    from amcpy_amd import _lib
+    rng = np.random.default_rng(77)
+    orders = list(itertools.permutations(range(3)))
+    seen = set()
+    for case in range(60):
+        S, K, N = int(rng.integers(1, 6)), int(rng.integers(1, 30)), int(rng.integers(2, 90))
+        pad = [int(rng.integers(0, 3)) for _ in range(3)]
+        shape = (S + pad[0], K + pad[1], N + pad[2])
+        order = orders[int(rng.integers(0, len(orders)))]
+        full = rng.standard_normal(shape) * 100 + 1j * rng.standard_normal(shape)
+        lay = lambda a: np.ascontiguousarray(a.transpose(order)).transpose(np.argsort(order))
+        arr = lay(full)
+        es = [st // arr.itemsize for st in arr.strides]
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            a64 = lay(full.astype(np.complex64))
+            re, im, k, es, want = a64, None, _lib.SRC_C64, [st // 8 for st in a64.strides], a64
+        elif kind == 1:
+            re, im, k, want = arr, None, _lib.SRC_C128, arr.astype(np.complex64)
+        elif kind == 2:
+            re, im, k, want = lay(full.real), lay(full.imag), _lib.SRC_F64_SPLIT, arr.astype(np.complex64)
+            es = [st // 8 for st in re.strides]
+        else:
+            re, im, k, want = lay(full.real), None, _lib.SRC_F64_SPLIT, arr.real.astype(np.complex64)
+            es = [st // 8 for st in re.strides]
+        unit_axes = [es[2] == 1, es[1] == 1 and K > 1, es[0] == 1 or S == 1]
+        if not any(unit_axes):
+            with pytest.raises(_lib.AmcxError):
+                _stage(re, im, k, S, K, max(N, 2), es, 0, 1)
+            continue
+        got_probe, pm, inner = _stage(re, im, k, S, K, N, es, 0, 1, threads=1)
+        total = N if pm else S * K
+        first = int(rng.integers(0, total))
+        count = int(rng.integers(1, total - first + 1))
+        got, pm, inner = _stage(re, im, k, S, K, N, es, first, count, threads=int(rng.integers(1, 6)))
+        used = want[:S, :K, :N]
+        if not pm:
+            ref = used.reshape(S * K, N)[first:first + count]
+        elif inner:
+            ref = used[:, :, first:first + count].transpose(2, 1, 0).reshape(count, K * S)
+        else:
+            ref = used[:, :, first:first + count].transpose(2, 0, 1).reshape(count, S * K)
+        assert np.array_equal(got, ref), (case, shape, order, kind, pm, inner, first, count)
+        seen.add((pm, inner))
+    assert seen == {(0, 0), (1, 0), (1, 1)}, seen
