@@ -373,7 +373,7 @@ def extract_radioml_hdf5(path, *, key: str = "X", frame_size: Optional[int] = No
 # ----------------------------------------------------------------------------
 # run_extraction
 # ----------------------------------------------------------------------------
-def _prefetched(items: List, fn: Callable, depth: int = 2):
+def _prefetched(items: List, fn: Callable, depth: int = 3):
     """``(item, future)`` pairs with ``fn(item)`` running on reader threads up to ``depth`` items ahead of the
     consumer: while the caller works on item k, items k+1 .. k+depth are being read / decoded (a memory-mapped
     variable costs nothing to "read"; a compressed one is a zlib inflate of hundreds of megabytes, which
