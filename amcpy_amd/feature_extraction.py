@@ -448,9 +448,9 @@ def _publish_container(parsed, n_snr: int, n_frames: int, N: int, threads: int) 
     return Path(name)
 
 
-def _load_variable(mat_path: Path, key: str):
+def _load_variable(mat_path: Path, key: str, pool=None):
     from .matfile import load_variable
-    return load_variable(mat_path, key)
+    return load_variable(mat_path, key, pool)
 
 
 def _same_host(world: int) -> bool:
@@ -493,13 +493,22 @@ def run_extraction(cfg: Config, *, compute=None, device: Optional[int] = None, v
     feed = None
     try:
         if world == 1:
-            feed = _prefetched(mods, lambda m: _load_variable(mat_path, cfg.signals.mat_info[m]))
+            from .matfile import BufferPool, stores_compressed
+            # A compressed container is inflate-bound: three reader threads run ahead (zlib releases the GIL).  An
+            # uncompressed one is read with preadv into two pairs of buffers that take turns (one being uploaded, one
+            # being filled): reading is faster than first-touching fresh pages, mapped or allocated.
+            pool = BufferPool()
+            depth = 3 if stores_compressed(mat_path) else 1
+            feed = _prefetched(mods, lambda m: _load_variable(mat_path, cfg.signals.mat_info[m], pool), depth)
             for mod, fut in feed:
                 t0 = time.perf_counter()
                 key = cfg.signals.mat_info[mod]
-                parsed = fut.result()                   # one variable at a time (two while the next decodes)
-                n_snr, n_frames, _ = _check_container(parsed, cfg)
-                feats = run(FrameRows(parsed, n_snr, n_frames)).reshape(n_snr, n_frames, 18)
+                parsed = fut.result()                   # the reader threads are up to three variables ahead
+                try:
+                    n_snr, n_frames, _ = _check_container(parsed, cfg)
+                    feats = run(FrameRows(parsed, n_snr, n_frames)).reshape(n_snr, n_frames, 18)
+                finally:
+                    getattr(parsed, "release", lambda: None)()
                 del parsed
                 writes.append(writer.submit(save, mod, key, feats, t0))
         else:

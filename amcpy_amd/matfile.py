@@ -21,12 +21,22 @@ part.  miCOMPRESSED (15) wraps one zlib-deflated miMATRIX.  Anything this reader
 -- big-endian files, integer-compressed numeric data, sparse / cell / struct / char variables, level
 4 or 7.3 (HDF5) files -- goes to ``scipy.io.loadmat``, whose result for the variable is returned
 as it is.
+
+Mapping is free, but the first touch of every mapped page is a minor fault, and those do not scale: 13-18 GB/s
+from one thread, 22 GB/s from eight (`profiles/r3_read_probe.txt`) -- 30 ms for a 436 MB variable whose upload
+takes 4.5 ms.  ``preadv`` into a buffer that is reused from variable to variable does 51 GB/s from eight
+threads, so a single-process ``run_extraction`` reads uncompressed variables that way (:func:`load_variable`
+with a :class:`BufferPool`) and keeps the mapping for the cases where only part of a variable is wanted (a
+rank's frame range) or nothing can be reused.
 """
 from __future__ import annotations
 
 import mmap
+import os
 import struct
+import threading
 import zlib
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 from typing import Optional, Tuple
 
@@ -66,20 +76,82 @@ def _matrix_header(buf, pos: int, end: int):
     return flags & 0xFF, bool(flags & 0x0800), dims, name, nxt3
 
 
-def _numeric_parts(buf, pos: int, end: int, dims, is_complex: bool):
+def _numeric_layout(buf, pos: int, dims, is_complex: bool):
+    """(storage dtype, element count, offset of the real data, offset of the imaginary data or None)."""
     t, n, d, nxt = _tag(buf, pos)
     count = int(np.prod(dims, dtype=np.int64))
     if t not in _STORAGE or n != count * _STORAGE[t].itemsize:
         raise _Unsupported(f"numeric data stored as MAT type {t}")
-    dt = _STORAGE[t]
-    real = np.frombuffer(buf, dtype=dt, count=count, offset=d).reshape(dims, order="F")
-    imag = None
+    d2 = None
     if is_complex:
         t2, n2, d2, _ = _tag(buf, nxt)
         if t2 != t or n2 != n:
             raise _Unsupported("imaginary part stored differently from the real part")
-        imag = np.frombuffer(buf, dtype=dt, count=count, offset=d2).reshape(dims, order="F")
+    return _STORAGE[t], count, d, d2
+
+
+def _numeric_parts(buf, pos: int, end: int, dims, is_complex: bool):
+    dt, count, d, d2 = _numeric_layout(buf, pos, dims, is_complex)
+    real = np.frombuffer(buf, dtype=dt, count=count, offset=d).reshape(dims, order="F")
+    imag = None if d2 is None else np.frombuffer(buf, dtype=dt, count=count, offset=d2).reshape(dims, order="F")
     return real, imag
+
+
+class BufferPool:
+    """Reusable host buffers for :func:`load_variable`: a variable read with ``preadv`` lands in arrays that the
+    previous variables of the same shape used, so their pages are already there (thread-safe)."""
+
+    def __init__(self):
+        self._free, self._lock = {}, threading.Lock()
+
+    def take(self, dtype, count: int) -> np.ndarray:
+        with self._lock:
+            lst = self._free.get((np.dtype(dtype).str, count))
+            if lst:
+                return lst.pop()
+        return np.empty(count, dtype=dtype)
+
+    def give(self, arr: np.ndarray) -> None:
+        with self._lock:
+            self._free.setdefault((arr.dtype.str, arr.size), []).append(arr)
+
+
+_PREAD_THREADS = 8
+_pread_pool = None
+_pread_lock = threading.Lock()
+
+
+def _pread_executor() -> ThreadPoolExecutor:
+    global _pread_pool
+    with _pread_lock:
+        if _pread_pool is None:
+            _pread_pool = ThreadPoolExecutor(max_workers=_PREAD_THREADS, thread_name_prefix="amcx-pread")
+        return _pread_pool
+
+
+def _pread_into(path, jobs) -> None:
+    """jobs: (destination uint8 view, file offset) pairs; pieces of <= 16 MiB spread over the pread threads
+    (os.preadv releases the GIL; 51 GB/s from eight threads out of the page cache)."""
+    piece = 16 << 20
+    fd = os.open(str(path), os.O_RDONLY)
+    try:
+        def one(view, off):
+            done, n = 0, len(view)
+            while done < n:
+                got = os.preadv(fd, [view[done:]], off + done)
+                if got <= 0:
+                    raise OSError(f"short read from {path} at offset {off + done}")
+                done += got
+        futs = []
+        ex = _pread_executor()
+        for dst, off in jobs:
+            mv = memoryview(dst)
+            for a in range(0, len(mv), piece):
+                futs.append(ex.submit(one, mv[a:a + piece], off + a))
+        for f in futs:
+            f.result()
+    finally:
+        os.close(fd)
 
 
 def _peek(comp: memoryview) -> Tuple[Optional[str], int]:
@@ -93,10 +165,11 @@ def _peek(comp: memoryview) -> Tuple[Optional[str], int]:
         return None, 0
 
 
-def read_variable_v5(path, key: str):
+def read_variable_v5(path, key: str, pool: Optional[BufferPool] = None):
     """The variable ``key`` of a little-endian level-5 MAT file: ``(real, imag, how)`` with Fortran-ordered
     float32 / float64 arrays (``imag`` None for a real variable) that are views of the file's memory mapping
-    (``how == "mapped"``) or, for a compressed variable, of its inflated bytes (``"inflated"``).
+    (``how == "mapped"``), of its inflated bytes for a compressed variable (``"inflated"``), or -- with a ``pool`` --
+    arrays from the pool that the data was read into with ``preadv`` (``"read"``; uncompressed variables only).
     Raises ``_Unsupported`` for what the module docstring lists, ``KeyError`` if there is no such variable."""
     with open(path, "rb") as fh:
         size = fh.seek(0, 2)
@@ -128,6 +201,19 @@ def read_variable_v5(path, key: str):
             if name == key:
                 if cls not in (MX_DOUBLE, MX_SINGLE):
                     raise _Unsupported(f"array class {cls}")
+                if pool is not None:                            # read it instead of mapping it
+                    dt, count, d_re, d_im = _numeric_layout(mm, data_pos, dims, cplx)
+                    real = pool.take(dt, count)
+                    imag = pool.take(dt, count) if d_im is not None else None
+                    jobs = [(real.view(np.uint8), d_re)] + ([(imag.view(np.uint8), d_im)] if imag is not None else [])
+                    try:
+                        _pread_into(path, jobs)
+                    except BaseException:
+                        pool.give(real)
+                        if imag is not None:
+                            pool.give(imag)
+                        raise
+                    return (real.reshape(dims, order="F"), None if imag is None else imag.reshape(dims, order="F"), "read")
                 return _numeric_parts(mm, data_pos, d + n, dims, cplx) + ("mapped",)
         if nxt <= pos:
             raise _Unsupported("corrupt element tag")
@@ -135,15 +221,35 @@ def read_variable_v5(path, key: str):
     raise KeyError(f"{path} has no variable {key!r}")
 
 
-def load_variable(mat_path, key: str):
+def stores_compressed(mat_path) -> bool:
+    """True if the first variable of a level-5 file is a miCOMPRESSED element (MATLAB's default ``save``): its
+    variables have to be inflated -- worth several reader threads -- rather than read or mapped.  False for
+    anything else, including files this reader does not take on."""
+    try:
+        with open(mat_path, "rb") as fh:
+            head = fh.read(136)
+        return len(head) == 136 and head[:10] == b"MATLAB 5.0" and head[126:128] == b"IM" and \
+            struct.unpack_from("<I", head, 128)[0] == MI_COMPRESSED
+    except OSError:
+        return False
+
+
+def load_variable(mat_path, key: str, pool: Optional[BufferPool] = None):
     """One variable of the container: a :class:`SplitComplex` over the memory-mapped file (its ``source``
-    says ``"mapped"``, or ``"inflated"`` for a compressed variable) when the fast reader applies, otherwise
-    what ``scipy.io.loadmat`` returns for it."""
+    says ``"mapped"``; ``"inflated"`` for a compressed variable; ``"read"`` when a ``pool`` was given and the data
+    was read into its buffers -- call ``release()`` on the result when done with it) when the fast reader applies,
+    otherwise what ``scipy.io.loadmat`` returns for it."""
     from .feature_extraction import SplitComplex
     try:
-        real, imag, how = read_variable_v5(Path(mat_path), key)
+        real, imag, how = read_variable_v5(Path(mat_path), key, pool)
         out = SplitComplex(real, imag)
         out.source = how
+        if how == "read":
+            def release(real=real, imag=imag):
+                pool.give(real.reshape(-1, order="F"))
+                if imag is not None:
+                    pool.give(imag.reshape(-1, order="F"))
+            out.release = release
         return out
     except _Unsupported:
         pass

@@ -471,6 +471,19 @@ def test_mat_reader_returns_views_equal_to_loadmat(tmp_path):
         assert isinstance(real, SplitComplex) and real.imag is None and real.real.dtype == np.float64
         assert np.array_equal(real.real, ref["just_real"]) and np.array_equal(real[:2], ref["just_real"][:2])
         assert real.source == got.source == ("inflated" if compress else "mapped")
+        # with a buffer pool an uncompressed variable is READ (preadv on threads) into arrays that are reused
+        from amcpy_amd.matfile import BufferPool
+        pool = BufferPool()
+        first = load_variable(path, "signal_bpsk", pool)
+        assert first.source == ("inflated" if compress else "read") and np.array_equal(first[:, :, :], ref["signal_bpsk"])
+        if not compress:
+            assert first.real.flags.f_contiguous and first.real.flags.writeable
+            addr = first.real.__array_interface__["data"][0]
+            first.release()
+            again = load_variable(path, "signal_bpsk", pool)    # same shape: the same buffers come back
+            assert again.real.__array_interface__["data"][0] in (addr, first.imag.__array_interface__["data"][0])
+            assert np.array_equal(again[:, :, :], ref["signal_bpsk"])
+            again.release()
         with pytest.raises(_Unsupported):
             read_variable_v5(path, "ints")                       # int16 storage: not the fast reader's business
         assert np.array_equal(load_variable(path, "ints"), ref["ints"])           # ... scipy's

@@ -24,15 +24,25 @@ with tempfile.TemporaryDirectory(dir="/dev/shm" if Path("/dev/shm").is_dir() els
     scipy.io.savemat(str(path), {cfg.signals.mat_info[m]: big[m] for m in synth.MODS6})
     run_extraction(cfg, verbose=False)
     t0 = time.perf_counter(); run_extraction(cfg, verbose=False); print(f"run_extraction: {(time.perf_counter() - t0) * 1e3:.1f} ms")
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable(); run_extraction(cfg, verbose=False); pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(8)
+    for _ in range(3):
+        t0 = time.perf_counter(); run_extraction(cfg, verbose=False); print(f"run_extraction: {(time.perf_counter() - t0) * 1e3:.1f} ms")
     eng = HipEngine(2048, threads=8)
-    for rep in range(2):
+    from amcpy_amd.matfile import BufferPool
+    pool = BufferPool()
+    for rep in range(3):
+        how = None if rep == 0 else pool                  # first round: memory-mapped; then: preadv into reused buffers
+        print("--- variables", "memory-mapped" if how is None else "read with preadv into a buffer pool")
         for m in synth.MODS6:
             key = cfg.signals.mat_info[m]
-            t0 = time.perf_counter(); v = _load_variable(path, key); t1 = time.perf_counter()
+            t0 = time.perf_counter(); v = _load_variable(path, key, how); t1 = time.perf_counter()
             feats = eng(FrameRows(v, 26, 512)); t2 = time.perf_counter()
             scipy.io.savemat(str(cfg.paths.calculated_features / f"{m}_features.mat"), {"Modulation": m, key: feats.reshape(26, 512, 18)})
             t3 = time.perf_counter()
+            getattr(v, "release", lambda: None)()
             st = eng.stats
-            print(f"{m:6s} map+prefault {(t1 - t0) * 1e3:6.1f} ms | engine {(t2 - t1) * 1e3:6.1f} ms (native {st['seconds_native'] * 1e3:.1f}: staging "
+            print(f"{m:6s} read / map {(t1 - t0) * 1e3:6.1f} ms | engine {(t2 - t1) * 1e3:6.1f} ms (native {st['seconds_native'] * 1e3:.1f}: staging "
                   f"{st['seconds_staging'] * 1e3:.1f}, waiting {st['seconds_waiting'] * 1e3:.1f}, tail {st['seconds_tail'] * 1e3:.1f}, prepare "
                   f"{st['seconds_prepare'] * 1e3:.1f}; {st['source_bytes'] / (t2 - t1) / 1e9:.0f} GB/s) | savemat {(t3 - t2) * 1e3:5.1f} ms")
