@@ -57,6 +57,7 @@ SIGNATURES = {
 }
 
 _lib = None
+_loaded_without_torch = False
 
 
 class AmcxError(RuntimeError):
@@ -65,20 +66,33 @@ class AmcxError(RuntimeError):
         super().__init__(f"amcx error {code}: {detail}")
 
 
+def torch_wanted() -> bool:
+    """False only when AMCX_SKIP_TORCH=1 and torch has not been imported yet: the host-buffer path (containers,
+    files, calculate_features) needs neither torch nor its HIP runtime, and a process that never touches torch
+    tensors -- the `extract` command line -- starts a second faster without the import."""
+    import sys
+    return "torch" in sys.modules or os.environ.get("AMCX_SKIP_TORCH", "0") != "1"
+
+
 def load() -> C.CDLL:
     """Load libamcx.so once.  torch (if installed) is imported first so that the
-    library binds to the HIP runtime torch ships and device pointers are shared."""
-    global _lib
+    library binds to the HIP runtime torch ships and device pointers are shared
+    (unless the process opted out of torch, see :func:`torch_wanted`: importing torch AFTER the library
+    has loaded the system runtime would put two HIP runtimes into one process)."""
+    global _lib, _loaded_without_torch
     if _lib is not None:
         return _lib
     if not LIB_PATH.exists():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python amcpy_amd/csrc/build.py` "
             "(hipcc, gfx950). amcpy_amd has no CPU fallback.")
-    try:
-        import torch  # noqa: F401  (side effect: loads torch's libamdhip64.so.7)
-    except Exception:
-        pass
+    if torch_wanted():
+        try:
+            import torch  # noqa: F401  (side effect: loads torch's libamdhip64.so.7)
+        except Exception:
+            pass
+    else:
+        _loaded_without_torch = True
     lib = C.CDLL(str(LIB_PATH), mode=C.RTLD_GLOBAL)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
@@ -88,6 +102,13 @@ def load() -> C.CDLL:
         raise ImportError(f"libamcx ABI {got} is older than the {ABI_VERSION} this binding needs")
     _lib = lib
     return lib
+
+
+def require_torch_runtime() -> None:
+    """The tensor entry points hand torch's device pointers to the library: both must sit on ONE HIP runtime."""
+    if _loaded_without_torch:
+        raise RuntimeError("libamcx.so was loaded with AMCX_SKIP_TORCH=1 (the system HIP runtime); torch tensors belong to "
+                           "the runtime torch ships. Unset AMCX_SKIP_TORCH, or import torch before amcpy_amd loads the library.")
 
 
 def check(code: int) -> None:

@@ -56,6 +56,8 @@ from .sharding import gather_rows, shard_range, sharded_features
 
 
 def _rank_world():
+    if not _lib.torch_wanted():          # a process that opted out of torch has no process group
+        return 0, 1
     try:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized():
@@ -178,12 +180,13 @@ class HipEngine:
         self.N = int(frame_size)
         if device is None:
             device = 0
-            try:
-                import torch
-                if torch.cuda.is_available():
-                    device = torch.cuda.current_device()
-            except Exception:
-                pass
+            if _lib.torch_wanted():
+                try:
+                    import torch
+                    if torch.cuda.is_available():
+                        device = torch.cuda.current_device()
+                except Exception:
+                    pass
         self.device = int(device)
         self.chunk_bytes = int(chunk_bytes)
         self.threads = max(1, min(int(threads or 8), os.cpu_count() or 1))

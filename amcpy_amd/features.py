@@ -44,6 +44,7 @@ def features18(iq, out=None, *, frame_size: int | None = None, variant="auto"):
     """
     import torch
 
+    _lib.require_torch_runtime()
     if not isinstance(iq, torch.Tensor) or iq.dtype != torch.complex64:
         raise TypeError("iq must be a torch.complex64 tensor")
     if not iq.is_cuda:

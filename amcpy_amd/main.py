@@ -9,6 +9,7 @@ written; this entry point takes the same defaults and simply works.
 from __future__ import annotations
 
 import argparse
+import os
 import sys
 from dataclasses import replace
 from pathlib import Path
@@ -41,6 +42,10 @@ def main(argv=None) -> int:
         sig = replace(sig, snr_values={i: str(v) for i, v in enumerate(args.snr_values)})
     cfg = replace(cfg, signals=sig)
     if args.command == "extract":
+        # One process, host containers in, files out: nothing here touches a torch tensor, so the import (a second of
+        # start-up) is skipped -- unless a launcher started this as one rank of several (torch.distributed needs it).
+        if "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+            os.environ.setdefault("AMCX_SKIP_TORCH", "1")
         from .feature_extraction import run_extraction
         run_extraction(cfg, device=args.device)
     return 0

@@ -36,7 +36,7 @@ for dtype in (np.complex64, np.complex128):
         r = subprocess.run([sys.executable, "-m", "amcpy_amd", "extract", "--root", td, "--num-frames", "500",
                             "--snr-values", "0", "10"], cwd=str(REPO), capture_output=True, text=True)
         print(f"{np.dtype(dtype).name:10s} `python -m amcpy_amd extract` as a subprocess: rc {r.returncode}, "
-              f"{time.time() - t0:.2f} s wall including interpreter start-up and `import torch`")
+              f"{time.time() - t0:.2f} s wall including interpreter start-up and HIP initialisation (torch is not imported)")
 
 # ---- round 3: a container at scale -- 6 modulations x (26, 512, 2048) complex128 = 2.6 GB in the file -------------------
 # How long does the container take to get from the file to the features, against decoding it with scipy alone?
