@@ -697,3 +697,26 @@ def test_native_staging_on_random_layouts():
         assert np.array_equal(got, ref), (case, shape, order, kind, pm, inner, first, count)
         seen.add((pm, inner))
     assert seen == {(0, 0), (1, 0), (1, 1)}, seen
+
+
+def test_opting_out_of_torch_is_all_or_nothing(tmp_path):
+    """AMCX_SKIP_TORCH=1 (what `python -m amcpy_amd extract` sets for itself): the library loads without importing
+    torch, the host-container path works from there, and the tensor entry point refuses instead of handing torch's
+    device pointers to a second HIP runtime."""
+    code = textwrap.dedent("""
+        import sys
+        from amcpy_amd import _lib
+        _lib.load()
+        assert "torch" not in sys.modules, "the library pulled torch in"
+        from amcpy_amd.feature_extraction import _rank_world
+        assert _rank_world() == (0, 1) and "torch" not in sys.modules
+        from amcpy_amd.features import features18
+        try:
+            features18(None)
+        except RuntimeError as exc:
+            assert "AMCX_SKIP_TORCH" in str(exc)
+            print("REFUSED")
+    """)
+    env = dict(os.environ, AMCX_SKIP_TORCH="1", PYTHONPATH=str(REPO), PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert r.returncode == 0 and "REFUSED" in r.stdout, r.stdout + r.stderr
