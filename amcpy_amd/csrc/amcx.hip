@@ -346,6 +346,7 @@ int ctx_run_strided(amcx_ctx* c, const void* re, const void* im, int32_t kind, i
   bool rows = false, inner_snr = false;
   amcx::RunMap map;
   if (!classify_layout(S, K, N, ss, sk, sn, &rows, &inner_snr, &map)) return AMCX_ENOTSUP;
+  if (!rows && S > 0x7fffffffLL) return AMCX_EINVAL;             // the transposition kernel indexes the snr axis with an int
   const bool as_c128 = c->round_on_device && kind == AMCX_SRC_C128;
   const size_t esz = as_c128 ? 16 : 8;
   const size_t src_esz = kind == AMCX_SRC_C64 ? 8 : kind == AMCX_SRC_C128 ? 16 : kind == AMCX_SRC_F32_SPLIT ? 4 : 8;
