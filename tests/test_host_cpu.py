@@ -720,3 +720,47 @@ def test_opting_out_of_torch_is_all_or_nothing(tmp_path):
     env = dict(os.environ, AMCX_SKIP_TORCH="1", PYTHONPATH=str(REPO), PYTHONDONTWRITEBYTECODE="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
     assert r.returncode == 0 and "REFUSED" in r.stdout, r.stdout + r.stderr
+
+
+def test_eight_rank_run_extraction_over_gloo(tmp_path):
+    """The target topology's rank count on CPU: eight ranks over gloo, 3 x 7 = 21 frames per modulation, so that
+    ceil(21 / 8) = 3 frames go to ranks 0..6 and rank 7's shard is EMPTY -- every rank still takes part in every
+    collective, rank 0 writes files equal to the single-process run."""
+    import scipy.io
+    from amcpy_amd.config import Config, Paths, SignalConfig
+    from amcpy_amd import feature_extraction as fe
+    rng = np.random.default_rng(13)
+    cfg = Config(paths=Paths(root=tmp_path / "eight"),
+                 signals=SignalConfig(snr_values={0: "0", 1: "10", 2: "20"}, num_frames=7, frame_size=16))
+    cfg1 = Config(paths=Paths(root=tmp_path / "one"), signals=cfg.signals)
+    container = {cfg.signals.mat_info[m]: (rng.standard_normal((3, 9, 20)) + 1j * rng.standard_normal((3, 9, 20)))
+                 for m in cfg.signals.modulations_with_noise}
+    for c in (cfg, cfg1):
+        c.paths.ensure_dirs()
+        scipy.io.savemat(str(c.paths.mat_data / c.paths.mat_filename), container)
+
+    def compute(block):
+        base = np.abs(np.asarray(block)[:, :16]).sum(axis=1, dtype=np.float64)
+        return (base[:, None] * np.arange(1, 19)[None, :]).astype(np.float32)
+
+    fe.run_extraction(cfg1, compute=compute, verbose=False)
+    script = tmp_path / "extract_worker8.py"
+    script.write_text(_EXTRACT_WORKER.replace(
+        'assert all(s[1] == (20 if direct else 16) for s in seen) and sum(s[0] for s in seen) in (6 * 11, 6 * 10), seen',
+        'assert sum(s[0] for s in seen) == (0 if rank == 7 else 6 * 3), (rank, seen)'))
+    port = _free_port()
+    procs = []
+    for r in range(8):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="8", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   AMCX_REPO=str(REPO), AMCX_ROOT=str(tmp_path / "eight"), AMCX_MODE="direct", PYTHONDONTWRITEBYTECODE="1",
+                   OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "EXTRACT_OK 0 6 18" in outs[0] and "EXTRACT_OK 7 6 0" in outs[7], (outs[0], outs[7])
+    for m in cfg.signals.modulations_with_noise:
+        a = scipy.io.loadmat(str(cfg1.paths.calculated_features / f"{m}_features.mat"))
+        b = scipy.io.loadmat(str(cfg.paths.calculated_features / f"{m}_features.mat"))
+        key = cfg.signals.mat_info[m]
+        assert b[key].shape == (3, 7, 18) and np.array_equal(a[key], b[key])
