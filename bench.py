@@ -567,6 +567,23 @@ def main():
         torch.cuda.empty_cache()
         h2d = h2d_path(dev, big=not args.no_h2d_big)
 
+    # N > 1: the one cross-rank step of the real path -- rank 0 collecting every rank's (F x 18) block
+    # (amcpy_amd/sharding.py: one padded float32 tensor gather; device tensors over RCCL) -- timed once, outside
+    # the timed region, so that a multi-GPU run also shows what the gather costs.  Never fatal to the headline.
+    gather = None
+    if use_dist and world > 1:
+        try:
+            from amcpy_amd.sharding import gather_rows
+            local = out.reshape(-1, 18).cpu().numpy()
+            dist.barrier()
+            t_g = time.perf_counter()
+            full = gather_rows(local, local.shape[0] * world, rank, world)
+            dist.barrier()
+            gather = {"ms": (time.perf_counter() - t_g) * 1e3, "bytes_per_rank": int(local.nbytes),
+                      "rows_on_rank0": None if full is None else int(full.shape[0]),
+                      "what": "sharding.gather_rows of one step's result from host memory, all ranks -> rank 0"}
+        except Exception as exc:
+            gather = {"error": repr(exc)}
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -607,6 +624,7 @@ def main():
         },
         "wall_incl_d2h_ms": wall_d2h_ms,
         "h2d": h2d,
+        "gather": gather,
         "parity": _parity_block(),
         "cpu_baseline": cpu,
         "cpu_baseline_reference_shaped": cpu_ref_shaped,

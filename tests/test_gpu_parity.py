@@ -1059,6 +1059,7 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     total = rec["value"] * rec["ms_per_step"] * 1e-3 * rec["steps"]
     assert abs(total - 2 * per_rank * 3) < 1e-3 * total, (total, rec["value"], rec["ms_per_step"])
     assert rec["roofline"]["launch_ms_min"] <= rec["roofline"]["launch_ms_median"] <= rec["roofline"]["launch_ms_max"]
+    assert rec["gather"]["rows_on_rank0"] == 2 * per_rank and rec["gather"]["bytes_per_rank"] == per_rank * 72, rec["gather"]
     # and a mismatch between --gpus and the launch is refused, not silently run as one rank
     bad = subprocess.run([sys.executable, str(repo / "bench.py"), "--gpus", "2", "--no-cpu-baseline"], env=env,
                          cwd=str(tmp_path), capture_output=True, text=True, timeout=120)
