@@ -11,6 +11,7 @@ those ids by up to 8.5e-3, so plain relative error is
 reported, not asserted, for them.
 """
 import os
+import textwrap
 from pathlib import Path
 import numpy as np
 import pytest
@@ -1109,3 +1110,30 @@ def test_strided_engine_on_random_layouts():
         assert got.shape == (hi - lo, 18)
         assert np.array_equal(got, want_all[lo:hi], equal_nan=True), (case, shape, order, kind, lo, hi, N)
         eng.close()
+
+
+def test_reference_side_ctypes_stub_from_integration_md():
+    """The binding INTEGRATION.md section 2 tells a maintainer of the reference to add -- ctypes and numpy only, no
+    amcpy_amd import -- executed as written (the fenced python blocks of that section, in order) on what loadmat
+    returns: a Fortran-ordered complex128 container with more frames and longer rows than the configuration uses."""
+    import re
+    import subprocess
+    import sys
+    repo = Path(__file__).resolve().parents[1]
+    text = (repo / "INTEGRATION.md").read_text()
+    sec = text[text.index("## 2. The stub"):text.index("## 3. The two edits")]
+    blocks = re.findall(r"```python\n(.*?)```", sec, flags=re.S)
+    assert len(blocks) >= 3
+    lib = repo / "amcpy_amd" / "lib" / "libamcx.so"
+    code = "\n".join(blocks[:2]).replace('C.CDLL("libamcx.so")', f'C.CDLL({str(lib)!r})')
+    code += textwrap.dedent("""
+        rng = np.random.default_rng(4)
+        full = np.asfortranarray(rng.standard_normal((3, 40, 300)) + 1j * rng.standard_normal((3, 40, 300)))
+        got = container_features(full, 2, 33, 256)
+        want = features18(full[:2, :33, :256].reshape(66, 256), 256).reshape(2, 33, 18)
+        assert got.shape == (2, 33, 18) and got.dtype == np.float32
+        assert np.array_equal(got, want, equal_nan=True), np.abs(got - want).max()
+        print("STUB_OK", float(got[1, 2, 5]))
+    """)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "STUB_OK" in r.stdout, r.stdout + r.stderr
