@@ -58,6 +58,32 @@ def gather_rows(local: np.ndarray, n_frames: int, rank: int, world: int, group=N
     return out
 
 
+def all_gather_rows(local, n_frames: int, rank: int, world: int, group=None):
+    """Every rank's (n_local, C) block of a torch tensor -> the full (n_frames, C) tensor ON EVERY RANK, in the
+    memory the blocks live in (device tensors over RCCL: ring / direct all-gather across xGMI; host tensors over
+    gloo).  For a device-side consumer that wants the whole feature matrix -- the standardising scaler's fit, the
+    per-SNR statistics (amcpy_amd/postprocess.py) -- without a trip through rank 0's host memory: 0.7 GB in all at
+    BASELINE configs[3].  Blocks are padded to the common ceil(F / W) rows, as in :func:`gather_rows`."""
+    import torch
+    if world == 1:
+        return local
+    import torch.distributed as dist
+    lo, hi = shard_range(n_frames, rank, world)
+    if local.shape[0] != hi - lo:
+        raise RuntimeError(f"rank {rank} holds {local.shape[0]} rows for [{lo}, {hi})")
+    per = -(-n_frames // world) if n_frames else 0
+    cols = local.shape[1]
+    mine = torch.zeros((per, cols), dtype=local.dtype, device=local.device)
+    if hi > lo:
+        mine[:hi - lo].copy_(local)
+    everything = torch.empty((world * per, cols), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(everything, mine, group=group)
+    if world * per == n_frames:
+        return everything
+    return torch.cat([everything[r * per:r * per + (b - a)] for r in range(world)
+                      for a, b in [shard_range(n_frames, r, world)] if b > a], dim=0)
+
+
 def sharded_features(frames: np.ndarray, frame_size: int, compute: Callable[[np.ndarray], np.ndarray],
                      rank: int = 0, world: int = 1, group=None) -> Optional[np.ndarray]:
     """(F, L) complex frames -> (F, 18) float32 on rank 0, each rank computing

@@ -170,6 +170,13 @@ _WORKER = textwrap.dedent('''
     out = sharded_features(frames, N, compute, rank, world)
     lo, hi = shard_range(F, rank, world)
     assert sum(calls) == hi - lo, (calls, lo, hi)
+    # the all-gather form (a device-side consumer on every rank): the same matrix everywhere
+    import torch
+    from amcpy_amd.sharding import all_gather_rows
+    mine = torch.from_numpy(compute(frames[lo:hi])) if hi > lo else torch.empty((0, 18))
+    everywhere = all_gather_rows(mine, F, rank, world)
+    want_all = (np.abs(frames[:, :N]).sum(axis=1, dtype=np.float64)[:, None] * np.arange(1, 19)).astype(np.float32)
+    assert tuple(everywhere.shape) == (F, 18) and np.array_equal(everywhere.numpy(), want_all), rank
     if rank == 0:
         want = (np.abs(frames[:, :N]).sum(axis=1, dtype=np.float64)[:, None] * np.arange(1, 19)).astype(np.float32)
         assert out.shape == (F, 18) and np.array_equal(out, want)
