@@ -12,7 +12,7 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("AMCX_LIB", _HERE / "lib" / "libamcx.so"))
 
-ABI_VERSION = 2          # the version this binding was written against; any library >= it will do (include/amcx.h)
+ABI_VERSION = 3          # the version this binding was written against; any library >= it will do (include/amcx.h)
 NUM_FEATURES = 18
 VARIANT_AUTO, VARIANT_BLOCK, VARIANT_WAVE = 0, 1, 2
 VARIANTS = {"auto": VARIANT_AUTO, "block": VARIANT_BLOCK, "wave": VARIANT_WAVE}
@@ -54,6 +54,11 @@ SIGNATURES = {
     "amcx_probe_read_bw": (C.c_int, [_vp, _i64, _vp, _vp]),
     "amcx_group_stats_f32": (C.c_int, [_vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp]),
     "amcx_select_scale_f32": (C.c_int, [_vp, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _i64, _vp]),
+    "amcx_group_stats_workspace_bytes": (_i64, [_i64, _i64, _i32]),
+    "amcx_group_stats_ws_f32": (C.c_int, [_vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _i64, _vp]),
+    "amcx_standardize_workspace_bytes": (_i64, [_i64, _i32]),
+    "amcx_standardize_fit_transform_f32": (C.c_int, [_vp, _i64, _i64, _i32, C.POINTER(_i32), _i32, _vp, _i64,
+                                                     _vp, _vp, _vp, _i64, _vp]),
 }
 
 _lib = None

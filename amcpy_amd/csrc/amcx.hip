@@ -663,17 +663,115 @@ int amcx_probe_read_bw(const void* src_dev, int64_t n_bytes, float* partial_dev,
   return AMCX_OK;
 }
 
+// how a statistics call is cut: chunks per group and rows per chunk (whole tiles)
+static void stats_plan(int64_t n_groups, int64_t rows_per_group, int n_cols, int64_t* chunks, int64_t* rows_per_chunk) {
+  const int64_t tile = amcx::stat_tile_rows(n_cols);
+  const int64_t tiles = (rows_per_group + tile - 1) / tile;
+  const int64_t target = 1024;                               // workgroups wanted in all (4 per CU, one resident round); the same on any device
+  int64_t want = (target + n_groups - 1) / n_groups;
+  if (want > tiles) want = tiles;
+  if (want < 1) want = 1;
+  const int64_t tiles_per_chunk = (tiles + want - 1) / want;
+  *rows_per_chunk = tiles_per_chunk * tile;
+  *chunks = (tiles + tiles_per_chunk - 1) / tiles_per_chunk;
+}
+
+static bool stats_args_ok(int64_t n_groups, int64_t rows_per_group, int64_t row_stride, int32_t n_cols) {
+  return n_groups >= 0 && rows_per_group >= 1 && n_cols >= 1 && n_cols <= amcx::kStatMaxCols &&
+         row_stride >= n_cols && row_stride <= (1 << 20) && n_groups <= 0x7fffffffLL;
+}
+
+int64_t amcx_group_stats_workspace_bytes(int64_t n_groups, int64_t rows_per_group, int32_t n_cols) {
+  if (!stats_args_ok(n_groups, rows_per_group, n_cols, n_cols)) return -1;
+  if (n_groups == 0) return 0;
+  int64_t chunks, rpc;
+  stats_plan(n_groups, rows_per_group, n_cols, &chunks, &rpc);
+  return n_groups * chunks * n_cols * 3 * (int64_t)sizeof(double);
+}
+
+int amcx_group_stats_ws_f32(const float* x_dev, int64_t n_groups, int64_t rows_per_group,
+                            int64_t row_stride, int32_t n_cols, double* mean_dev, double* std_dev,
+                            void* workspace_dev, int64_t workspace_bytes, void* hip_stream) {
+  if (!stats_args_ok(n_groups, rows_per_group, row_stride, n_cols)) return AMCX_EINVAL;
+  if (n_groups == 0) return AMCX_OK;
+  if (x_dev == nullptr || mean_dev == nullptr || std_dev == nullptr || workspace_dev == nullptr) return AMCX_EINVAL;
+  if (on_another_device(x_dev) || on_another_device(workspace_dev)) return AMCX_EINVAL;
+  int64_t chunks, rpc;
+  stats_plan(n_groups, rows_per_group, n_cols, &chunks, &rpc);
+  if (workspace_bytes < n_groups * chunks * n_cols * 3 * (int64_t)sizeof(double)) return AMCX_EINVAL;
+  if (n_groups * chunks > 0x7fffffffLL) return AMCX_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  double* part = static_cast<double*>(workspace_dev);
+  hipLaunchKernelGGL(amcx::amcx_stats_part_kernel, dim3((unsigned)(n_groups * chunks)),
+                     dim3(amcx::kStatThreads), 0, st, x_dev, (long long)rows_per_group,
+                     (long long)row_stride, (int)n_cols, (long long)rpc, (int)chunks, part);
+  // the pooling launch: one small workgroup per (column, group); groups beyond the grid's y limit go in slices
+  const unsigned pool_threads = chunks > 128 ? 256u : chunks > 64 ? 128u : 64u;
+  for (int64_t g0 = 0; g0 < n_groups; g0 += 65535) {
+    const int64_t ng = n_groups - g0 < 65535 ? n_groups - g0 : 65535;
+    hipLaunchKernelGGL(amcx::amcx_stats_combine_kernel, dim3((unsigned)n_cols, (unsigned)ng), dim3(pool_threads), 0, st,
+                       part + g0 * n_cols * 3 * chunks, (int)chunks, (int)n_cols, mean_dev + g0 * n_cols,
+                       std_dev + g0 * n_cols);
+  }
+  AMCX_HIP(hipGetLastError());
+  return AMCX_OK;
+}
+
 int amcx_group_stats_f32(const float* x_dev, int64_t n_groups, int64_t rows_per_group,
                          int64_t row_stride, int32_t n_cols, double* mean_dev, double* std_dev,
                          void* hip_stream) {
-  if (n_groups < 0 || rows_per_group < 1 || n_cols < 1 || n_cols > amcx::kStatMaxCols ||
-      row_stride < n_cols || n_groups > 0x7fffffffLL)
-    return AMCX_EINVAL;
+  if (!stats_args_ok(n_groups, rows_per_group, row_stride, n_cols)) return AMCX_EINVAL;
   if (n_groups == 0) return AMCX_OK;
   if (x_dev == nullptr || mean_dev == nullptr || std_dev == nullptr) return AMCX_EINVAL;
-  hipLaunchKernelGGL(amcx::amcx_group_stats_kernel, dim3((unsigned)n_groups), dim3(amcx::kBlockThreads), 0,
-                     static_cast<hipStream_t>(hip_stream), x_dev, (long long)rows_per_group,
-                     (long long)row_stride, (int)n_cols, mean_dev, std_dev);
+  const int64_t bytes = amcx_group_stats_workspace_bytes(n_groups, rows_per_group, n_cols);
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  void* ws = nullptr;
+  AMCX_HIP(hipMallocAsync(&ws, (size_t)bytes, st));           // stream-ordered: no synchronisation
+  const int rc = amcx_group_stats_ws_f32(x_dev, n_groups, rows_per_group, row_stride, n_cols, mean_dev,
+                                         std_dev, ws, bytes, hip_stream);
+  const hipError_t fe = hipFreeAsync(ws, st);
+  if (rc != AMCX_OK) return rc;
+  AMCX_HIP(fe);
+  return AMCX_OK;
+}
+
+int64_t amcx_standardize_workspace_bytes(int64_t n_rows, int32_t n_cols) {
+  if (n_rows < 1) return n_rows == 0 ? 0 : -1;
+  const int64_t part = amcx_group_stats_workspace_bytes(1, n_rows, n_cols);
+  return part < 0 ? -1 : part + 2 * (int64_t)amcx::kStatMaxCols * (int64_t)sizeof(double);
+}
+
+int amcx_standardize_fit_transform_f32(const float* x_dev, int64_t n_rows, int64_t row_stride,
+                                       int32_t n_cols, const int32_t* cols_host, int32_t n_sel,
+                                       float* out_dev, int64_t out_stride, double* mean_dev,
+                                       double* scale_dev, void* workspace_dev, int64_t workspace_bytes,
+                                       void* hip_stream) {
+  if (n_rows < 0 || n_sel < 1 || n_sel > amcx::kStatMaxCols || out_stride < n_sel || cols_host == nullptr ||
+      n_cols < 1 || n_cols > amcx::kStatMaxCols || row_stride < n_cols)
+    return AMCX_EINVAL;
+  amcx::SelectCols sel;
+  sel.n = n_sel;
+  for (int j = 0; j < amcx::kStatMaxCols; ++j) sel.c[j] = 0;
+  for (int j = 0; j < n_sel; ++j) {
+    if (cols_host[j] < 0 || cols_host[j] >= n_cols) return AMCX_EINVAL;
+    sel.c[j] = cols_host[j];
+  }
+  if (n_rows == 0) return AMCX_OK;
+  if (!x_dev || !out_dev || !mean_dev || !scale_dev || !workspace_dev) return AMCX_EINVAL;
+  if (on_another_device(x_dev) || on_another_device(out_dev)) return AMCX_EINVAL;
+  const int64_t need = amcx_standardize_workspace_bytes(n_rows, n_cols);
+  if (need < 0 || workspace_bytes < need) return AMCX_EINVAL;
+  double* all_mean = static_cast<double*>(workspace_dev);
+  double* all_std = all_mean + amcx::kStatMaxCols;
+  void* part = all_std + amcx::kStatMaxCols;
+  const int rc = amcx_group_stats_ws_f32(x_dev, 1, n_rows, row_stride, n_cols, all_mean, all_std, part,
+                                         need - 2 * (int64_t)amcx::kStatMaxCols * (int64_t)sizeof(double), hip_stream);
+  if (rc != AMCX_OK) return rc;
+  const int64_t grid = (n_rows + amcx::kSelectRows - 1) / amcx::kSelectRows;
+  if (grid > 0x7fffffffLL) return AMCX_EINVAL;
+  hipLaunchKernelGGL(amcx::amcx_select_fit_scale_kernel, dim3((unsigned)grid), dim3(amcx::kBlockThreads), 0,
+                     static_cast<hipStream_t>(hip_stream), x_dev, (long long)n_rows, (long long)row_stride, sel,
+                     all_mean, all_std, out_dev, (long long)out_stride, mean_dev, scale_dev);
   AMCX_HIP(hipGetLastError());
   return AMCX_OK;
 }

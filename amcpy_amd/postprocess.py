@@ -15,9 +15,9 @@ of amcpy_amd/csrc/amcx_post_kernels.h behind the C ABI.
 """
 from __future__ import annotations
 
+import ctypes
 from typing import Sequence, Tuple
 
-import numpy as np
 
 from . import _lib
 
@@ -43,37 +43,22 @@ def snr_statistics(feats):
     G = flat.shape[0]
     mean = torch.empty((G, Cc), dtype=torch.float64, device=feats.device)
     std = torch.empty_like(mean)
+    lib = _lib.load()
+    need = lib.amcx_group_stats_workspace_bytes(G, R, Cc)
+    if need < 0:
+        raise ValueError(f"statistics over {R} rows x {Cc} columns: at least one row, at most 32 columns")
+    ws = torch.empty((max(int(need), 8),), dtype=torch.uint8, device=feats.device)
     with torch.cuda.device(feats.device):
-        _lib.check(_lib.load().amcx_group_stats_f32(
-            flat.data_ptr(), G, R, flat.stride(1), Cc, mean.data_ptr(), std.data_ptr(),
+        _lib.check(lib.amcx_group_stats_ws_f32(
+            flat.data_ptr(), G, R, flat.stride(1), Cc, mean.data_ptr(), std.data_ptr(), ws.data_ptr(), ws.numel(),
             torch.cuda.current_stream(feats.device).cuda_stream))
     return mean.reshape(lead + (Cc,)), std.reshape(lead + (Cc,))
 
 
-def _column_stats(rows, chunk: int = 1024):
-    """Column mean / population std over ALL rows of a 2-D matrix: the group kernel over
-    row chunks (one workgroup each, so a 600 k-row matrix fills the chip), then the exact
-    pooled combination of the per-chunk (n, mean, M2) in fp64 on the tiny result."""
-    import torch
-    R = rows.shape[0]
-    parts = []
-    full = (R // chunk) * chunk
-    if full:
-        m, s = snr_statistics(rows[:full].reshape(R // chunk, chunk, rows.shape[1]))
-        parts.append((torch.full((m.shape[0], 1), float(chunk), dtype=torch.float64, device=rows.device), m, s))
-    if R - full:
-        m, s = snr_statistics(rows[full:][None])
-        parts.append((torch.full((1, 1), float(R - full), dtype=torch.float64, device=rows.device), m, s))
-    n = torch.cat([p[0] for p in parts]); m = torch.cat([p[1] for p in parts]); sd = torch.cat([p[2] for p in parts])
-    mean = (n * m).sum(dim=0) / R
-    m2 = (n * sd * sd + n * (m - mean) ** 2).sum(dim=0)
-    return mean, torch.sqrt(m2 / R)
-
-
 def select_standardize(rows, cols: Sequence[int]) -> Tuple["object", "object", "object"]:
     """rows: (R, C) float32 on the GPU -> (scaled (R, len(cols)) float32, mean, scale):
-    ``StandardScaler().fit_transform(rows[:, cols])`` (zero-variance columns get scale 1,
-    as sklearn does)."""
+    ``StandardScaler().fit_transform(rows[:, cols])`` (columns sklearn cannot tell from constant get
+    scale 1, by its own variance bound).  One C-ABI call, three launches, no host round trip."""
     import torch
     rows = _as_rows(rows)
     if rows.dim() != 2:
@@ -82,16 +67,21 @@ def select_standardize(rows, cols: Sequence[int]) -> Tuple["object", "object", "
     cols = [int(c) for c in cols]
     if any(c < 0 or c >= Cc for c in cols):
         raise IndexError("column index out of range")
-    mean_all, std_all = _column_stats(rows)
-    idx = torch.tensor(cols, dtype=torch.int64, device=rows.device)
-    mean = mean_all[idx].contiguous()
-    scale = std_all[idx].contiguous()
-    scale = torch.where(scale < 10 * np.finfo(np.float64).eps, torch.ones_like(scale), scale)
-    cols_dev = torch.tensor(cols, dtype=torch.int32, device=rows.device)
+    if not cols or len(cols) > 32 or Cc > 32:
+        raise ValueError("between 1 and 32 columns")
+    lib = _lib.load()
     out = torch.empty((R, len(cols)), dtype=torch.float32, device=rows.device)
+    mean = torch.empty((len(cols),), dtype=torch.float64, device=rows.device)
+    scale = torch.empty_like(mean)
+    if R == 0:
+        raise ValueError("no rows to fit the scaler on")
+    need = lib.amcx_standardize_workspace_bytes(R, Cc)
+    ws = torch.empty((int(need),), dtype=torch.uint8, device=rows.device)
+    cols_c = (ctypes.c_int32 * len(cols))(*cols)
     with torch.cuda.device(rows.device):
-        _lib.check(_lib.load().amcx_select_scale_f32(
-            rows.data_ptr(), R, rows.stride(0), cols_dev.data_ptr(), len(cols), mean.data_ptr(),
-            scale.data_ptr(), out.data_ptr(), out.stride(0),
+        # three launches on the current stream, nothing else: all-column statistics (read 1), chunk merge, transform (read 2)
+        _lib.check(lib.amcx_standardize_fit_transform_f32(
+            rows.data_ptr(), R, rows.stride(0), Cc, cols_c, len(cols), out.data_ptr(), out.stride(0),
+            mean.data_ptr(), scale.data_ptr(), ws.data_ptr(), ws.numel(),
             torch.cuda.current_stream(rows.device).cuda_stream))
     return out, mean, scale

@@ -76,8 +76,10 @@ extern "C" {
  * written against version v works with every library whose amcx_abi_version() >= v (and must
  * refuse an older one).  History: 1 = round 1-2 (features18, host / context entries, post kernels);
  * 2 = strided containers (amcx_ctx_features18_strided_host, amcx_stage_host, amcx_pack_planes_c64,
- * amcx_ctx_configure, amcx_ctx_upload_stats), device-ownership rule below made explicit. */
-#define AMCX_ABI_VERSION 2
+ * amcx_ctx_configure, amcx_ctx_upload_stats), device-ownership rule below made explicit;
+ * 3 = single-read statistics with a caller workspace (amcx_group_stats_ws_f32,
+ * amcx_group_stats_workspace_bytes) and amcx_standardize_fit_transform_f32 / _workspace_bytes. */
+#define AMCX_ABI_VERSION 3
 #define AMCX_NUM_FEATURES 18
 
 /* error codes */
@@ -284,11 +286,24 @@ int amcx_probe_read_bw(const void* src_dev, int64_t n_bytes, float* partial_dev,
  * rows, column mean and POPULATION standard deviation (ddof = 0) of the first n_cols
  * (<= 32) columns, fp64: mean_dev / std_dev are [n_groups][n_cols] doubles.
  * Replaces the per-SNR np.mean / np.std triple loop, graphics.py:50-62, and the fit
- * of StandardScaler, preprocessing.py:59-61.
+ * of StandardScaler, preprocessing.py:59-61.  The matrix is read once: every group is
+ * cut into chunks (one workgroup each, ~2048 in all), a chunk's (n, sum, M2) is formed
+ * from register-held tiles about each tile's own mean, and a second small launch merges
+ * the chunks pairwise (Chan, Golub & LeVeque); an inf in a column gives mean +-inf and
+ * std nan, as numpy's two passes do.  The chunk triples go through a workspace:
+ * amcx_group_stats_f32 takes it from the stream-ordered allocator (hipMallocAsync /
+ * hipFreeAsync on hip_stream: no synchronisation, but not capturable in a graph on
+ * every runtime); amcx_group_stats_ws_f32 takes the caller's (at least
+ * amcx_group_stats_workspace_bytes(...) bytes of device memory, contents undefined
+ * afterwards; the size depends on the three arguments only, -1 for invalid ones).
  */
 int amcx_group_stats_f32(const float* x_dev, int64_t n_groups, int64_t rows_per_group,
                          int64_t row_stride, int32_t n_cols, double* mean_dev, double* std_dev,
                          void* hip_stream);
+int64_t amcx_group_stats_workspace_bytes(int64_t n_groups, int64_t rows_per_group, int32_t n_cols);
+int amcx_group_stats_ws_f32(const float* x_dev, int64_t n_groups, int64_t rows_per_group,
+                            int64_t row_stride, int32_t n_cols, double* mean_dev, double* std_dev,
+                            void* workspace_dev, int64_t workspace_bytes, void* hip_stream);
 
 /*
  * amcx_select_scale_f32: out[r][j] = (x[r][cols[j]] - mean[j]) / scale[j], rounded to
@@ -300,6 +315,25 @@ int amcx_select_scale_f32(const float* x_dev, int64_t n_rows, int64_t row_stride
                           const int32_t* cols_dev, int32_t n_sel, const double* mean_dev,
                           const double* scale_dev, float* out_dev, int64_t out_stride,
                           void* hip_stream);
+
+/*
+ * amcx_standardize_fit_transform_f32: StandardScaler().fit_transform(X[:, cols]) of
+ * preprocessing.py:52-62 as three launches on hip_stream and nothing else -- no host
+ * round trip, no synchronisation: statistics of all n_cols (<= 32) columns over the
+ * n_rows rows (the two launches above, one group), then one launch that picks the
+ * n_sel (<= 32) columns cols_host[] (HOST array of 0-based indices, passed by value),
+ * turns their std into sklearn's scale_ (a column that the two-pass error bound cannot
+ * tell from constant gets 1: var <= n eps var + (n mean eps)^2, sklearn >= 0.24
+ * _is_constant_feature), writes mean_dev[n_sel] / scale_dev[n_sel] (doubles) and
+ * out_dev[r][j] with the two float32 roundings of amcx_select_scale_f32.
+ * workspace_dev: at least amcx_standardize_workspace_bytes(n_rows, n_cols) bytes.
+ */
+int64_t amcx_standardize_workspace_bytes(int64_t n_rows, int32_t n_cols);
+int amcx_standardize_fit_transform_f32(const float* x_dev, int64_t n_rows, int64_t row_stride,
+                                       int32_t n_cols, const int32_t* cols_host, int32_t n_sel,
+                                       float* out_dev, int64_t out_stride, double* mean_dev,
+                                       double* scale_dev, void* workspace_dev, int64_t workspace_bytes,
+                                       void* hip_stream);
 
 #ifdef __cplusplus
 }

@@ -57,6 +57,17 @@ int main(int argc, char** argv) {
     CHECK(amcx_stage_host(src, NULL, AMCX_SRC_C128, 2, 3, 4, 2, 4, 12, 0, 1, staged, sizeof staged, 1, NULL, NULL) == AMCX_ENOTSUP);
     CHECK(amcx_stage_host(src, NULL, AMCX_SRC_C128, 2, 3, 4, 1, 2, 6, 3, 2, staged, sizeof staged, 1, NULL, NULL) == AMCX_EINVAL);
   }
+  /* version-3 additions: workspace sizes are pure functions of their arguments */
+  CHECK(amcx_group_stats_workspace_bytes(156, 4096, 18) > 0);
+  CHECK(amcx_group_stats_workspace_bytes(1, 0, 18) == -1 && amcx_group_stats_workspace_bytes(1, 4, 33) == -1);
+  CHECK(amcx_group_stats_workspace_bytes(0, 4, 18) == 0);
+  CHECK(amcx_standardize_workspace_bytes(638976, 18) > amcx_group_stats_workspace_bytes(1, 638976, 18));
+  CHECK(amcx_group_stats_ws_f32(NULL, 1, 4, 18, 18, NULL, NULL, NULL, 0, NULL) == AMCX_EINVAL);
+  {
+    const int32_t cols[2] = {2, 18};
+    CHECK(amcx_standardize_fit_transform_f32(NULL, 4, 18, 18, cols, 2, NULL, 2, NULL, NULL, NULL, 0, NULL) == AMCX_EINVAL);
+    CHECK(amcx_standardize_fit_transform_f32(NULL, 0, 18, 18, cols, 1, NULL, 1, NULL, NULL, NULL, 0, NULL) == AMCX_OK);
+  }
   if (argc < 4 || strcmp(argv[1], "compute") != 0) {
     /* without a GPU the host-buffer entries must refuse, not compute */
     if (amcx_device_count() <= 0) {

@@ -54,6 +54,68 @@ def test_select_standardize_matches_sklearn():
     assert (g[:, -1] == 0).all()
 
 
+def test_statistics_shapes_outliers_and_infinities():
+    """Every cut of the chunked single-read statistics: ragged last tile, one row, one column, 32 columns, the whole
+    benchmark matrix as ONE group (1 427 chunks merged), a huge outlier in the first row (what a shifted one-pass sum
+    would lose), and an inf (numpy: mean inf, std nan)."""
+    import torch
+    from amcpy_amd import _lib
+    from amcpy_amd.postprocess import snr_statistics
+    rng = np.random.default_rng(11)
+    for shape in [(3, 1, 18), (2, 447, 18), (2, 449, 18), (1, 5000, 1), (4, 700, 32), (1, 638976, 18), (7, 12345, 5)]:
+        x = (rng.standard_normal(shape) * 3 + rng.standard_normal(shape[-1]) * 50).astype(np.float32)
+        mean, std = snr_statistics(torch.from_numpy(x).cuda())
+        x64 = x.astype(np.float64)
+        assert np.allclose(mean.cpu().numpy(), x64.mean(axis=1), rtol=1e-12, atol=1e-13), shape
+        assert np.allclose(std.cpu().numpy(), x64.std(axis=1), rtol=1e-11, atol=0), shape
+    x = rng.standard_normal((2, 3000, 18)).astype(np.float32)
+    x[0, 0, 3] = 1e30                                # outlier in the first row of a group
+    x[1, 2999, 4] = -3e25                            # and in the last
+    x[1, 17, 7] = np.inf
+    x[0, 100, 9] = np.inf; x[0, 200, 9] = -np.inf
+    mean, std = snr_statistics(torch.from_numpy(x).cuda())
+    with np.errstate(invalid="ignore", over="ignore"):
+        want_m, want_s = x.astype(np.float64).mean(axis=1), x.astype(np.float64).std(axis=1)
+    assert np.allclose(mean.cpu().numpy(), want_m, rtol=1e-12, atol=1e-13, equal_nan=True)
+    assert np.allclose(std.cpu().numpy(), want_s, rtol=1e-11, atol=0, equal_nan=True)
+    assert np.isposinf(want_m[1, 7]) and np.isnan(want_s[1, 7]) and np.isnan(want_m[0, 9])
+    # the entry without a workspace argument (stream-ordered allocation inside) gives the same doubles
+    lib = _lib.load()
+    xd = torch.from_numpy(x).cuda()
+    m2 = torch.empty((2, 18), dtype=torch.float64, device="cuda"); s2 = torch.empty_like(m2)
+    assert lib.amcx_group_stats_f32(xd.data_ptr(), 2, 3000, 18, 18, m2.data_ptr(), s2.data_ptr(),
+                                    torch.cuda.current_stream().cuda_stream) == _lib.OK
+    torch.cuda.synchronize()
+    assert np.array_equal(m2.cpu().numpy(), mean.cpu().numpy(), equal_nan=True)
+    assert np.array_equal(s2.cpu().numpy(), std.cpu().numpy(), equal_nan=True)
+    # a workspace that is too small is refused, not overrun
+    ws = torch.empty((64,), dtype=torch.uint8, device="cuda")
+    assert lib.amcx_group_stats_ws_f32(xd.data_ptr(), 2, 3000, 18, 18, m2.data_ptr(), s2.data_ptr(), ws.data_ptr(), 64,
+                                       None) == _lib.EINVAL
+
+
+def test_select_standardize_benchmark_matrix_and_near_constant_columns():
+    """The 638 976-row matrix of BASELINE configs[1] against sklearn, with a column that is constant up to float32
+    noise far below its mean (sklearn's variance bound decides, not a fixed threshold) and a strided input view."""
+    import torch
+    from sklearn.preprocessing import StandardScaler
+    from amcpy_amd.postprocess import select_standardize
+    x = _feats((638976, 18), 5)
+    x[:, 10] = np.float32(3.0e7)                      # constant, large
+    x[::2, 11] = np.float32(1.0); x[1::2, 11] = np.nextafter(np.float32(1.0), np.float32(2.0))   # 1-ulp ripple
+    used = [2, 4, 6, 8, 12, 14, 10, 11, 0, 17]
+    wide = torch.zeros((638976, 20), dtype=torch.float32, device="cuda")
+    wide[:, :18] = torch.from_numpy(x).cuda()
+    got, mean, scale = select_standardize(wide[:, :18], used)          # row stride 20
+    sc = StandardScaler()
+    want = sc.fit_transform(x[:, used])
+    assert np.allclose(mean.cpu().numpy(), sc.mean_, rtol=1e-12, atol=1e-12)
+    assert np.allclose(scale.cpu().numpy(), sc.scale_, rtol=1e-9, atol=0), (scale.cpu().numpy(), sc.scale_)
+    assert scale[6].item() == 1.0
+    g = got.cpu().numpy()
+    assert np.allclose(g, want, rtol=2e-6, atol=2e-6)
+
+
 def test_postprocess_argument_errors():
     import torch
     from amcpy_amd import _lib
