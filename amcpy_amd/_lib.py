@@ -16,14 +16,14 @@ ABI_VERSION = 3          # the version this binding was written against; any lib
 NUM_FEATURES = 18
 VARIANT_AUTO, VARIANT_BLOCK, VARIANT_WAVE = 0, 1, 2
 VARIANTS = {"auto": VARIANT_AUTO, "block": VARIANT_BLOCK, "wave": VARIANT_WAVE}
-OK, EINVAL, ENOTSUP, EHIP, ENODEV, ENOMEM = 0, -1, -2, -3, -4, -5
+OK, EINVAL, ENOTSUP, EHIP, ENODEV, ENOMEM, EIO = 0, -1, -2, -3, -4, -5, -6
 SRC_C64, SRC_C128, SRC_F32_SPLIT, SRC_F64_SPLIT = 0, 1, 2, 3
 
 
 class UploadStats(C.Structure):
     """amcx_upload_stats (include/amcx.h)."""
     _fields_ = [("frames", C.c_int64), ("source_bytes", C.c_int64), ("pcie_bytes", C.c_int64),
-                ("chunks", C.c_int32), ("threads", C.c_int32), ("plane_major", C.c_int32), ("reserved", C.c_int32),
+                ("chunks", C.c_int32), ("threads", C.c_int32), ("plane_major", C.c_int32), ("from_file", C.c_int32),
                 ("seconds", C.c_double), ("seconds_staging", C.c_double), ("seconds_waiting", C.c_double),
                 ("seconds_prepare", C.c_double), ("seconds_tail", C.c_double)]
 
@@ -46,6 +46,10 @@ SIGNATURES = {
     "amcx_ctx_features18_strided_host": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i64, _i32, _i64, _i64, _i64,
                                                    _vp, _i64, _i32]),
     "amcx_stage_host": (C.c_int, [_vp, _vp, _i32, _i64, _i64, _i32, _i64, _i64, _i64, _i64, _i64, _vp, _i64, _i32,
+                                  C.POINTER(_i32), C.POINTER(_i32)]),
+    "amcx_ctx_features18_strided_file": (C.c_int, [_vp, _i32, _i64, _i64, _i32, _i64, _i64, _i32, _i64, _i64, _i64,
+                                                   _vp, _i64, _i32]),
+    "amcx_stage_file": (C.c_int, [_i32, _i64, _i64, _i32, _i64, _i64, _i32, _i64, _i64, _i64, _i64, _i64, _vp, _i64, _i32,
                                   C.POINTER(_i32), C.POINTER(_i32)]),
     "amcx_ctx_configure": (C.c_int, [_vp, _i32, _i64, _i32]),
     "amcx_ctx_upload_stats": (C.c_int, [_vp, C.POINTER(UploadStats)]),
@@ -121,8 +125,10 @@ def check(code: int) -> None:
         return
     lib = load()
     msg = lib.amcx_strerror(code).decode()
-    if code == EHIP:
+    if code in (EHIP, EIO):
         msg += ": " + lib.amcx_last_hip_error().decode()
+    if code == EIO:
+        raise OSError(f"amcx: {msg}")
     if code == EINVAL:
         raise ValueError(f"amcx: {msg}")
     raise AmcxError(code, msg)
@@ -162,10 +168,19 @@ class HostContext:
             self._h, re_ptr, im_ptr, int(kind), int(n_snr), int(n_frames), int(frame_size),
             int(strides[0]), int(strides[1]), int(strides[2]), out.ctypes.data, out.shape[1], int(variant)))
 
+    def run_file(self, fd: int, re_offset: int, im_offset, kind: int, n_snr: int, n_frames: int, frame_size: int,
+                 strides, out, variant: int = VARIANT_AUTO) -> None:
+        """amcx_ctx_features18_strided_file: the container read from its file by the staging threads (byte
+        offsets of the real / imaginary arrays; strides in elements).  OSError if a read fails."""
+        check(load().amcx_ctx_features18_strided_file(
+            self._h, int(fd), int(re_offset), -1 if im_offset is None else int(im_offset), int(kind), int(n_snr),
+            int(n_frames), int(frame_size), int(strides[0]), int(strides[1]), int(strides[2]), out.ctypes.data,
+            out.shape[1], int(variant)))
+
     def upload_stats(self) -> dict:
         st = UploadStats()
         check(load().amcx_ctx_upload_stats(self._h, C.byref(st)))
-        return {name: getattr(st, name) for name, _ in UploadStats._fields_ if name != "reserved"}
+        return {name: getattr(st, name) for name, _ in UploadStats._fields_}
 
     def close(self) -> None:
         if self._h:

@@ -155,6 +155,7 @@ const char* amcx_strerror(int code) {
     case AMCX_EHIP: return "HIP runtime error (see amcx_last_hip_error)";
     case AMCX_ENODEV: return "no usable gfx950 device";
     case AMCX_ENOMEM: return "device memory allocation failed";
+    case AMCX_EIO: return "reading the container's file failed (see amcx_last_hip_error for the errno text)";
     default: return "unknown amcx error code";
   }
 }
@@ -330,10 +331,12 @@ int strided_prepare(amcx_ctx* c, size_t slot, size_t dslot, size_t frames_bytes,
   return rc;
 }
 
-int ctx_run_strided(amcx_ctx* c, const void* re, const void* im, int32_t kind, int64_t S, int64_t K,
+// src: memory (re / im) or a file (fd, byte offsets); src.kind is checked here, src.io_error is set here
+int ctx_run_strided(amcx_ctx* c, amcx::Source src, int64_t S, int64_t K,
                     int32_t N, int64_t ss, int64_t sk, int64_t sn, float* out_host, int64_t out_row_stride,
                     int32_t variant) {
   if (c == nullptr) return AMCX_EINVAL;
+  const int32_t kind = src.kind;
   if (S < 0 || K < 0 || ss < 0 || sk < 0 || sn < 0 || out_row_stride < AMCX_NUM_FEATURES ||
       kind < AMCX_SRC_C64 || kind > AMCX_SRC_F64_SPLIT)
     return AMCX_EINVAL;
@@ -341,7 +344,10 @@ int ctx_run_strided(amcx_ctx* c, const void* re, const void* im, int32_t kind, i
   if (v < 0) return v;
   if (S == 0 || K == 0) return AMCX_OK;
   if (S > (int64_t(1) << 40) / K) return AMCX_EINVAL;
-  if (re == nullptr || out_host == nullptr) return AMCX_EINVAL;
+  if ((src.fd < 0 && src.re == nullptr) || (src.fd >= 0 && src.re_off < 0) || out_host == nullptr) return AMCX_EINVAL;
+  if (kind < AMCX_SRC_F32_SPLIT) { src.im = nullptr; src.im_off = -1; }
+  std::atomic<int> io_error{0};
+  src.io_error = &io_error;
   const int64_t F = S * K;
   bool rows = false, inner_snr = false;
   amcx::RunMap map;
@@ -369,14 +375,10 @@ int ctx_run_strided(amcx_ctx* c, const void* re, const void* im, int32_t kind, i
                            threaded);
   if (rc != AMCX_OK) return rc;
   amcx::Pool inline_pool;                                          // size 1: stage_runs runs on the caller
-  amcx::Source src;
-  src.re = static_cast<const char*>(re);
-  src.im = (kind >= AMCX_SRC_F32_SPLIT) ? static_cast<const char*>(im) : nullptr;
-  src.kind = kind;
   amcx_upload_stats st = {};
   amcx::Pool& pool = threaded ? c->pool : inline_pool;
-  st.frames = F; st.threads = pool.size(); st.plane_major = rows ? 0 : 1;
-  st.source_bytes = F * (int64_t)N * (int64_t)src_esz * ((kind >= AMCX_SRC_F32_SPLIT && src.im) ? 2 : 1);
+  st.frames = F; st.threads = pool.size(); st.plane_major = rows ? 0 : 1; st.from_file = src.fd >= 0 ? 1 : 0;
+  st.source_bytes = F * (int64_t)N * (int64_t)src_esz * ((kind >= AMCX_SRC_F32_SPLIT && src.has_im()) ? 2 : 1);
 
   hipError_t e = hipSuccess;
   const double t_loop = wall_now();
@@ -408,6 +410,11 @@ int ctx_run_strided(amcx_ctx* c, const void* re, const void* im, int32_t kind, i
       const int64_t per_unit = rows ? 1 : map.cnt_b;
       amcx::stage_runs(pool, pinned, src, map, u * per_unit, (u + take) * per_unit, as_c128);
       st.seconds_staging += wall_now() - t0;
+      if (io_error.load() != 0) {                          // nothing of this chunk is queued; what is in flight is drained below
+        snprintf(g_hip_err, sizeof g_hip_err, "reading the container's file: %s", strerror(io_error.load()));
+        rc = AMCX_EIO;
+        break;
+      }
     }
     if (ch >= 2) { e = hipStreamWaitEvent(c->copy_stream, c->slab_free[ds], 0); if (e != hipSuccess) break; }
     e = hipMemcpyAsync(dev, pinned, bytes, hipMemcpyHostToDevice, c->copy_stream);
@@ -479,8 +486,10 @@ int ctx_run(amcx_ctx* c, const void* iq_host, bool is_c128, int64_t n_frames, in
             int64_t row_stride_elems, float* out_host, int64_t out_row_stride, int32_t variant) {
   if (c == nullptr) return AMCX_EINVAL;
   if (n_frames < 0 || row_stride_elems < frame_size || out_row_stride < AMCX_NUM_FEATURES) return AMCX_EINVAL;
-  return ctx_run_strided(c, iq_host, nullptr, is_c128 ? AMCX_SRC_C128 : AMCX_SRC_C64, 1, n_frames, frame_size, 0,
-                         row_stride_elems, 1, out_host, out_row_stride, variant);
+  amcx::Source src;
+  src.re = static_cast<const char*>(iq_host);
+  src.kind = is_c128 ? AMCX_SRC_C128 : AMCX_SRC_C64;
+  return ctx_run_strided(c, src, 1, n_frames, frame_size, 0, row_stride_elems, 1, out_host, out_row_stride, variant);
 }
 
 }  // namespace
@@ -527,14 +536,33 @@ int amcx_ctx_features18_strided_host(amcx_ctx* ctx, const void* re, const void* 
                                      int64_t n_snr, int64_t n_frames, int32_t frame_size,
                                      int64_t stride_snr, int64_t stride_frame, int64_t stride_sample,
                                      float* out_host, int64_t out_row_stride, int32_t variant) {
-  return ctx_run_strided(ctx, re, im, kind, n_snr, n_frames, frame_size, stride_snr, stride_frame, stride_sample,
+  amcx::Source src;
+  src.re = static_cast<const char*>(re);
+  src.im = static_cast<const char*>(im);
+  src.kind = kind;
+  return ctx_run_strided(ctx, src, n_snr, n_frames, frame_size, stride_snr, stride_frame, stride_sample,
                          out_host, out_row_stride, variant);
 }
 
-int amcx_stage_host(const void* re, const void* im, int32_t kind, int64_t n_snr, int64_t n_frames,
-                    int32_t frame_size, int64_t stride_snr, int64_t stride_frame, int64_t stride_sample,
-                    int64_t first_unit, int64_t n_units, void* dst, int64_t dst_bytes, int32_t threads,
-                    int32_t* plane_major, int32_t* inner_snr_out) {
+int amcx_ctx_features18_strided_file(amcx_ctx* ctx, int32_t fd, int64_t re_offset, int64_t im_offset, int32_t kind,
+                                     int64_t n_snr, int64_t n_frames, int32_t frame_size,
+                                     int64_t stride_snr, int64_t stride_frame, int64_t stride_sample,
+                                     float* out_host, int64_t out_row_stride, int32_t variant) {
+  if (fd < 0 || re_offset < 0) return AMCX_EINVAL;
+  amcx::Source src;
+  src.fd = fd;
+  src.re_off = re_offset;
+  src.im_off = im_offset;
+  src.kind = kind;
+  return ctx_run_strided(ctx, src, n_snr, n_frames, frame_size, stride_snr, stride_frame, stride_sample,
+                         out_host, out_row_stride, variant);
+}
+
+static int stage_any(amcx::Source src, int64_t n_snr, int64_t n_frames,
+                     int32_t frame_size, int64_t stride_snr, int64_t stride_frame, int64_t stride_sample,
+                     int64_t first_unit, int64_t n_units, void* dst, int64_t dst_bytes, int32_t threads,
+                     int32_t* plane_major, int32_t* inner_snr_out) {
+  const int32_t kind = src.kind;
   if (n_snr < 0 || n_frames < 0 || stride_snr < 0 || stride_frame < 0 || stride_sample < 0 || first_unit < 0 ||
       n_units < 0 || threads < 0 || threads > 256 || kind < AMCX_SRC_C64 || kind > AMCX_SRC_F64_SPLIT ||
       frame_size < AMCX_MIN_FRAME_SIZE || frame_size > AMCX_MAX_FRAME_SIZE)
@@ -549,16 +577,45 @@ int amcx_stage_host(const void* re, const void* im, int32_t kind, int64_t n_snr,
   const int64_t F = n_snr * n_frames, unit = rows ? frame_size : F, total_units = rows ? F : frame_size;
   if (first_unit + n_units > total_units) return AMCX_EINVAL;
   if (n_units == 0 || unit == 0) return AMCX_OK;
-  if (re == nullptr || dst == nullptr || dst_bytes < n_units * unit * 8) return AMCX_EINVAL;
-  amcx::Source src;
-  src.re = static_cast<const char*>(re);
-  src.im = (kind >= AMCX_SRC_F32_SPLIT) ? static_cast<const char*>(im) : nullptr;
-  src.kind = kind;
+  if ((src.fd < 0 && src.re == nullptr) || dst == nullptr || dst_bytes < n_units * unit * 8) return AMCX_EINVAL;
+  if (kind < AMCX_SRC_F32_SPLIT) { src.im = nullptr; src.im_off = -1; }
+  std::atomic<int> io_error{0};
+  src.io_error = &io_error;
   amcx::Pool pool;
   pool.resize(threads < 1 ? 1 : threads);
   const int64_t per_unit = rows ? 1 : map.cnt_b;
   amcx::stage_runs(pool, static_cast<char*>(dst), src, map, first_unit * per_unit, (first_unit + n_units) * per_unit, false);
+  if (io_error.load() != 0) {
+    snprintf(g_hip_err, sizeof g_hip_err, "reading the container's file: %s", strerror(io_error.load()));
+    return AMCX_EIO;
+  }
   return AMCX_OK;
+}
+
+int amcx_stage_host(const void* re, const void* im, int32_t kind, int64_t n_snr, int64_t n_frames,
+                    int32_t frame_size, int64_t stride_snr, int64_t stride_frame, int64_t stride_sample,
+                    int64_t first_unit, int64_t n_units, void* dst, int64_t dst_bytes, int32_t threads,
+                    int32_t* plane_major, int32_t* inner_snr_out) {
+  amcx::Source src;
+  src.re = static_cast<const char*>(re);
+  src.im = static_cast<const char*>(im);
+  src.kind = kind;
+  return stage_any(src, n_snr, n_frames, frame_size, stride_snr, stride_frame, stride_sample, first_unit, n_units, dst,
+                   dst_bytes, threads, plane_major, inner_snr_out);
+}
+
+int amcx_stage_file(int32_t fd, int64_t re_offset, int64_t im_offset, int32_t kind, int64_t n_snr, int64_t n_frames,
+                    int32_t frame_size, int64_t stride_snr, int64_t stride_frame, int64_t stride_sample,
+                    int64_t first_unit, int64_t n_units, void* dst, int64_t dst_bytes, int32_t threads,
+                    int32_t* plane_major, int32_t* inner_snr_out) {
+  if (fd < 0 || re_offset < 0) return AMCX_EINVAL;
+  amcx::Source src;
+  src.fd = fd;
+  src.re_off = re_offset;
+  src.im_off = im_offset;
+  src.kind = kind;
+  return stage_any(src, n_snr, n_frames, frame_size, stride_snr, stride_frame, stride_sample, first_unit, n_units, dst,
+                   dst_bytes, threads, plane_major, inner_snr_out);
 }
 
 int amcx_ctx_configure(amcx_ctx* ctx, int32_t threads, int64_t slot_bytes, int32_t round_on_device) {

@@ -14,8 +14,10 @@
 // (profiles/r3_h2d_probe.txt): 8 threads copy pageable -> pinned at 138 GB/s, the link does 57 GB/s.
 #pragma once
 
+#include <errno.h>
 #include <stdint.h>
 #include <string.h>
+#include <unistd.h>
 #if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
 #include <emmintrin.h>
 #define AMCX_STAGE_SSE2 1
@@ -131,10 +133,21 @@ class Pool {
 // ---- source description ---------------------------------------------------------------------------
 // kinds as in include/amcx.h (AMCX_SRC_*): interleaved complex64 / complex128, or split real / imaginary
 // arrays of float32 / float64 (im == nullptr: a real signal, imaginary part zero)
+//
+// A source is memory (re / im pointers) or a FILE (fd >= 0; re_off / im_off are byte offsets of the same arrays,
+// im_off < 0: no imaginary part).  A file is read with pread by the staging threads themselves, 16 K elements at a
+// time into a per-thread scratch that stays in the core's L2, and converted from there into the pinned slot: the
+// container never exists in host memory outside the page cache.  First-touching the pages of a fresh mapping of a
+// 436 MB variable costs 30 ms however many threads fault, reading it into a fresh buffer as much again for the
+// buffer's own pages (profiles/r3_read_probe.txt); pread into 256 KB that every thread reuses has neither cost.
 struct Source {
   const char* re = nullptr;
   const char* im = nullptr;
   int kind = 0;
+  int fd = -1;
+  int64_t re_off = 0, im_off = -1;
+  std::atomic<int>* io_error = nullptr;     // set to an errno (EIO for a short file) by the first read that fails
+  bool has_im() const { return fd >= 0 ? im_off >= 0 : im != nullptr; }
 };
 enum { kSrcC64 = 0, kSrcC128 = 1, kSrcF32Split = 2, kSrcF64Split = 3 };
 
@@ -196,9 +209,65 @@ inline void round_interleave_doubles(float* dst, const double* re, const double*
 inline void stage_fence() {}
 #endif
 
+inline bool read_exact(int fd, char* buf, size_t n, int64_t off) {
+  while (n > 0) {
+    const ssize_t got = pread(fd, buf, n, (off_t)off);
+    if (got < 0) {
+      if (errno == EINTR) continue;
+      return false;
+    }
+    if (got == 0) { errno = EIO; return false; }       // the file ends inside the variable
+    buf += got; n -= (size_t)got; off += got;
+  }
+  return true;
+}
+
+constexpr int64_t kFileBlockElems = 16384;
+
+inline void stage_elems(char* dst, const Source& s, int64_t off, int64_t count, bool as_c128);
+
+// the file form of stage_elems: blocks of the source through the calling thread's scratch
+inline void stage_elems_file(char* dst, const Source& s, int64_t off, int64_t count, bool as_c128) {
+  if (s.io_error != nullptr && s.io_error->load(std::memory_order_relaxed) != 0) return;   // the call has failed already
+  bool ok = true;
+  if (s.kind == kSrcC64) {
+    ok = read_exact(s.fd, dst, (size_t)count * 8, s.re_off + off * 8);
+  } else if (s.kind == kSrcC128 && as_c128) {
+    ok = read_exact(s.fd, dst, (size_t)count * 16, s.re_off + off * 16);
+  } else {
+    thread_local std::vector<char> scratch;
+    if (scratch.size() < (size_t)kFileBlockElems * 16) scratch.resize((size_t)kFileBlockElems * 16);
+    char* const a = scratch.data();
+    char* const b = a + kFileBlockElems * 8;
+    const int64_t part = s.kind == kSrcF32Split ? 4 : 8;       // bytes per element of one split array
+    Source mem;
+    mem.kind = s.kind;
+    mem.re = a;
+    mem.im = (s.kind != kSrcC128 && s.im_off >= 0) ? b : nullptr;
+    for (int64_t done = 0; done < count && ok; done += kFileBlockElems) {
+      const int64_t n = count - done < kFileBlockElems ? count - done : kFileBlockElems;
+      if (s.kind == kSrcC128) {
+        ok = read_exact(s.fd, a, (size_t)n * 16, s.re_off + (off + done) * 16);
+      } else {
+        ok = read_exact(s.fd, a, (size_t)(n * part), s.re_off + (off + done) * part);
+        if (ok && mem.im != nullptr) ok = read_exact(s.fd, b, (size_t)(n * part), s.im_off + (off + done) * part);
+      }
+      if (ok) stage_elems(dst + (size_t)done * 8, mem, 0, n, false);
+    }
+  }
+  if (!ok && s.io_error != nullptr) {
+    int expected = 0;
+    s.io_error->compare_exchange_strong(expected, errno != 0 ? errno : EIO);
+  }
+}
+
 // count elements starting at source element `off` -> dst.  as_c128: complex128 copied as it is
 // (16 bytes per element, rounded later on the device); otherwise dst is complex64.
 inline void stage_elems(char* dst, const Source& s, int64_t off, int64_t count, bool as_c128) {
+  if (s.fd >= 0) {
+    stage_elems_file(dst, s, off, count, as_c128);
+    return;
+  }
   float* const q = reinterpret_cast<float*>(dst);
   switch (s.kind) {
     case kSrcC64:
@@ -249,7 +318,12 @@ inline void stage_runs(Pool& pool, char* dst, const Source& s, const RunMap& m, 
       const int64_t r = e / m.run_len, within = e - r * m.run_len;
       int64_t n = m.run_len - within;
       if (n > e1 - e) n = e1 - e;
-      stage_elems(dst + (size_t)e * esz, s, m.offset(run0 + r) + within, n, as_c128);
+      const int64_t from = m.offset(run0 + r) + within;
+      // runs that follow each other in the source (the rows of a raw stream, the planes of an unpadded
+      // container) are one copy -- for a file, one pread
+      for (int64_t rr = r; e + n < e1 && m.offset(run0 + rr + 1) == m.offset(run0 + rr) + m.run_len; ++rr)
+        n += (m.run_len < e1 - e - n) ? m.run_len : e1 - e - n;
+      stage_elems(dst + (size_t)e * esz, s, from, n, as_c128);
       e += n;
     }
     stage_fence();

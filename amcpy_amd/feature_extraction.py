@@ -40,9 +40,11 @@ What is different underneath:
 """
 from __future__ import annotations
 
+import functools
 import os
 import socket
 import tempfile
+import threading
 import time
 from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
@@ -91,6 +93,72 @@ class SplitComplex:
         if self.imag is not None:
             out.imag = self.imag[idx]
         return out
+
+
+class FileComplex:
+    """A complex ``(n_snr, n_frames, L)`` container that is still in its FILE: the byte offsets of its real and
+    imaginary arrays (column-major float32 / float64, how a level-5 .mat stores an uncompressed complex variable;
+    ``imag_offset`` None: a real signal), or of ONE interleaved complex array (``interleaved=True``: a raw
+    complex64 / complex128 stream, C-ordered).  Nothing is read or mapped here: the engine's staging threads pread
+    the file block by block on their way to the pinned slots (``amcx_ctx_features18_strided_file``), so the
+    variable never exists in host memory outside the page cache.  Indexing (tests, injected engines) goes
+    through a memory mapping.  ``release()`` closes the descriptor."""
+
+    def __init__(self, path, store_dtype, shape, real_offset: int, imag_offset: Optional[int] = None, *,
+                 interleaved: bool = False):
+        self.path = Path(path)
+        self.store = np.dtype(store_dtype)
+        self.interleaved = bool(interleaved)
+        if not self.interleaved and self.store not in (np.float32, np.float64):
+            raise TypeError(f"split containers hold float32 or float64, got {self.store}")
+        if self.interleaved and self.store not in (np.complex64, np.complex128):
+            raise TypeError(f"interleaved containers hold complex64 or complex128, got {self.store}")
+        self.shape, self.ndim = tuple(int(x) for x in shape), len(shape)
+        self.real_offset, self.imag_offset = int(real_offset), (None if imag_offset is None else int(imag_offset))
+        self.dtype = self.store if self.interleaved else \
+            np.dtype(np.complex64 if self.store == np.float32 else np.complex128)
+        # element strides: column-major for the split arrays of a .mat, row-major for a raw stream
+        st, acc = [], 1
+        for n in (self.shape if not self.interleaved else self.shape[::-1]):
+            st.append(acc)
+            acc *= n
+        self.strides_elems = tuple(st if not self.interleaved else st[::-1])
+        self.source = "file"
+        self._fd, self._view, self._lock = None, None, threading.Lock()
+
+    def fileno(self) -> int:
+        with self._lock:
+            if self._fd is None:
+                self._fd = os.open(str(self.path), os.O_RDONLY)
+            return self._fd
+
+    def release(self) -> None:
+        with self._lock:
+            if self._fd is not None:
+                os.close(self._fd)
+                self._fd = None
+            self._view = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    def _mapped(self):
+        if self._view is None:
+            order = "C" if self.interleaved else "F"
+            re = np.memmap(self.path, dtype=self.store, mode="r", offset=self.real_offset, shape=self.shape, order=order)
+            if self.interleaved:
+                self._view = re
+            else:
+                im = None if self.imag_offset is None else \
+                    np.memmap(self.path, dtype=self.store, mode="r", offset=self.imag_offset, shape=self.shape, order="F")
+                self._view = SplitComplex(re, im)
+        return self._view
+
+    def __getitem__(self, idx) -> np.ndarray:
+        return np.asarray(self._mapped()[idx])
 
 
 class FrameRows:
@@ -143,8 +211,15 @@ class FrameRows:
 
 
 def _native_source(arr):
-    """(keepalive, re_ptr, im_ptr, kind, element strides, bytes per element) of a container the
-    native engine can read in place, or None if it has to be copied first."""
+    """(keepalive, re_ptr, im_ptr, kind, element strides, bytes per element, fd) of a container the
+    native engine can read in place -- pointers, or byte offsets into the file ``fd`` -- or None if it has to be
+    copied first."""
+    if isinstance(arr, FileComplex):
+        if arr.interleaved:
+            kind = _lib.SRC_C64 if arr.store == np.complex64 else _lib.SRC_C128
+        else:
+            kind = _lib.SRC_F32_SPLIT if arr.store == np.float32 else _lib.SRC_F64_SPLIT
+        return arr, arr.real_offset, arr.imag_offset, kind, list(arr.strides_elems), arr.store.itemsize, arr.fileno()
     if isinstance(arr, SplitComplex):
         re, im = arr.real, arr.imag
         kind = _lib.SRC_F32_SPLIT if re.dtype == np.float32 else _lib.SRC_F64_SPLIT
@@ -157,7 +232,7 @@ def _native_source(arr):
     item = re.itemsize
     if any(st < 0 or st % item for st in re.strides):
         return None
-    return (re, im), re.ctypes.data, (None if im is None else im.ctypes.data), kind, [st // item for st in re.strides], item
+    return (re, im), re.ctypes.data, (None if im is None else im.ctypes.data), kind, [st // item for st in re.strides], item, None
 
 
 # ----------------------------------------------------------------------------
@@ -201,15 +276,30 @@ class HipEngine:
         return self._ctx
 
     def _run_block(self, src, base_elems: int, n_snr: int, n_frames: int, strides, out: np.ndarray) -> None:
-        keep, re_ptr, im_ptr, kind, _, item = src
+        keep, re_ptr, im_ptr, kind, _, item, fd = src
+        if fd is not None:
+            # a file is read run by run (one pread each): worth it for whole planes or rows, not for the few snr
+            # values per sample that a shard cut across the snr axis leaves of a column-major plane
+            ss, sk, sn = strides
+            if sn == 1:
+                run = self.N * (n_frames if sk == self.N else 1)       # rows that follow each other are one read
+            elif sk == 1 and n_frames > 1:
+                run = n_snr * n_frames if ss == n_frames else n_frames
+            else:
+                run = n_snr * n_frames if sk == n_snr else n_snr
+            if run * item < (8 << 10):
+                src = _native_source(keep._mapped())
+                keep, re_ptr, im_ptr, kind, _, item, fd = src
         ctx = self._context()
-        ctx.run_strided(re_ptr + base_elems * item, None if im_ptr is None else im_ptr + base_elems * item,
-                        kind, n_snr, n_frames, self.N, strides, out)
+        run = ctx.run_strided if fd is None else functools.partial(ctx.run_file, fd)
+        run(re_ptr + base_elems * item, None if im_ptr is None else im_ptr + base_elems * item,
+            kind, n_snr, n_frames, self.N, strides, out)
         st = ctx.upload_stats()
         for k in ("frames", "source_bytes", "pcie_bytes", "chunks", "seconds_staging", "seconds_waiting",
                   "seconds_prepare", "seconds_tail", "seconds"):
             self.stats[k] = self.stats.get(k, 0) + st[k]
         self.stats["gather_threads"], self.stats["plane_major"] = st["threads"], st["plane_major"]
+        self.stats["from_file"] = max(self.stats.get("from_file", 0), st["from_file"])
 
     def __call__(self, frames) -> np.ndarray:
         if isinstance(frames, FrameRows):
@@ -317,7 +407,7 @@ def extract_raw_stream(path, frame_size: int, *, skip_samples: int = 0, max_fram
     ``np.fromfile(..., dtype=np.complex64)`` and a fixed number of leading samples dropped,
     old/read_binary_stream.py:28,48,54-56).  The file is memory-mapped and cut into
     consecutive ``frame_size``-sample frames (a trailing partial frame is dropped); the staging
-    threads read the mapping slot by slot, so the file never has to fit in host memory.
+    threads read the file slot by slot, so it never has to fit in host memory.
     Returns ``(n_frames, 18)`` float32."""
     if frame_size < 2:
         raise ValueError("frame_size must be >= 2")
@@ -329,10 +419,15 @@ def extract_raw_stream(path, frame_size: int, *, skip_samples: int = 0, max_fram
         n_frames = min(n_frames, int(max_frames))
     if n_frames == 0:
         return np.empty((0, 18), dtype=np.float32)
+    if compute is None:                 # the staging threads read the file themselves, part by part
+        stream = FileComplex(path, np.complex64, (1, n_frames, frame_size), 8 * skip_samples, interleaved=True)
+        try:
+            return np.asarray(HipEngine(frame_size, device)(FrameRows(stream, 1, n_frames)), dtype=np.float32)
+        finally:
+            stream.release()
     frames = np.memmap(path, dtype=np.complex64, mode="r", offset=8 * skip_samples,
                        shape=(n_frames, frame_size))
-    fn = compute or HipEngine(frame_size, device)
-    return np.asarray(fn(frames), dtype=np.float32)
+    return np.asarray(compute(frames), dtype=np.float32)
 
 
 def _pairs_as_complex(block: np.ndarray) -> np.ndarray:
@@ -472,9 +567,9 @@ def _publish_container(parsed, n_snr: int, n_frames: int, N: int, threads: int) 
     return Path(name)
 
 
-def _load_variable(mat_path: Path, key: str, pool=None):
+def _load_variable(mat_path: Path, key: str, pool=None, direct: bool = False):
     from .matfile import load_variable
-    return load_variable(mat_path, key, pool)
+    return load_variable(mat_path, key, pool, direct)
 
 
 def _same_host(world: int) -> bool:
@@ -511,6 +606,9 @@ def run_extraction(cfg: Config, *, compute=None, device: Optional[int] = None, v
             print(f"[{mod}] {feats.shape[0] * feats.shape[1]} frames in "
                   f"{time.perf_counter() - t0:.2f}s -> {out_path}")
 
+    # uncompressed variables go from the file to the pinned slots inside the native engine (AMCX_DIRECT_FILE=0: read /
+    # map them in Python first, the round-3 path kept for A/B runs); an injected engine gets arrays
+    direct = compute is None and os.environ.get("AMCX_DIRECT_FILE", "1") != "0"
     writer = ThreadPoolExecutor(max_workers=1, thread_name_prefix="amcx-writer") if rank == 0 else None
     writes = []
     published: List[Path] = []          # rank 0: shared files not yet removed
@@ -519,11 +617,13 @@ def run_extraction(cfg: Config, *, compute=None, device: Optional[int] = None, v
         if world == 1:
             from .matfile import BufferPool, stores_compressed
             # A compressed container is inflate-bound: three reader threads run ahead (zlib releases the GIL).  An
-            # uncompressed one is read with preadv into two pairs of buffers that take turns (one being uploaded, one
-            # being filled): reading is faster than first-touching fresh pages, mapped or allocated.
+            # uncompressed variable is only LOCATED here: the native engine's staging threads read it from the file
+            # on their way to the pinned slots.  With an injected engine (tests) it is read with preadv into two
+            # pairs of buffers that take turns: reading is faster than first-touching fresh pages, mapped or allocated.
             pool = BufferPool()
             depth = 3 if stores_compressed(mat_path) else 1
-            feed = _prefetched(mods, lambda m: _load_variable(mat_path, cfg.signals.mat_info[m], pool), depth)
+            feed = _prefetched(mods, lambda m: _load_variable(mat_path, cfg.signals.mat_info[m], pool, direct),
+                               depth)
             for mod, fut in feed:
                 t0 = time.perf_counter()
                 key = cfg.signals.mat_info[mod]
@@ -541,17 +641,17 @@ def run_extraction(cfg: Config, *, compute=None, device: Optional[int] = None, v
             mapped = {}                                 # rank 0: variables its reader thread has already mapped
 
             def decode_and_publish(mod):                # rank 0's reader thread
-                parsed = _load_variable(mat_path, cfg.signals.mat_info[mod])
+                parsed = _load_variable(mat_path, cfg.signals.mat_info[mod], None, direct)
                 n_snr, n_frames, _ = _check_container(parsed, cfg)
-                if getattr(parsed, "source", None) == "mapped":
-                    mapped[mod] = parsed                # every rank maps the variable itself: nothing to publish
+                if getattr(parsed, "source", None) in ("mapped", "file"):
+                    mapped[mod] = parsed                # every rank reads / maps the variable itself: nothing to publish
                     return "", n_snr, n_frames
                 path = _publish_container(parsed, n_snr, n_frames, N, threads)
                 published.append(path)
                 return str(path), n_snr, n_frames
 
             def decode_locally(mod):                    # ranks on different hosts: as the reference's children do
-                parsed = _load_variable(mat_path, cfg.signals.mat_info[mod])
+                parsed = _load_variable(mat_path, cfg.signals.mat_info[mod], None, direct)
                 n_snr, n_frames, _ = _check_container(parsed, cfg)
                 return parsed, n_snr, n_frames
 
@@ -586,7 +686,7 @@ def run_extraction(cfg: Config, *, compute=None, device: Optional[int] = None, v
                     else:                               # mapped straight from the container, by every rank
                         parsed = mapped.pop(mod, None) if rank == 0 else None
                         if parsed is None:
-                            parsed = _load_variable(mat_path, key)
+                            parsed = _load_variable(mat_path, key, None, direct)
                         _check_container(parsed, cfg)
                     F = n_snr * n_frames
                     lo, hi = shard_range(F, rank, world)

@@ -165,12 +165,8 @@ def _peek(comp: memoryview) -> Tuple[Optional[str], int]:
         return None, 0
 
 
-def read_variable_v5(path, key: str, pool: Optional[BufferPool] = None):
-    """The variable ``key`` of a little-endian level-5 MAT file: ``(real, imag, how)`` with Fortran-ordered
-    float32 / float64 arrays (``imag`` None for a real variable) that are views of the file's memory mapping
-    (``how == "mapped"``), of its inflated bytes for a compressed variable (``"inflated"``), or -- with a ``pool`` --
-    arrays from the pool that the data was read into with ``preadv`` (``"read"``; uncompressed variables only).
-    Raises ``_Unsupported`` for what the module docstring lists, ``KeyError`` if there is no such variable."""
+def _open_v5(path):
+    """(memory mapping, size) of a little-endian level-5 file, or ``_Unsupported``."""
     with open(path, "rb") as fh:
         size = fh.seek(0, 2)
         if size < 136:
@@ -179,6 +175,12 @@ def read_variable_v5(path, key: str, pool: Optional[BufferPool] = None):
     head = mm[:128]
     if head[:10] != b"MATLAB 5.0" or head[126:128] != b"IM":
         raise _Unsupported("not a little-endian level-5 file")
+    return mm, size
+
+
+def _find(mm, size: int, key: str, path):
+    """Walk the top-level elements for the variable ``key``: ``("matrix", class, is_complex, dims, data offset, end)``
+    for a plain miMATRIX element, ``("compressed", offset, byte count, inflated size)`` for a compressed one."""
     pos = 128
     while pos + 8 <= size:
         t, n, d, nxt = _tag(mm, pos)
@@ -186,39 +188,69 @@ def read_variable_v5(path, key: str, pool: Optional[BufferPool] = None):
             nxt = d + n                                         # compressed elements are not padded
             name, inflated = _peek(memoryview(mm)[d:d + n])
             if name == key:
-                # one allocation of the final size instead of a buffer that doubles its way up (zlib releases the GIL:
-                # run_extraction inflates the next variables on reader threads meanwhile)
-                body = zlib.decompress(memoryview(mm)[d:d + n], zlib.MAX_WBITS, max(inflated, 1 << 16))
-                t2, n2, d2, _ = _tag(body, 0)
-                if t2 != MI_MATRIX:
-                    raise _Unsupported("compressed element is not a matrix")
-                cls, cplx, dims, _, data_pos = _matrix_header(body, d2, d2 + n2)
-                if cls not in (MX_DOUBLE, MX_SINGLE):
-                    raise _Unsupported(f"array class {cls}")
-                return _numeric_parts(body, data_pos, d2 + n2, dims, cplx) + ("inflated",)
+                return "compressed", d, n, inflated
         elif t == MI_MATRIX and n >= 48:
             cls, cplx, dims, name, data_pos = _matrix_header(mm, d, d + n)
             if name == key:
-                if cls not in (MX_DOUBLE, MX_SINGLE):
-                    raise _Unsupported(f"array class {cls}")
-                if pool is not None:                            # read it instead of mapping it
-                    dt, count, d_re, d_im = _numeric_layout(mm, data_pos, dims, cplx)
-                    real = pool.take(dt, count)
-                    imag = pool.take(dt, count) if d_im is not None else None
-                    jobs = [(real.view(np.uint8), d_re)] + ([(imag.view(np.uint8), d_im)] if imag is not None else [])
-                    try:
-                        _pread_into(path, jobs)
-                    except BaseException:
-                        pool.give(real)
-                        if imag is not None:
-                            pool.give(imag)
-                        raise
-                    return (real.reshape(dims, order="F"), None if imag is None else imag.reshape(dims, order="F"), "read")
-                return _numeric_parts(mm, data_pos, d + n, dims, cplx) + ("mapped",)
+                return "matrix", cls, cplx, dims, data_pos, d + n
         if nxt <= pos:
             raise _Unsupported("corrupt element tag")
         pos = nxt
     raise KeyError(f"{path} has no variable {key!r}")
+
+
+def locate_variable_v5(path, key: str):
+    """Where the variable ``key`` lies in a little-endian level-5 MAT file, without touching its data:
+    ``(storage dtype, dims, byte offset of the real array, byte offset of the imaginary array or None)`` -- both
+    arrays column-major.  ``_Unsupported`` for a compressed or non-float variable, ``KeyError`` if there is none."""
+    mm, size = _open_v5(path)
+    found = _find(mm, size, key, path)
+    if found[0] != "matrix":
+        raise _Unsupported("compressed variable")
+    _, cls, cplx, dims, data_pos, _ = found
+    if cls not in (MX_DOUBLE, MX_SINGLE):
+        raise _Unsupported(f"array class {cls}")
+    dt, _, d_re, d_im = _numeric_layout(mm, data_pos, dims, cplx)
+    return dt, tuple(int(x) for x in dims), d_re, d_im
+
+
+def read_variable_v5(path, key: str, pool: Optional[BufferPool] = None):
+    """The variable ``key`` of a little-endian level-5 MAT file: ``(real, imag, how)`` with Fortran-ordered
+    float32 / float64 arrays (``imag`` None for a real variable) that are views of the file's memory mapping
+    (``how == "mapped"``), of its inflated bytes for a compressed variable (``"inflated"``), or -- with a ``pool`` --
+    arrays from the pool that the data was read into with ``preadv`` (``"read"``; uncompressed variables only).
+    Raises ``_Unsupported`` for what the module docstring lists, ``KeyError`` if there is no such variable."""
+    mm, size = _open_v5(path)
+    found = _find(mm, size, key, path)
+    if found[0] == "compressed":
+        _, d, n, inflated = found
+        # one allocation of the final size instead of a buffer that doubles its way up (zlib releases the GIL:
+        # run_extraction inflates the next variables on reader threads meanwhile)
+        body = zlib.decompress(memoryview(mm)[d:d + n], zlib.MAX_WBITS, max(inflated, 1 << 16))
+        t2, n2, d2, _ = _tag(body, 0)
+        if t2 != MI_MATRIX:
+            raise _Unsupported("compressed element is not a matrix")
+        cls, cplx, dims, _, data_pos = _matrix_header(body, d2, d2 + n2)
+        if cls not in (MX_DOUBLE, MX_SINGLE):
+            raise _Unsupported(f"array class {cls}")
+        return _numeric_parts(body, data_pos, d2 + n2, dims, cplx) + ("inflated",)
+    _, cls, cplx, dims, data_pos, end = found
+    if cls not in (MX_DOUBLE, MX_SINGLE):
+        raise _Unsupported(f"array class {cls}")
+    if pool is not None:                            # read it instead of mapping it
+        dt, count, d_re, d_im = _numeric_layout(mm, data_pos, dims, cplx)
+        real = pool.take(dt, count)
+        imag = pool.take(dt, count) if d_im is not None else None
+        jobs = [(real.view(np.uint8), d_re)] + ([(imag.view(np.uint8), d_im)] if imag is not None else [])
+        try:
+            _pread_into(path, jobs)
+        except BaseException:
+            pool.give(real)
+            if imag is not None:
+                pool.give(imag)
+            raise
+        return (real.reshape(dims, order="F"), None if imag is None else imag.reshape(dims, order="F"), "read")
+    return _numeric_parts(mm, data_pos, end, dims, cplx) + ("mapped",)
 
 
 def stores_compressed(mat_path) -> bool:
@@ -234,12 +266,21 @@ def stores_compressed(mat_path) -> bool:
         return False
 
 
-def load_variable(mat_path, key: str, pool: Optional[BufferPool] = None):
-    """One variable of the container: a :class:`SplitComplex` over the memory-mapped file (its ``source``
+def load_variable(mat_path, key: str, pool: Optional[BufferPool] = None, direct: bool = False):
+    """One variable of the container.  ``direct``: a :class:`FileComplex` -- offsets into the file, nothing read;
+    the engine's staging threads read it (``source == "file"``; uncompressed variables only, anything else falls
+    through to the forms below).  Otherwise a :class:`SplitComplex` over the memory-mapped file (its ``source``
     says ``"mapped"``; ``"inflated"`` for a compressed variable; ``"read"`` when a ``pool`` was given and the data
     was read into its buffers -- call ``release()`` on the result when done with it) when the fast reader applies,
     otherwise what ``scipy.io.loadmat`` returns for it."""
-    from .feature_extraction import SplitComplex
+    from .feature_extraction import FileComplex, SplitComplex
+    if direct:
+        try:
+            dt, dims, d_re, d_im = locate_variable_v5(Path(mat_path), key)
+            if len(dims) == 3:
+                return FileComplex(mat_path, dt, dims, d_re, d_im)
+        except (_Unsupported, struct.error, ValueError, zlib.error):
+            pass
     try:
         real, imag, how = read_variable_v5(Path(mat_path), key, pool)
         out = SplitComplex(real, imag)

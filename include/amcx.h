@@ -78,7 +78,8 @@ extern "C" {
  * 2 = strided containers (amcx_ctx_features18_strided_host, amcx_stage_host, amcx_pack_planes_c64,
  * amcx_ctx_configure, amcx_ctx_upload_stats), device-ownership rule below made explicit;
  * 3 = single-read statistics with a caller workspace (amcx_group_stats_ws_f32,
- * amcx_group_stats_workspace_bytes) and amcx_standardize_fit_transform_f32 / _workspace_bytes. */
+ * amcx_group_stats_workspace_bytes), amcx_standardize_fit_transform_f32 / _workspace_bytes, and containers
+ * read straight from their file (amcx_ctx_features18_strided_file, amcx_stage_file, AMCX_EIO). */
 #define AMCX_ABI_VERSION 3
 #define AMCX_NUM_FEATURES 18
 
@@ -89,6 +90,8 @@ extern "C" {
 #define AMCX_EHIP (-3)     /* HIP runtime / launch failure (see amcx_last_hip_error) */
 #define AMCX_ENODEV (-4)   /* no usable gfx950 device */
 #define AMCX_ENOMEM (-5)   /* device allocation failed (host-buffer entry point only) */
+#define AMCX_EIO (-6)      /* a read from the container's file failed or the file ends inside the variable
+                              (the *_file entries; amcx_last_hip_error() holds the errno text) */
 
 /* kernel variants (amcx_features18_c64_ex) */
 #define AMCX_VARIANT_AUTO 0     /* fastest kernel that supports frame_size */
@@ -233,6 +236,26 @@ int amcx_stage_host(const void* re, const void* im, int32_t kind, int64_t n_snr,
                     int32_t* plane_major, int32_t* inner_snr);
 
 /*
+ * The same two entries for a container that is still in its FILE: fd is an open descriptor (the library
+ * neither closes nor seeks it: every read is a pread), re_offset / im_offset the byte offsets of the arrays
+ * that `re` / `im` would point to (im_offset < 0: no imaginary part; ignored for the interleaved kinds);
+ * strides stay in elements.  A MATLAB level-5 variable that is not compressed is exactly this: two column-major
+ * arrays at fixed offsets (amcpy_amd/matfile.py locates them), so all_modulations.mat goes from the page cache
+ * to the pinned slots through 256 KB of per-thread scratch -- without the page faults of a mapping (30 ms per
+ * 436 MB variable however many threads fault) and without a host copy of the variable.  Replaces
+ * scipy.io.loadmat + the slicing of feature_extraction.py:46-48,64-72.  AMCX_EIO if a read fails or the file
+ * is shorter than the strides say (nothing is left in flight; the output is not written).
+ */
+int amcx_ctx_features18_strided_file(amcx_ctx* ctx, int32_t fd, int64_t re_offset, int64_t im_offset,
+                                     int32_t kind, int64_t n_snr, int64_t n_frames, int32_t frame_size,
+                                     int64_t stride_snr, int64_t stride_frame, int64_t stride_sample,
+                                     float* out_host, int64_t out_row_stride, int32_t variant);
+int amcx_stage_file(int32_t fd, int64_t re_offset, int64_t im_offset, int32_t kind, int64_t n_snr,
+                    int64_t n_frames, int32_t frame_size, int64_t stride_snr, int64_t stride_frame,
+                    int64_t stride_sample, int64_t first_unit, int64_t n_units, void* dst, int64_t dst_bytes,
+                    int32_t threads, int32_t* plane_major, int32_t* inner_snr);
+
+/*
  * Tuning of a context's upload path: threads = staging threads including the caller's (0 = keep;
  * default min(8, hardware threads); the reference's SignalConfig.num_threads maps here),
  * slot_bytes = size of one pinned staging slot (0 = keep; default 32 MiB; three are allocated),
@@ -249,7 +272,7 @@ typedef struct amcx_upload_stats {
   int32_t chunks;
   int32_t threads;
   int32_t plane_major;      /* 1: planes + device transposition, 0: rows */
-  int32_t reserved;
+  int32_t from_file;       /* 1: the source was a file read by the staging threads (version 3; `reserved`, always 0, before) */
   double seconds;           /* whole call */
   double seconds_staging;   /* caller thread inside the staging copies */
   double seconds_waiting;   /* caller thread blocked on a pinned slot still being uploaded */

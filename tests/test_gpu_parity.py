@@ -1137,3 +1137,58 @@ def test_reference_side_ctypes_stub_from_integration_md():
     """)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "STUB_OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_engine_reads_the_container_from_its_file(tmp_path):
+    """amcx_ctx_features18_strided_file: the variable of an uncompressed level-5 .mat staged from the FILE by the
+    engine's threads gives bit-identical features to the array loadmat returns for it (whole container, a
+    sub-rectangle with fewer snr rows / frames / samples than stored, a frame range of a shard); run_extraction
+    writes the same files whichever way it reads; a file cut short is an OSError that leaves the engine usable."""
+    import scipy.io
+    from amcpy_amd.config import Config, Paths, SignalConfig
+    from amcpy_amd.feature_extraction import FileComplex, FrameRows, HipEngine, run_extraction
+    from amcpy_amd.matfile import load_variable
+    rng = np.random.default_rng(31)
+    S, K, L, N = 5, 400, 1100, 1024        # planes of 16 KB: long enough runs for the file path
+    cfg = Config(paths=Paths(root=tmp_path), signals=SignalConfig(snr_values={i: str(i) for i in range(S)}, num_frames=K,
+                                                                  frame_size=N, modulations_with_noise=("BPSK", "QPSK")))
+    cfg.paths.ensure_dirs()
+    mats = {cfg.signals.mat_info[m]: np.asfortranarray(rng.standard_normal((S, K, L)) + 1j * rng.standard_normal((S, K, L)))
+            for m in cfg.signals.modulations_with_noise}
+    path = cfg.paths.mat_data / cfg.paths.mat_filename
+    scipy.io.savemat(str(path), mats)
+    key = cfg.signals.mat_info["QPSK"]
+    loaded = scipy.io.loadmat(str(path))[key]
+    fx = load_variable(path, key, direct=True)
+    assert isinstance(fx, FileComplex)
+    eng = HipEngine(N, threads=4, chunk_bytes=1 << 20)              # several chunks
+    # whole container: planes read from the file; fewer snr rows / a shard's frame range / one snr row leave runs of
+    # a few elements, which go through the mapping instead
+    for (s, k, lo, hi, from_file) in [(S, K, 0, None, 1), (3, 50, 0, None, 0), (S, K, 37, 1290, 0), (1, K, 0, None, 0)]:
+        a = eng(FrameRows(loaded, s, k, lo, hi))
+        assert eng.stats["from_file"] == 0
+        b = eng(FrameRows(fx, s, k, lo, hi))
+        assert eng.stats["from_file"] == from_file, (s, k, lo, hi, eng.stats)
+        assert np.array_equal(a, b, equal_nan=True), (s, k, lo, hi)
+    want = orc.features18_batch(loaded[:S, :K, :N].reshape(-1, N).astype(np.complex64))
+    _assert_parity(eng(FrameRows(fx, S, K)), want, loaded[:S, :K, :N].reshape(-1, N), "file engine")
+    # run_extraction: direct (default) against the python-side readers
+    run_extraction(cfg, verbose=False)
+    first = {m: scipy.io.loadmat(str(cfg.paths.calculated_features / f"{m}_features.mat"))[cfg.signals.mat_info[m]]
+             for m in cfg.signals.modulations_with_noise}
+    os.environ["AMCX_DIRECT_FILE"] = "0"
+    try:
+        run_extraction(cfg, verbose=False)
+    finally:
+        del os.environ["AMCX_DIRECT_FILE"]
+    for m, f in first.items():
+        again = scipy.io.loadmat(str(cfg.paths.calculated_features / f"{m}_features.mat"))[cfg.signals.mat_info[m]]
+        assert f.shape == (S, K, 18) and np.array_equal(f, again, equal_nan=True), m
+    # a file that ends inside the variable
+    cut = tmp_path / "cut.mat"
+    cut.write_bytes(path.read_bytes()[:fx.imag_offset + 4096])
+    broken = FileComplex(cut, fx.store, fx.shape, fx.real_offset, fx.imag_offset)
+    with pytest.raises(OSError):
+        eng(FrameRows(broken, S, K))
+    assert np.array_equal(eng(FrameRows(fx, S, K)), eng(FrameRows(loaded, S, K)), equal_nan=True)
+    eng.close()

@@ -317,9 +317,9 @@ _EXTRACT_WORKER = textwrap.dedent('''
     dist.init_process_group("gloo", rank=rank, world_size=world)
     loads = []
     real_load = fe._load_variable
-    def counting_load(path, key):
+    def counting_load(path, key, *more):
         loads.append(key)
-        return real_load(path, key)
+        return real_load(path, key, *more)
     fe._load_variable = counting_load
     seen = []
     def compute(block):                       # stand-in engine: per-row checksum
@@ -771,3 +771,117 @@ def test_eight_rank_run_extraction_over_gloo(tmp_path):
         b = scipy.io.loadmat(str(cfg.paths.calculated_features / f"{m}_features.mat"))
         key = cfg.signals.mat_info[m]
         assert b[key].shape == (3, 7, 18) and np.array_equal(a[key], b[key])
+
+
+def _stage_file(path, re_off, im_off, kind, S, K, N, strides, first, count, threads=3):
+    import ctypes as C
+    import os
+    from amcpy_amd import _lib
+    lib = _lib.load()
+    pm, inner = C.c_int32(-1), C.c_int32(-1)
+    fd = os.open(str(path), os.O_RDONLY)
+    try:
+        _lib.check(lib.amcx_stage_file(fd, re_off, -1 if im_off is None else im_off, kind, S, K, N, *strides, 0, 0, None, 0,
+                                       threads, C.byref(pm), C.byref(inner)))
+        unit = S * K if pm.value else N
+        dst = np.full((count, unit), np.nan + 1j * np.nan, dtype=np.complex64)
+        _lib.check(lib.amcx_stage_file(fd, re_off, -1 if im_off is None else im_off, kind, S, K, N, *strides, first, count,
+                                       dst.ctypes.data, dst.nbytes, threads, C.byref(pm), C.byref(inner)))
+    finally:
+        os.close(fd)
+    return dst, pm.value, inner.value
+
+
+def test_native_staging_from_a_file_equals_staging_from_memory(tmp_path):
+    """amcx_stage_file (the host half of amcx_ctx_features18_strided_file; no GPU): the same containers as bytes in a
+    file at odd offsets -- column-major split doubles as a level-5 .mat keeps them, split singles, interleaved
+    complex64 / complex128 in both orders, real-only, blocks longer than the per-thread scratch -- staged by pread
+    are bit-identical to staging the arrays from memory; a file that ends inside the variable is AMCX_EIO (OSError)."""
+    from amcpy_amd import _lib
+    rng = np.random.default_rng(21)
+    es = lambda a: [st // a.itemsize for st in a.strides]
+    for case, (S, K, N) in enumerate([(3, 33, 256), (1, 7, 64), (26, 40, 128), (2, 9000, 16)]):   # 18 000-element planes > one scratch block
+        full = rng.standard_normal((S, K, N)) * 1e3 + 1j * rng.standard_normal((S, K, N))
+        re, im = np.asfortranarray(full.real), np.asfortranarray(full.imag)
+        path = tmp_path / f"c{case}.bin"
+        pad_a, pad_b = 8 * int(rng.integers(1, 9)), 8 * int(rng.integers(0, 5))
+        with open(path, "wb") as fh:
+            fh.write(b"\x5a" * pad_a); fh.write(re.tobytes(order="F")); fh.write(b"\xa5" * pad_b); fh.write(im.tobytes(order="F"))
+            off32 = fh.tell()
+            fh.write(re.astype(np.float32).tobytes(order="F")); fh.write(im.astype(np.float32).tobytes(order="F"))
+            off_c = fh.tell()
+            fh.write(np.asfortranarray(full).tobytes(order="F"))
+            off_rows = fh.tell()
+            fh.write(full.astype(np.complex64).tobytes(order="C"))
+        d_im = pad_a + re.nbytes + pad_b
+        first, count = int(rng.integers(0, N - 1)), int(rng.integers(1, 6))
+        count = min(count, N - first)
+        for threads in (1, 4):
+            want, pm, inner = _stage(re, im, _lib.SRC_F64_SPLIT, S, K, N, es(re), first, count, threads)
+            got, pm2, inner2 = _stage_file(path, pad_a, d_im, _lib.SRC_F64_SPLIT, S, K, N, es(re), first, count, threads)
+            assert (pm, inner) == (pm2, inner2) and np.array_equal(got, want), (case, threads)
+        want, _, _ = _stage(re, None, _lib.SRC_F64_SPLIT, S, K, N, es(re), first, count)
+        got, _, _ = _stage_file(path, pad_a, None, _lib.SRC_F64_SPLIT, S, K, N, es(re), first, count)
+        assert np.array_equal(got, want)
+        re32, im32 = np.asfortranarray(re.astype(np.float32)), np.asfortranarray(im.astype(np.float32))
+        want, _, _ = _stage(re32, im32, _lib.SRC_F32_SPLIT, S, K, N, es(re32), first, count)
+        got, _, _ = _stage_file(path, off32, off32 + re32.nbytes, _lib.SRC_F32_SPLIT, S, K, N, es(re32), first, count)
+        assert np.array_equal(got, want)
+        fc = np.asfortranarray(full)
+        want, _, _ = _stage(fc, None, _lib.SRC_C128, S, K, N, es(fc), first, count)
+        got, _, _ = _stage_file(path, off_c, None, _lib.SRC_C128, S, K, N, es(fc), first, count)
+        assert np.array_equal(got, want)
+        rows = np.ascontiguousarray(full.astype(np.complex64))
+        f0 = int(rng.integers(0, S * K - 1))
+        want, pm, _ = _stage(rows, None, _lib.SRC_C64, S, K, N, es(rows), f0, min(5, S * K - f0))
+        got, pm2, _ = _stage_file(path, off_rows, None, _lib.SRC_C64, S, K, N, es(rows), f0, min(5, S * K - f0))
+        assert pm == pm2 == 0 and np.array_equal(got, want)
+        # the file ends inside the imaginary array
+        short = tmp_path / f"short{case}.bin"
+        short.write_bytes(path.read_bytes()[:d_im + im.nbytes // 2])
+        with pytest.raises(OSError):
+            _stage_file(short, pad_a, d_im, _lib.SRC_F64_SPLIT, S, K, N, es(re), 0, N)
+    with pytest.raises(ValueError):
+        _stage_file(path, -8, None, _lib.SRC_C64, 1, 1, 64, [64, 64, 1], 0, 1)
+
+
+def test_mat_variables_located_in_the_file(tmp_path):
+    """load_variable(direct=True): an uncompressed variable comes back as offsets into the file (FileComplex) whose
+    indexing equals loadmat's array and whose staging from the file equals staging loadmat's array from memory; a
+    compressed or integer variable falls through to the other readers."""
+    import scipy.io
+    from amcpy_amd import _lib
+    from amcpy_amd.feature_extraction import FileComplex, FrameRows, _native_source
+    from amcpy_amd.matfile import load_variable
+    rng = np.random.default_rng(8)
+    shape = (4, 30, 160)
+    x = np.asfortranarray(rng.standard_normal(shape) + 1j * rng.standard_normal(shape))
+    r = np.asfortranarray(rng.standard_normal(shape).astype(np.float32))
+    path = tmp_path / "c.mat"
+    scipy.io.savemat(str(path), {"first": np.arange(7.0), "x": x, "r": r, "i8": np.arange(24, dtype=np.int8).reshape(2, 3, 4)})
+    want = scipy.io.loadmat(str(path))
+    fx = load_variable(path, "x", direct=True)
+    assert isinstance(fx, FileComplex) and fx.shape == shape and fx.dtype == np.complex128 and fx.source == "file"
+    assert np.array_equal(fx[1:3, 4:20, :128], want["x"][1:3, 4:20, :128])
+    src = _native_source(fx)
+    assert src[3] == _lib.SRC_F64_SPLIT and src[4] == [1, 4, 120] and src[6] == fx.fileno()
+    S, K, N = 3, 28, 128
+    got, pm, inner = _stage_file(path, src[1], src[2], src[3], S, K, N, src[4], 5, 40)
+    ref, _, _ = _stage(np.asfortranarray(want["x"].real), np.asfortranarray(want["x"].imag), _lib.SRC_F64_SPLIT, S, K, N,
+                       src[4], 5, 40)
+    assert (pm, inner) == (1, 1) and np.array_equal(got, ref)
+    assert np.array_equal(got, want["x"][:S, :K, 5:45].astype(np.complex64).transpose(2, 1, 0).reshape(40, K * S))
+    # the host gather of a FrameRows over it (injected engines, tests) goes through a mapping
+    assert np.array_equal(FrameRows(fx, S, K, 10, 50).to_array()[:, :N], want["x"][:S, :K, :].reshape(S * K, -1)[10:50, :N])
+    fx.release(); fx.release()
+    fr = load_variable(path, "r", direct=True)                 # a real float32 variable: no imaginary array
+    assert isinstance(fr, FileComplex) and fr.imag_offset is None and fr.dtype == np.complex64
+    assert np.array_equal(fr[:, :, :10], want["r"][:, :, :10].astype(np.complex64))
+    assert not isinstance(load_variable(path, "i8", direct=True), FileComplex)       # int8 storage: scipy
+    assert not isinstance(load_variable(path, "first", direct=True), FileComplex)    # not 3-D
+    zpath = tmp_path / "z.mat"
+    scipy.io.savemat(str(zpath), {"x": x}, do_compression=True)
+    z = load_variable(zpath, "x", direct=True)
+    assert not isinstance(z, FileComplex) and z.source == "inflated" and np.array_equal(z[:2, :5, :9], x[:2, :5, :9])
+    with pytest.raises(KeyError):
+        load_variable(path, "absent", direct=True)

@@ -32,12 +32,14 @@ with tempfile.TemporaryDirectory(dir="/dev/shm" if Path("/dev/shm").is_dir() els
     eng = HipEngine(2048, threads=8)
     from amcpy_amd.matfile import BufferPool
     pool = BufferPool()
-    for rep in range(3):
-        how = None if rep == 0 else pool                  # first round: memory-mapped; then: preadv into reused buffers
-        print("--- variables", "memory-mapped" if how is None else "read with preadv into a buffer pool")
+    for rep in range(5):
+        how = None if rep == 0 else pool                  # first round: memory-mapped; then: preadv into reused buffers; then: located only
+        direct = rep >= 3
+        print("--- variables", "located in the file, read by the engine's staging threads" if direct else
+              "memory-mapped" if how is None else "read with preadv into a buffer pool")
         for m in synth.MODS6:
             key = cfg.signals.mat_info[m]
-            t0 = time.perf_counter(); v = _load_variable(path, key, how); t1 = time.perf_counter()
+            t0 = time.perf_counter(); v = _load_variable(path, key, how, direct); t1 = time.perf_counter()
             feats = eng(FrameRows(v, 26, 512)); t2 = time.perf_counter()
             scipy.io.savemat(str(cfg.paths.calculated_features / f"{m}_features.mat"), {"Modulation": m, key: feats.reshape(26, 512, 18)})
             t3 = time.perf_counter()
