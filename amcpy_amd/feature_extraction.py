@@ -54,7 +54,7 @@ import numpy as np
 
 from . import _lib
 from .config import Config
-from .sharding import gather_rows, shard_range, sharded_features
+from .sharding import gather_frame_columns, gather_rows, shard_by_frames, shard_range, sharded_features
 
 
 def _rank_world():
@@ -208,6 +208,32 @@ class FrameRows:
         out = np.empty(self.shape, dtype=self.dtype)
         self.gather(out, 0, self.shape[0], self.shape[1])
         return out
+
+
+class FrameColumns(FrameRows):
+    """Frames ``[k_lo, k_hi)`` of EVERY snr row of ``parsed[:n_snr, :n_frames]``, snr-major (row
+    ``s * (k_hi - k_lo) + (k - k_lo)``): a rank's share when a container is cut along its frame axis
+    (``sharding.shard_by_frames``).  In a column-major container that is one contiguous run of every sample
+    plane -- what the staging threads read from the file or copy at full rate."""
+
+    def __init__(self, parsed, n_snr: int, n_frames: int, k_lo: int, k_hi: int):
+        super().__init__(parsed, n_snr, n_frames, 0, n_snr * max(0, k_hi - k_lo))
+        self.k_lo, self.k_hi = k_lo, max(k_lo, k_hi)
+
+    def slice(self, lo: int, hi: int) -> "FrameRows":
+        if (lo, hi) != (0, self.hi):
+            raise NotImplementedError("a frame-axis share is taken whole")
+        return self
+
+    def blocks(self) -> Iterator[Tuple[int, int, int, int]]:
+        if self.k_hi > self.k_lo and self.n_snr:
+            yield 0, self.n_snr, self.k_lo, self.k_hi
+
+    def gather(self, dst: np.ndarray, g0: int, g1: int, n: int) -> None:
+        w = self.k_hi - self.k_lo
+        for g in range(g0, g1):                           # host copy: tests and injected engines only
+            s, k = divmod(g, w)
+            np.copyto(dst[g - g0], self.parsed[s, self.k_lo + k, :n], casting="same_kind")
 
 
 def _native_source(arr):
@@ -677,7 +703,7 @@ def run_extraction(cfg: Config, *, compute=None, device: Optional[int] = None, v
                     if status != "ok":
                         raise RuntimeError(f"rank 0 could not read {key!r} from {mat_path}: {shared}")
                 # 2. this rank's frame range; a failure is kept until every rank has reported
-                local, failure = None, None
+                local, failure, by_frames = None, None, False
                 try:
                     if not shared_host:
                         parsed, n_snr, n_frames = fut.result()
@@ -689,8 +715,13 @@ def run_extraction(cfg: Config, *, compute=None, device: Optional[int] = None, v
                             parsed = _load_variable(mat_path, key, None, direct)
                         _check_container(parsed, cfg)
                     F = n_snr * n_frames
-                    lo, hi = shard_range(F, rank, world)
-                    local = run(FrameRows(parsed, n_snr, n_frames, lo, hi))
+                    by_frames = shard_by_frames(n_snr, n_frames, world)     # the same answer on every rank
+                    if by_frames:
+                        k_lo, k_hi = shard_range(n_frames, rank, world)
+                        local = run(FrameColumns(parsed, n_snr, n_frames, k_lo, k_hi))
+                    else:
+                        lo, hi = shard_range(F, rank, world)
+                        local = run(FrameRows(parsed, n_snr, n_frames, lo, hi))
                 except Exception as exc:
                     failure = f"{type(exc).__name__}: {exc}"
                 del parsed
@@ -705,7 +736,8 @@ def run_extraction(cfg: Config, *, compute=None, device: Optional[int] = None, v
                 if bad:
                     raise RuntimeError(f"feature extraction of {mod!r} failed on " +
                                        "; ".join(f"rank {r}: {s}" for r, s in bad))
-                mat = gather_rows(local, F, rank, world)
+                mat = gather_frame_columns(local, n_snr, n_frames, rank, world) if by_frames else \
+                    gather_rows(local, F, rank, world)
                 if rank == 0:
                     writes.append(writer.submit(save, mod, key, mat.reshape(n_snr, n_frames, 18), t0))
         for w in writes:

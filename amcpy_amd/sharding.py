@@ -4,8 +4,11 @@ Every frame is independent (reference feature_extraction.py:64-72 enqueues
 each (snr, frame) on its own), so the flattened frame index g in [0, F) is cut
 into contiguous blocks, rank r of W taking
 ``[r*ceil(F/W), min(F, (r+1)*ceil(F/W)))``: contiguous in memory, never
-splitting a frame, and with no collective on the data path.  The only
-cross-rank step is gathering the tiny (F x 18) float32 result on rank 0.
+splitting a frame, and with no collective on the data path.  A container that
+is still in a .mat (column-major: snr the fastest axis) is cut along its FRAME
+axis instead when that balances as well (:func:`shard_by_frames`): a rank's share
+is then one contiguous run of every sample plane.  The only cross-rank step
+is gathering the tiny (F x 18) float32 result on rank 0.
 """
 from __future__ import annotations
 
@@ -25,36 +28,73 @@ def shard_range(n_frames: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, min(n_frames, lo + per)
 
 
-def gather_rows(local: np.ndarray, n_frames: int, rank: int, world: int, group=None) -> Optional[np.ndarray]:
-    """Collect every rank's (n_local, 18) block on rank 0 as (n_frames, 18).
+def shard_by_frames(n_snr: int, n_frames: int, world: int) -> bool:
+    """How a container of (n_snr, n_frames) frames is cut over ``world`` ranks: True -- every rank takes the frames
+    ``shard_range(n_frames, rank, world)`` of EVERY snr row -- when that is as balanced (within 1/8) as cutting the
+    snr-major flattening, False for the flattening.  A column-major container (what a .mat holds: snr the fastest
+    axis) keeps a rank's frame range of all snr rows as ONE contiguous run per sample plane, which the staging
+    threads read or copy at full rate; a range of the flattening leaves it n_snr / world elements per run."""
+    if world <= 1 or n_frames < world:
+        return False
+    by_k = n_snr * (-(-n_frames // world))
+    by_g = -(-(n_snr * n_frames) // world)
+    return 8 * by_k <= 9 * by_g
 
-    One ``torch.distributed.gather`` of float32 tensors, each rank's block padded to the common
-    ``ceil(F / W)`` rows -- a plain copy (92 MB per rank at BASELINE configs[3]), not a pickle -- on
-    whatever backend the caller initialised: device tensors over RCCL for GPU jobs, host tensors
-    over gloo in the CPU tests.  Returns the full matrix on rank 0 and None elsewhere."""
+
+def gather_blocks(local: np.ndarray, counts, rank: int, world: int, group=None):
+    """Collect every rank's (counts[r], C) float32 block on rank 0: a list of the ``world`` blocks there, None
+    elsewhere.  One ``torch.distributed.gather`` of tensors padded to ``max(counts)`` rows -- a plain copy (92 MB
+    per rank at BASELINE configs[3]), not a pickle -- on whatever backend the caller initialised: device tensors
+    over RCCL for GPU jobs, host tensors over gloo in the CPU tests."""
+    counts = [int(c) for c in counts]
+    if len(counts) != world or local.shape[0] != counts[rank]:
+        raise RuntimeError(f"rank {rank} holds {local.shape[0]} rows, expected {counts}")
     if world == 1:
-        return local
+        return [local]
     import torch
     import torch.distributed as dist
     cols = local.shape[1]
-    per = -(-n_frames // world) if n_frames else 0
-    lo, hi = shard_range(n_frames, rank, world)
-    if local.shape[0] != hi - lo:
-        raise RuntimeError(f"rank {rank} holds {local.shape[0]} rows for [{lo}, {hi})")
+    per = max(counts)
     on_gpu = "nccl" in str(dist.get_backend(group)).lower()
     dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
     mine = torch.zeros((per, cols), dtype=torch.float32, device=dev)
-    if hi > lo:
-        mine[:hi - lo].copy_(torch.from_numpy(np.ascontiguousarray(local, dtype=np.float32)))
+    if counts[rank]:
+        mine[:counts[rank]].copy_(torch.from_numpy(np.ascontiguousarray(local, dtype=np.float32)))
     parts = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
     dist.gather(mine, parts, dst=0, group=group)
     if rank != 0:
         return None
-    out = np.empty((n_frames, cols), dtype=np.float32)
-    for r, blk in enumerate(parts):
-        a, b = shard_range(n_frames, r, world)
-        if b > a:
-            out[a:b] = blk[:b - a].cpu().numpy()
+    return [blk[:counts[r]].cpu().numpy() for r, blk in enumerate(parts)]
+
+
+def gather_rows(local: np.ndarray, n_frames: int, rank: int, world: int, group=None) -> Optional[np.ndarray]:
+    """Collect every rank's (n_local, 18) block of the contiguous cut (:func:`shard_range`) on rank 0 as
+    (n_frames, 18): :func:`gather_blocks` + concatenation.  Returns the full matrix on rank 0 and None elsewhere."""
+    if world == 1:
+        return local
+    ranges = [shard_range(n_frames, r, world) for r in range(world)]
+    lo, hi = ranges[rank]
+    if local.shape[0] != hi - lo:
+        raise RuntimeError(f"rank {rank} holds {local.shape[0]} rows for [{lo}, {hi})")
+    blocks = gather_blocks(local, [b - a for a, b in ranges], rank, world, group)
+    if blocks is None:
+        return None
+    out = np.empty((n_frames, local.shape[1]), dtype=np.float32)
+    for (a, b), blk in zip(ranges, blocks):
+        out[a:b] = blk
+    return out
+
+
+def gather_frame_columns(local: np.ndarray, n_snr: int, n_frames: int, rank: int, world: int, group=None):
+    """The frame-axis cut (:func:`shard_by_frames`): rank r holds the (n_snr * K_r, C) rows of frames
+    ``shard_range(n_frames, r, world)`` of every snr row, snr-major; rank 0 gets (n_snr, n_frames, C), others None."""
+    ranges = [shard_range(n_frames, r, world) for r in range(world)]
+    blocks = gather_blocks(local, [n_snr * (b - a) for a, b in ranges], rank, world, group)
+    if blocks is None:
+        return None
+    out = np.empty((n_snr, n_frames, local.shape[1]), dtype=np.float32)
+    for (a, b), blk in zip(ranges, blocks):
+        out[:, a:b] = blk.reshape(n_snr, b - a, -1)
     return out
 
 

@@ -330,10 +330,11 @@ _EXTRACT_WORKER = textwrap.dedent('''
                  signals=SignalConfig(snr_values={0: "0", 1: "10", 2: "20"}, num_frames=7, frame_size=16))
     fe.run_extraction(cfg, compute=compute, verbose=False)
     # a compressed container: rank 0 alone decodes it (and publishes); an uncompressed one is mapped by every
-    # rank for itself; either way every rank computes only its contiguous share
+    # rank for itself; either way every rank computes only its share -- 3 snr rows x 7 frames over two ranks are cut
+    # along the frame axis (sharding.shard_by_frames): frames 0-3 and 4-6 of every snr row
     direct = os.environ["AMCX_MODE"] == "direct"
     assert len(loads) == (6 if rank == 0 or direct else 0), (rank, loads)
-    assert all(s[1] == (20 if direct else 16) for s in seen) and sum(s[0] for s in seen) in (6 * 11, 6 * 10), seen
+    assert all(s[1] == (20 if direct else 16) for s in seen) and sum(s[0] for s in seen) == 6 * (12, 9)[rank], seen
     print("EXTRACT_OK", rank, len(loads), sum(s[0] for s in seen))
     dist.destroy_process_group()
 ''')
@@ -376,7 +377,7 @@ def test_two_rank_run_extraction_rank0_decodes_and_publishes(tmp_path, mode):
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=180)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
-    assert "EXTRACT_OK 0 6 66" in outs[0] and f"EXTRACT_OK 1 {6 if mode == 'direct' else 0} 60" in outs[1], outs
+    assert "EXTRACT_OK 0 6 72" in outs[0] and f"EXTRACT_OK 1 {6 if mode == 'direct' else 0} 54" in outs[1], outs
     assert set(glob.glob(str(fe._shared_dir(0) / "amcx_frames_*"))) == before, "shared frame files left behind"
     for m in cfg.signals.modulations_with_noise:
         a = scipy.io.loadmat(str(cfg1.paths.calculated_features / f"{m}_features.mat"))
@@ -753,8 +754,9 @@ def test_eight_rank_run_extraction_over_gloo(tmp_path):
     fe.run_extraction(cfg1, compute=compute, verbose=False)
     script = tmp_path / "extract_worker8.py"
     script.write_text(_EXTRACT_WORKER.replace(
-        'assert all(s[1] == (20 if direct else 16) for s in seen) and sum(s[0] for s in seen) in (6 * 11, 6 * 10), seen',
+        'assert all(s[1] == (20 if direct else 16) for s in seen) and sum(s[0] for s in seen) == 6 * (12, 9)[rank], seen',
         'assert sum(s[0] for s in seen) == (0 if rank == 7 else 6 * 3), (rank, seen)'))
+    assert "6 * 3" in script.read_text()            # seven frames per snr row over eight ranks: the flattening is cut
     port = _free_port()
     procs = []
     for r in range(8):
@@ -885,3 +887,37 @@ def test_mat_variables_located_in_the_file(tmp_path):
     assert not isinstance(z, FileComplex) and z.source == "inflated" and np.array_equal(z[:2, :5, :9], x[:2, :5, :9])
     with pytest.raises(KeyError):
         load_variable(path, "absent", direct=True)
+
+
+def test_frame_axis_cut_of_a_container():
+    """sharding.shard_by_frames / FrameColumns / gather_frame_columns (world 1 semantics here; two ranks in
+    test_two_rank_run_extraction_*): the cut is chosen when it balances within 1/8 of the flattening's, a rank's
+    share is the frames [k_lo, k_hi) of every snr row in snr-major order, and the shares tile the container."""
+    from amcpy_amd.feature_extraction import FrameColumns
+    from amcpy_amd.sharding import gather_frame_columns, shard_by_frames, shard_range
+    assert shard_by_frames(26, 4096, 8) and shard_by_frames(26, 512, 8) and shard_by_frames(3, 7, 2)
+    assert not shard_by_frames(3, 7, 8)            # fewer frames per row than ranks
+    assert not shard_by_frames(26, 9, 8)           # 26 * 2 = 52 frames on the busiest rank against 30: the flattening balances better
+    assert not shard_by_frames(26, 4096, 1)
+    rng = np.random.default_rng(4)
+    S, K, L, N = 3, 11, 20, 16
+    full = np.asfortranarray(rng.standard_normal((S + 1, K + 2, L)) + 1j * rng.standard_normal((S + 1, K + 2, L)))
+    W = 4
+    seen = np.zeros((S, K), dtype=int)
+    parts = []
+    for r in range(W):
+        k_lo, k_hi = shard_range(K, r, W)
+        share = FrameColumns(full, S, K, k_lo, k_hi)
+        assert share.shape == (S * (k_hi - k_lo), L) and list(share.blocks()) == ([(0, S, k_lo, k_hi)] if k_hi > k_lo else [])
+        got = share.to_array()
+        assert np.array_equal(got, full[:S, k_lo:k_hi].reshape(-1, L))
+        sub = np.empty((2, N), dtype=np.complex64)
+        if share.shape[0] >= 3:
+            share.gather(sub, 1, 3, N)
+            assert np.array_equal(sub, got[1:3, :N].astype(np.complex64))
+        seen[:, k_lo:k_hi] += 1
+        parts.append(np.abs(got[:, :4]).astype(np.float32))
+    assert (seen == 1).all()
+    # gather on one rank: the block comes back as (S, K, C)
+    one = gather_frame_columns(np.abs(full[:S, :K, :4]).reshape(-1, 4).astype(np.float32), S, K, 0, 1)
+    assert one.shape == (S, K, 4) and np.array_equal(one, np.abs(full[:S, :K, :4]).astype(np.float32))
