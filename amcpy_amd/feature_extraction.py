@@ -418,6 +418,11 @@ def extract_modulation(parsed: np.ndarray, cfg: Config, *, compute=None, device:
     rows = FrameRows(parsed, n_snr, n_frames)
     if compute is None:
         engine = HipEngine(N, device, threads=cfg.signals.num_threads)
+        if shard_by_frames(n_snr, n_frames, world):          # frames [k_lo, k_hi) of every snr row (sharding.py)
+            k_lo, k_hi = shard_range(n_frames, rank, world)
+            local = engine(FrameColumns(parsed, n_snr, n_frames, k_lo, k_hi)) if k_hi > k_lo else \
+                np.empty((0, 18), dtype=np.float32)
+            return gather_frame_columns(local, n_snr, n_frames, rank, world, group)
         lo, hi = shard_range(n_snr * n_frames, rank, world)
         local = engine(rows.slice(lo, hi)) if hi > lo else np.empty((0, 18), dtype=np.float32)
         mat = gather_rows(local, n_snr * n_frames, rank, world, group)

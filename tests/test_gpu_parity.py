@@ -431,6 +431,21 @@ cfg = Config(paths=Paths(root=Path(os.environ["AMCX_ROOT"])),
                                   frame_size=int(os.environ["AMCX_FS"])))
 run_extraction(cfg, verbose=False)
 dist.barrier()
+# extract_modulation: every rank holds the array; the ranks cut it along the frame axis (or the flattening when
+# there are fewer frames per row than ranks) and rank 0 gets what one process computes
+from amcpy_amd.feature_extraction import FrameRows, HipEngine, extract_modulation
+rng = np.random.default_rng(5)
+for shape, nf in (((2, 9, cfg.signals.frame_size + 3), 9), ((3, 1, cfg.signals.frame_size), 1)):
+    arr = np.asfortranarray(rng.standard_normal(shape) + 1j * rng.standard_normal(shape))
+    c2 = Config(paths=cfg.paths, signals=SignalConfig(snr_values={i: str(i) for i in range(shape[0])}, num_frames=nf,
+                                                      frame_size=cfg.signals.frame_size))
+    got = extract_modulation(arr, c2)
+    if rank == 0:
+        want = HipEngine(cfg.signals.frame_size)(FrameRows(arr, shape[0], nf)).reshape(shape[0], nf, 18)
+        assert got.shape == want.shape and np.array_equal(got, want, equal_nan=True), shape
+    else:
+        assert got is None
+dist.barrier()
 dist.destroy_process_group()
 print("RANK_DONE", rank)
 """
@@ -1112,10 +1127,11 @@ def test_strided_engine_on_random_layouts():
         eng.close()
 
 
-def test_reference_side_ctypes_stub_from_integration_md():
-    """The binding INTEGRATION.md section 2 tells a maintainer of the reference to add -- ctypes and numpy only, no
-    amcpy_amd import -- executed as written (the fenced python blocks of that section, in order) on what loadmat
-    returns: a Fortran-ordered complex128 container with more frames and longer rows than the configuration uses."""
+def test_reference_side_ctypes_stub_from_integration_md(tmp_path):
+    """The binding INTEGRATION.md section 2 tells a maintainer of the reference to add -- ctypes and numpy only (the
+    file form also takes the variable's offsets from amcpy_amd.matfile) -- executed as written (the fenced python
+    blocks of that section, in order) on what loadmat returns: a Fortran-ordered complex128 container with more frames
+    and longer rows than the configuration uses; and on the .mat file itself."""
     import re
     import subprocess
     import sys
@@ -1125,14 +1141,20 @@ def test_reference_side_ctypes_stub_from_integration_md():
     blocks = re.findall(r"```python\n(.*?)```", sec, flags=re.S)
     assert len(blocks) >= 3
     lib = repo / "amcpy_amd" / "lib" / "libamcx.so"
-    code = "\n".join(blocks[:2]).replace('C.CDLL("libamcx.so")', f'C.CDLL({str(lib)!r})')
-    code += textwrap.dedent("""
+    assert "amcx_ctx_features18_strided_file" in blocks[2]
+    code = f"import os, sys\nsys.path.insert(0, {str(repo)!r})\n" + \
+        "\n".join(blocks[:3]).replace('C.CDLL("libamcx.so")', f'C.CDLL({str(lib)!r})')
+    code += textwrap.dedent(f"""
         rng = np.random.default_rng(4)
         full = np.asfortranarray(rng.standard_normal((3, 40, 300)) + 1j * rng.standard_normal((3, 40, 300)))
         got = container_features(full, 2, 33, 256)
         want = features18(full[:2, :33, :256].reshape(66, 256), 256).reshape(2, 33, 18)
         assert got.shape == (2, 33, 18) and got.dtype == np.float32
         assert np.array_equal(got, want, equal_nan=True), np.abs(got - want).max()
+        import scipy.io
+        scipy.io.savemat({str(tmp_path / "c.mat")!r}, {{"other": np.arange(5.0), "signal": full}})
+        from_file = mat_variable_features({str(tmp_path / "c.mat")!r}, "signal", 3, 40, 256)
+        assert np.array_equal(from_file, container_features(full, 3, 40, 256), equal_nan=True)
         print("STUB_OK", float(got[1, 2, 5]))
     """)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
