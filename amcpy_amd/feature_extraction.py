@@ -603,6 +603,29 @@ def _load_variable(mat_path: Path, key: str, pool=None, direct: bool = False):
     return load_variable(mat_path, key, pool, direct)
 
 
+def _read_ahead(inflated_bytes: int, n_variables: int) -> int:
+    """How many variables the reader threads decode ahead of the GPU.  An uncompressed container: 1 (it is only
+    located, or read at link rate).  A compressed one is inflate-bound, one deflate stream per variable, so every
+    variable ahead is a core at work (2.2 / 0.9 / 0.62 s for the 2.6 GB container at 1 / 3 / 6,
+    profiles/r3_extract_ab_readahead.txt): up to six, as many as fit twice over in a quarter of the memory the host
+    has available.  AMCX_READ_AHEAD overrides."""
+    if "AMCX_READ_AHEAD" in os.environ:
+        return max(1, int(os.environ["AMCX_READ_AHEAD"]))
+    if inflated_bytes <= 0:
+        return 1
+    avail = 0
+    try:
+        with open("/proc/meminfo") as fh:
+            for line in fh:
+                if line.startswith("MemAvailable:"):
+                    avail = int(line.split()[1]) * 1024
+                    break
+    except OSError:
+        pass
+    fit = (avail // 4) // (2 * inflated_bytes) if avail else 3
+    return int(max(1, min(6, n_variables, (os.cpu_count() or 2) - 1, fit)))
+
+
 def _same_host(world: int) -> bool:
     import torch.distributed as dist
     hosts = [None] * world
@@ -646,13 +669,13 @@ def run_extraction(cfg: Config, *, compute=None, device: Optional[int] = None, v
     feed = None
     try:
         if world == 1:
-            from .matfile import BufferPool, stores_compressed
+            from .matfile import BufferPool, compressed_variable_bytes
             # A compressed container is inflate-bound: three reader threads run ahead (zlib releases the GIL).  An
             # uncompressed variable is only LOCATED here: the native engine's staging threads read it from the file
             # on their way to the pinned slots.  With an injected engine (tests) it is read with preadv into two
             # pairs of buffers that take turns: reading is faster than first-touching fresh pages, mapped or allocated.
             pool = BufferPool()
-            depth = 3 if stores_compressed(mat_path) else 1
+            depth = _read_ahead(compressed_variable_bytes(mat_path), len(mods))
             feed = _prefetched(mods, lambda m: _load_variable(mat_path, cfg.signals.mat_info[m], pool, direct),
                                depth)
             for mod, fut in feed:

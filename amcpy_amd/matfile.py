@@ -266,6 +266,19 @@ def stores_compressed(mat_path) -> bool:
         return False
 
 
+def compressed_variable_bytes(mat_path) -> int:
+    """Inflated size of the first variable of a level-5 file if it is stored compressed, else 0: what one reader
+    thread of ``run_extraction`` holds while it decodes ahead of the GPU."""
+    if not stores_compressed(mat_path):
+        return 0
+    try:
+        mm, size = _open_v5(mat_path)
+        t, n, d, _ = _tag(mm, 128)
+        return max(1, _peek(memoryview(mm)[d:d + n])[1])
+    except Exception:
+        return 1
+
+
 def load_variable(mat_path, key: str, pool: Optional[BufferPool] = None, direct: bool = False):
     """One variable of the container.  ``direct``: a :class:`FileComplex` -- offsets into the file, nothing read;
     the engine's staging threads read it (``source == "file"``; uncompressed variables only, anything else falls

@@ -921,3 +921,25 @@ def test_frame_axis_cut_of_a_container():
     # gather on one rank: the block comes back as (S, K, C)
     one = gather_frame_columns(np.abs(full[:S, :K, :4]).reshape(-1, 4).astype(np.float32), S, K, 0, 1)
     assert one.shape == (S, K, 4) and np.array_equal(one, np.abs(full[:S, :K, :4]).astype(np.float32))
+
+
+def test_read_ahead_depth_follows_the_container(tmp_path, monkeypatch):
+    """run_extraction's reader threads: one variable ahead for an uncompressed container, up to six (bounded by the
+    variables, the cores and a quarter of the available memory) for a compressed one; AMCX_READ_AHEAD overrides."""
+    import scipy.io
+    from amcpy_amd import feature_extraction as fe
+    from amcpy_amd.matfile import compressed_variable_bytes
+    x = np.asfortranarray(np.random.default_rng(0).standard_normal((2, 30, 64)) + 0j)
+    plain, packed = tmp_path / "p.mat", tmp_path / "z.mat"
+    scipy.io.savemat(str(plain), {"x": x})
+    scipy.io.savemat(str(packed), {"x": x}, do_compression=True)
+    assert compressed_variable_bytes(plain) == 0 and compressed_variable_bytes(tmp_path / "absent.mat") == 0
+    inflated = compressed_variable_bytes(packed)
+    assert 2 * x.real.nbytes <= inflated <= 2 * x.real.nbytes + 256
+    monkeypatch.delenv("AMCX_READ_AHEAD", raising=False)
+    assert fe._read_ahead(0, 6) == 1
+    cores = os.cpu_count() or 2
+    assert fe._read_ahead(inflated, 6) == min(6, cores - 1) and fe._read_ahead(inflated, 2) == min(2, cores - 1)
+    assert fe._read_ahead(1 << 50, 6) == 1                      # a variable that does not fit: one at a time
+    monkeypatch.setenv("AMCX_READ_AHEAD", "4")
+    assert fe._read_ahead(0, 6) == 4

@@ -2,7 +2,8 @@
 """run_extraction on the 2.6 GB uncompressed container (6 x (26, 512, 2048) complex128 in /dev/shm), five times in a
 fresh process per setting of an environment switch: an A/B of host-side choices on one box.
     python tools/extract_ab.py AMCX_DIRECT_FILE 0 1
-    python tools/extract_ab.py AB_THREADS 4 8 12 16        (SignalConfig.num_threads = staging threads)"""
+    python tools/extract_ab.py AB_THREADS 4 8 12 16        (SignalConfig.num_threads = staging threads)
+    python tools/extract_ab.py --compressed AMCX_READ_AHEAD 1 3 6"""
 import os
 import subprocess
 import sys
@@ -30,7 +31,9 @@ import scipy.io
 from amcpy_amd import synth
 from amcpy_amd.config import Config, Paths, SignalConfig
 
-var, values = (sys.argv[1], sys.argv[2:]) if len(sys.argv) > 2 else ("AMCX_HUGEPAGES", ["0", "1"])
+compress = "--compressed" in sys.argv          # MATLAB's default save: every variable one deflate stream
+args = [a for a in sys.argv[1:] if a != "--compressed"]
+var, values = (args[0], args[1:]) if len(args) > 1 else ("AMCX_DIRECT_FILE", ["0", "1"])
 for f in ("enabled", "defrag", "shmem_enabled"):
     p = Path("/sys/kernel/mm/transparent_hugepage") / f
     print(f"transparent_hugepage/{f}: {p.read_text().strip() if p.exists() else 'absent'}")
@@ -40,7 +43,9 @@ with tempfile.TemporaryDirectory(dir="/dev/shm" if Path("/dev/shm").is_dir() els
     cfg = Config(paths=Paths(root=Path(td)),
                  signals=SignalConfig(snr_values={i: str(v) for i, v in enumerate(range(-20, 32, 2))}, num_frames=512))
     cfg.paths.ensure_dirs()
-    scipy.io.savemat(str(cfg.paths.mat_data / cfg.paths.mat_filename), {cfg.signals.mat_info[m]: big[m] for m in synth.MODS6})
+    scipy.io.savemat(str(cfg.paths.mat_data / cfg.paths.mat_filename), {cfg.signals.mat_info[m]: big[m] for m in synth.MODS6},
+                     do_compression=compress)
+    print(f"container: {(cfg.paths.mat_data / cfg.paths.mat_filename).stat().st_size / 1e9:.2f} GB on disk, compressed: {compress}")
     del big
     for rep in range(2):
         for v in values:
