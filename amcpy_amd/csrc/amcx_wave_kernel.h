@@ -242,6 +242,108 @@ __device__ __forceinline__ void dif_stage(float (&re)[R], float (&im)[R]) {
   });
 }
 
+
+// ---- EXPERIMENT (-DAMCX_EXP_PK_FFT, _PK_PASS1_ONLY, _PK_TAIL_ONLY; the product build uses none of it) -----------
+// The same butterflies on (re, im) register PAIRS with packed fp32 instructions.  v_pk_add / v_pk_mul /
+// v_pk_fma_f32 work on an aligned VGPR pair per operand and choose, per operand and per result half, which
+// half of the pair feeds it (op_sel / op_sel_hi) and whether it is negated (neg_lo / neg_hi): a complex value
+// kept as one pair needs no shuffles, a + b and a - b are one instruction, multiplication by -i or by a twiddle
+// folds into the operand selectors, and the 6-FMA butterfly of twisted_dit is three v_pk_fma_f32.  Every half is
+// rounded exactly as in the scalar form (same operations, same order): the builds give bit-identical features.
+// In isolation the packed 16-point pass takes 24 % fewer SIMD cycles (tools/ubench_fft.hip: 328 against 433 at
+// three waves per SIMD) and a packed FMA stream does 17 % more flops under the power cap than a scalar one
+// (profiles/r1_valu_issue_rates.txt).  IN the kernel it loses: 503 VALU instructions fewer per frame, the clock
+// 3 % higher (less energy per frame, as predicted) -- and 470 SIMD cycles per frame MORE (10 590 against 10 120;
+// pass 1 alone +528, passes 2-3 alone +937), i.e. -2.5 % frames/s, however the butterflies are ordered
+// (profiles/r3_pk_fft_ab.txt).  The kernel is not issue-bound (66 % of the VALU slots): a wave in its FFT shares
+// the SIMD with two waves in their statistics sweeps, and there a packed instruction costs the wave ~12 cycles
+// where the microbenchmark's three packed waves pay 8.8.  Kept for the record and for other silicon.
+// The compiler folds whole-pair swaps and negations into the modifiers by itself; the forms that negate
+// ONE half are spelled as inline assembly.
+typedef float v2 __attribute__((ext_vector_type(2)));
+#if defined(AMCX_EXP_PK_FFT)
+constexpr bool kPkPass1 = true, kPkTail = true;
+#elif defined(AMCX_EXP_PK_PASS1_ONLY)
+constexpr bool kPkPass1 = true, kPkTail = false;
+#elif defined(AMCX_EXP_PK_TAIL_ONLY)
+constexpr bool kPkPass1 = false, kPkTail = true;
+#else
+constexpr bool kPkPass1 = false, kPkTail = false;       // the product: scalar butterflies (see above)
+#endif
+
+__device__ __forceinline__ v2 pk_fma(v2 a, v2 b, v2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// y + t.y * (-b.y, b.x): the second half of y = a + t b
+__device__ __forceinline__ v2 pk_fma_rot(v2 b, v2 t, v2 y) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "+v"(y) : "v"(b), "v"(t));
+  return y;
+}
+// (a, b) <- (a + t b, a - t b): bfly6 in three packed FMAs
+__device__ __forceinline__ void bfly6_pk(v2& a, v2& b, const v2 t) {
+  const v2 y = pk_fma_rot(b, t, pk_fma(b, t.xx, a));
+  b = pk_fma(a, (v2){2.0f, 2.0f}, -y);
+  a = y;
+}
+// (a - b) * (-i) = (a.y - b.y, b.x - a.x)
+__device__ __forceinline__ v2 pk_sub_mul_mi(v2 a, v2 b) {
+  v2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// (z.x + z.y, z.y - z.x) = z * (1 - i)
+__device__ __forceinline__ v2 pk_mul_1mi(v2 z) {
+  v2 r;
+  asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(z));
+  return r;
+}
+// (z.y - z.x, -z.x - z.y) = z * (-1 - i)
+__device__ __forceinline__ v2 pk_mul_m1mi(v2 z) {
+  v2 r;
+  asm("v_pk_add_f32 %0, %1, %1 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[1,1]" : "=v"(r) : "v"(z));
+  return r;
+}
+// (z.y * k.y, -(z.x * k.y)): the inner products of z * (k.x - i k.y), k = (cos, sin) in an SGPR pair
+__device__ __forceinline__ v2 pk_cross(v2 z, v2 k) {
+  v2 r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[1,0]" : "=v"(r) : "v"(z), "s"(k));
+  return r;
+}
+// (a - b) * W_32^J, every half rounded as dr = ar - br ... mul_w32<J>(dr, di) rounds it
+template <int J>
+__device__ __forceinline__ v2 pk_sub_mul_w32(v2 a, v2 b) {
+  constexpr float h = 0.70710678118654752f;
+  if constexpr (J == 0) {
+    return a - b;
+  } else if constexpr (J == 8) {
+    return pk_sub_mul_mi(a, b);
+  } else if constexpr (J == 4) {
+    return pk_mul_1mi(a - b) * (v2){h, h};
+  } else if constexpr (J == 12) {
+    return pk_mul_m1mi(a - b) * (v2){h, h};
+  } else {
+    const v2 d = a - b, k = {kC32[J], kS32[J]};
+    return pk_fma(d, k.xx, pk_cross(d, k));
+  }
+}
+template <int LEN, int OFF, int R>
+__device__ __forceinline__ void dif_stage_pk(v2 (&x)[R]) {
+  constexpr int H = LEN / 2;
+  static_for<H>([&](auto jj) {
+    constexpr int j = decltype(jj)::value;
+    const v2 a = x[OFF + j], b = x[OFF + j + H];
+    x[OFF + j] = a + b;
+    x[OFF + j + H] = pk_sub_mul_w32<j * (32 / LEN)>(a, b);
+  });
+}
+template <int LEN, int OFF, int R>
+__device__ __forceinline__ void dif_pk(v2 (&x)[R]) {
+  if constexpr (LEN >= 2) {
+    dif_stage_pk<LEN, OFF, R>(x);
+    dif_pk<LEN / 2, OFF, R>(x);
+    dif_pk<LEN / 2, OFF + LEN / 2, R>(x);
+  }
+}
+
 // ---- DPP helpers -------------------------------------------------------------
 template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf, bool BOUND = true>
 __device__ __forceinline__ float dpp(float v) {
@@ -469,6 +571,86 @@ __device__ __forceinline__ void twisted_dit(float (&re)[LEN], float (&im)[LEN], 
   });
 }
 
+// A stage's LEN/2 butterflies are issued as three sweeps -- first FMA of all, second FMA of all, third of all --
+// with the scheduler fenced in between: a packed FMA's result is needed LEN/2 instructions later, not two (left to
+// itself the scheduler puts the three FMAs of a butterfly two apart, and the packed passes ran at 5.4 cycles
+// per instruction per SIMD instead of the 3.1 the instruction issues at).  The factors of the next stage are read
+// from LDS before the third sweep of this one.
+template <int LEN, class TW>
+__device__ __forceinline__ void twisted_dit_pk(v2 (&x)[LEN], TW&& tw) {
+  constexpr int LOG = LEN == 16 ? 4 : 3;
+  constexpr int NB = LEN / 2;
+  static_assert(LEN == 16 || LEN == 8, "pass lengths");
+  v2 t[NB], tn[NB];
+  t[0] = tw(std::integral_constant<int, 0>{});
+  static_for<LOG>([&](auto ss) {
+    constexpr int sidx = decltype(ss)::value;
+    constexpr int half = 1 << sidx;             // factors in this stage
+    constexpr int d = LEN / (2 * half);         // distance between the two inputs; butterfly (k, m): factor k
+    v2 y[NB];
+    static_for<NB>([&](auto bb) {
+      constexpr int k = decltype(bb)::value / d, m = decltype(bb)::value % d;
+      constexpr int p = m + 2 * d * bitrev(k, sidx);
+      y[decltype(bb)::value] = pk_fma(x[p + d], t[k].xx, x[p]);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<NB>([&](auto bb) {
+      constexpr int k = decltype(bb)::value / d, m = decltype(bb)::value % d;
+      constexpr int p = m + 2 * d * bitrev(k, sidx);
+      y[decltype(bb)::value] = pk_fma_rot(x[p + d], t[k], y[decltype(bb)::value]);
+    });
+    if constexpr (sidx + 1 < LOG)
+      static_for<2 * half>([&](auto kk) {
+        tn[decltype(kk)::value] = tw(std::integral_constant<int, 2 * half - 1 + decltype(kk)::value>{});
+      });
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<NB>([&](auto bb) {
+      constexpr int k = decltype(bb)::value / d, m = decltype(bb)::value % d;
+      constexpr int p = m + 2 * d * bitrev(k, sidx);
+      x[p + d] = pk_fma(x[p], (v2){2.0f, 2.0f}, -y[decltype(bb)::value]);
+      x[p] = y[decltype(bb)::value];
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (sidx + 1 < LOG)
+      static_for<2 * half>([&](auto kk) { t[decltype(kk)::value] = tn[decltype(kk)::value]; });
+  });
+}
+
+// passes 2 and 3 behind exchange 1 (shared by fft_peak and fft_back): reads the lane's 16 pass-2 inputs, returns
+// the lane's max |X|^2; TW2 / TW3 give factor i of pass 2 / of pass 3's half j
+template <class TW2, class TW3>
+__device__ __forceinline__ float fft_tail_pk(const LaneAddr& la, float peak, TW2&& tw2, TW3&& tw3, bool mark) {
+  v2 z[16];
+  static_for<16>([&](auto nn) {
+    constexpr int n2 = decltype(nn)::value;
+    z[n2] = *reinterpret_cast<const v2*>(la.ex1_r + n2 * 32);
+  });
+  if (mark) asm volatile("; MARK fft2");
+  __builtin_amdgcn_sched_barrier(0);
+  twisted_dit_pk<16>(z, tw2);
+  lds_wave_fence();
+  static_for<16>([&](auto kk2) {
+    constexpr int k2 = decltype(kk2)::value;
+    *reinterpret_cast<v2*>(la.ex2_w + (k2 * kEx2StrideK2) * 8) = z[bitrev(k2, 4)];
+  });
+  lds_wave_fence();
+  static_for<2>([&](auto jj) {
+    constexpr int j = decltype(jj)::value;
+    v2 u[8];
+    static_for<8>([&](auto nn) {
+      constexpr int n3 = decltype(nn)::value;
+      u[n3] = *reinterpret_cast<const v2*>(la.ex2_r + (j * 8 * kEx2StrideK2 + n3) * 8);
+    });
+    twisted_dit_pk<8>(u, [&](auto ii) { return tw3(jj, ii); });
+    static_for<4>([&](auto pp) {
+      constexpr int p = 2 * decltype(pp)::value;
+      peak = __builtin_fmaxf(__builtin_fmaxf(peak, __builtin_fmaf(u[p].x, u[p].x, u[p].y * u[p].y)),
+                             __builtin_fmaf(u[p + 1].x, u[p + 1].x, u[p + 1].y * u[p + 1].y));   // v_max3
+    });
+  });
+  return peak;
+}
+
 // Register FFT of 128*R points held as xr/xi[2*i+b] (see header); returns this
 // lane's max |X|^2 over the 2R bins it ends up with.
 template <int R>
@@ -483,28 +665,59 @@ __device__ __forceinline__ float fft_peak(const float (&xr)[2 * R], const float 
   // pass 2, exchange 2 and pass 3 -- 32 registers fewer in flight than with both phases' pass-2
   // inputs read before either is processed.
   float v0r[R], v0i[R], v1r[R], v1i[R];
-  static_for<R>([&](auto ii) {
-    constexpr int i = decltype(ii)::value;
-    v0r[i] = xr[2 * i]; v0i[i] = xi[2 * i]; v1r[i] = xr[2 * i + 1]; v1i[i] = xi[2 * i + 1];
-  });
-  if constexpr (PH == 2) {
-    dif_stage<R, 0>(v0r, v0i);
-    dif_stage<R, 0>(v1r, v1i);
+  v2 v0[R], v1[R];
+  if constexpr (kPkPass1) {
+    static_for<R>([&](auto ii) {
+      constexpr int i = decltype(ii)::value;
+      v0[i] = (v2){xr[2 * i], xi[2 * i]}; v1[i] = (v2){xr[2 * i + 1], xi[2 * i + 1]};
+    });
+    if constexpr (PH == 2) {
+      dif_stage_pk<R, 0>(v0);
+      dif_stage_pk<R, 0>(v1);
+    }
+  } else {
+    static_for<R>([&](auto ii) {
+      constexpr int i = decltype(ii)::value;
+      v0r[i] = xr[2 * i]; v0i[i] = xi[2 * i]; v1r[i] = xr[2 * i + 1]; v1i[i] = xi[2 * i + 1];
+    });
+    if constexpr (PH == 2) {
+      dif_stage<R, 0>(v0r, v0i);
+      dif_stage<R, 0>(v1r, v1i);
+    }
   }
   float peak = 0.f;
   static_for<PH>([&](auto gg) {
     constexpr int gph = decltype(gg)::value;
-    dif<8, 8 * gph>(v0r, v0i);
-    dif<8, 8 * gph>(v1r, v1i);
+    if constexpr (kPkPass1) {
+      dif_pk<8, 8 * gph>(v0);
+      dif_pk<8, 8 * gph>(v1);
+    } else {
+      dif<8, 8 * gph>(v0r, v0i);
+      dif<8, 8 * gph>(v1r, v1i);
+    }
     float zr[16], zi[16];
     lds_wave_fence();
     static_for<8>([&](auto kk_) {
       constexpr int kk = decltype(kk_)::value;
       constexpr int p = 8 * gph + bitrev(kk, 3);        // R = 16: k1 = 2 kk + gph; R = 8: k1 = kk
-      *reinterpret_cast<float2*>(la.ex1_w + (kk * kEx1StrideKK) * 8) = make_float2(v0r[p], v0i[p]);
-      *reinterpret_cast<float2*>(la.ex1_w + (kk * kEx1StrideKK + kEx1StrideB) * 8) = make_float2(v1r[p], v1i[p]);
+      if constexpr (kPkPass1) {
+        *reinterpret_cast<v2*>(la.ex1_w + (kk * kEx1StrideKK) * 8) = v0[p];
+        *reinterpret_cast<v2*>(la.ex1_w + (kk * kEx1StrideKK + kEx1StrideB) * 8) = v1[p];
+      } else {
+        *reinterpret_cast<float2*>(la.ex1_w + (kk * kEx1StrideKK) * 8) = make_float2(v0r[p], v0i[p]);
+        *reinterpret_cast<float2*>(la.ex1_w + (kk * kEx1StrideKK + kEx1StrideB) * 8) = make_float2(v1r[p], v1i[p]);
+      }
     });
     lds_wave_fence();
+    if constexpr (kPkTail) {
+      const char* const tw2p = la.tw2;
+      const char* const tw3p = la.tw3;
+      peak = fft_tail_pk(la, peak,
+          [&](auto ii) { return *reinterpret_cast<const v2*>(tw2p + gph * 8 * kTw2Stride + decltype(ii)::value * 8); },
+          [&](auto jj, auto ii) {
+            return *reinterpret_cast<const v2*>(tw3p + ((gph * 2 + decltype(jj)::value) * 7 + decltype(ii)::value) * kTw3Row);
+          }, gph == 0);
+    } else {
     static_for<16>([&](auto nn) {
       constexpr int n2 = decltype(nn)::value;
       const float2 v = *reinterpret_cast<const float2*>(la.ex1_r + n2 * 32);
@@ -542,6 +755,7 @@ __device__ __forceinline__ float fft_peak(const float (&xr)[2 * R], const float 
                                __builtin_fmaf(ur[p + 1], ur[p + 1], ui[p + 1] * ui[p + 1]));   // v_max3
       });
     });
+    }
     if constexpr (gph + 1 < PH) __builtin_amdgcn_sched_barrier(0);   // the other half starts only now
   });
   lds_wave_fence();

@@ -65,6 +65,13 @@ void run(const char* label, const float2* d_iq, long long F, float* d_out, unsig
          "(min %.3f max %.3f) | wave lifetime us med %.0f min %.0f max %.0f | SIMD cycles/frame %.0f",
          label, N, grid, launches, ms, F / ms / 1e3, clock, mn(clk), mx(clk), med(life), mn(life), mx(life),
          cyc_per_frame_simd);
+  {  // FNV-1a over the output rows (sums + features): two builds that claim bit-identical arithmetic print the same word
+    std::vector<unsigned> o((size_t)F * 18);
+    CHECK(hipMemcpy(o.data(), d_out, o.size() * 4, hipMemcpyDeviceToHost));
+    unsigned long long hsh = 1469598103934665603ull;
+    for (unsigned w : o) { hsh ^= w; hsh *= 1099511628211ull; }
+    printf(" | out %016llx", hsh);
+  }
   if (g_valu_per_frame > 0)
     printf(" | VALU issue slots used %.1f %% (%.0f instr x 2 cyc)", 100.0 * g_valu_per_frame * 2.0 / cyc_per_frame_simd,
            g_valu_per_frame);
@@ -120,6 +127,12 @@ int main(int argc, char** argv) {
   printf("# build: v_rcp_f32 of the half-angle quotient removed (AMCX_ABL_NORCP)\n");
 #elif defined(AMCX_ABL_NOSQRT)
   printf("# build: v_sqrt_f32 of the envelope removed (AMCX_ABL_NOSQRT)\n");
+#elif defined(AMCX_EXP_PK_FFT)
+  printf("# build: packed-fp32 FFT butterflies, all passes (AMCX_EXP_PK_FFT)\n");
+#elif defined(AMCX_EXP_PK_PASS1_ONLY)
+  printf("# build: packed-fp32 butterflies in FFT pass 1 only (AMCX_EXP_PK_PASS1_ONLY)\n");
+#elif defined(AMCX_EXP_PK_TAIL_ONLY)
+  printf("# build: packed-fp32 butterflies in FFT passes 2-3 only (AMCX_EXP_PK_TAIL_ONLY)\n");
 #else
   printf("# build: product instruction stream\n");
 #endif
