@@ -1186,12 +1186,17 @@ def test_engine_reads_the_container_from_its_file(tmp_path):
     eng = HipEngine(N, threads=4, chunk_bytes=1 << 20)              # several chunks
     # whole container: planes read from the file; fewer snr rows / a shard's frame range / one snr row leave runs of
     # a few elements, which go through the mapping instead
-    for (s, k, lo, hi, from_file) in [(S, K, 0, None, 1), (3, 50, 0, None, 0), (S, K, 37, 1290, 0), (1, K, 0, None, 0)]:
+    for (s, k, lo, hi, from_file) in [(S, K, 0, None, 1), (S, 300, 0, None, 1), (3, 50, 0, None, 0), (S, K, 37, 1290, 0), (1, K, 0, None, 0)]:
         a = eng(FrameRows(loaded, s, k, lo, hi))
         assert eng.stats["from_file"] == 0
         b = eng(FrameRows(fx, s, k, lo, hi))
         assert eng.stats["from_file"] == from_file, (s, k, lo, hi, eng.stats)
         assert np.array_equal(a, b, equal_nan=True), (s, k, lo, hi)
+    # a rank's share when the container is cut along the frame axis: frames [k_lo, k_hi) of every snr row, from the file
+    from amcpy_amd.feature_extraction import FrameColumns
+    whole = eng(FrameRows(loaded, S, K)).reshape(S, K, 18)
+    share = eng(FrameColumns(fx, S, K, 120, 330))
+    assert eng.stats["from_file"] == 1 and np.array_equal(share.reshape(S, 210, 18), whole[:, 120:330], equal_nan=True)
     want = orc.features18_batch(loaded[:S, :K, :N].reshape(-1, N).astype(np.complex64))
     _assert_parity(eng(FrameRows(fx, S, K)), want, loaded[:S, :K, :N].reshape(-1, N), "file engine")
     # run_extraction: direct (default) against the python-side readers
