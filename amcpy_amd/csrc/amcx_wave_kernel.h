@@ -47,14 +47,13 @@
 // Every ds_write_b64 / ds_read_b64 / ds_read_b128 of the exchanges and twiddle
 // tables is bank-conflict free and addressed as lane_base + immediate.
 //
-// 768-thread workgroups (N <= 2048): 12 waves = exactly 3 per SIMD, one workgroup per CU;
-// LDS, not registers, sets that number (125 VGPRs at N = 2048 since the sums are reduced
-// before the FFT).  16 waves fit with the exchange buffer at its exact 8672 bytes and batches of
-// four frames (-DAMCX_EXP_WAVES16): 5.6 % fewer cycles per frame, +1 % frames/s -- the board is at
-// its power cap and the clock gives the difference back.
+// One workgroup per CU.  N <= 1024: 768 threads = 12 waves = 3 per SIMD.  N = 2048: 1024 threads = 16 waves = 4 per
+// SIMD (128 VGPRs, no spill; the exchange buffer at its exact 8672 bytes and batches of four frames make
+// the LDS fit): 4.3 % fewer SIMD cycles per frame than with 12 waves, of which the power cap takes 2.5 % back
+// as clock -- +1.8 % frames/s (-DAMCX_EXP_WAVES12 builds the 12-wave form).
 // (Two 6-wave workgroups did NOT co-reside at the 160 VGPRs of round 1a: their waves
 // landed 2,2,1,1 on the SIMDs, profiles/r1a.)  LDS per workgroup at N = 2048:
-// factor tables 1920 + 14336 B, 12 x 8672 B exchange, 12 x 1056 B stash = 133.3 KB.
+// factor tables 1920 + 14336 B, 16 x 8672 B exchange, 16 x 528 B stash = 159.6 KB.
 // Algorithmic HBM bytes per frame: 8*N read + 72 written.
 #pragma once
 
@@ -85,10 +84,11 @@ struct Cfg {
   static constexpr bool kSplit2 = N == 8192;           // ... and a second one in front of that
   // frames per wave per batch, finalised together one frame per lane: the fp64 algebra costs
   // the same per batch whatever N is, so short frames come in larger batches
-#ifdef AMCX_EXP_WAVES16   // experiment: 4 waves per SIMD (tools/wave_clock.hip)
-  static constexpr int kFramesPerWave = N == 2048 ? 4 : N >= 1024 ? 8 : (N == 512 ? 16 : 32);
-#else
+  // (N = 2048 runs 16 waves per CU, below: batches of four are what its LDS then holds)
+#ifdef AMCX_EXP_WAVES12   // the 12-wave configuration of rounds 1-3 at N = 2048, for A/B runs (tools/wave_clock.hip)
   static constexpr int kFramesPerWave = N >= 1024 ? 8 : (N == 512 ? 16 : 32);
+#else
+  static constexpr int kFramesPerWave = N == 2048 ? 4 : N >= 1024 ? 8 : (N == 512 ? 16 : 32);
 #endif
   // how many times per frame the per-lane fp32 sums are reduced into the stash and started
   // afresh (the finaliser adds the rows in fp64): at N = 8192 a lane would otherwise run 128
@@ -103,14 +103,16 @@ struct Cfg {
   static constexpr int kGroup = N < 1024 ? 1024 / N : 1;
   // frames per grab over the last stretch of a workgroup's slice (levels the waves' finish)
   static constexpr int kTailChunk = kGroup > 2 ? kGroup : 2;
-  // waves per workgroup = waves per CU: 3 per SIMD at 161-168 VGPRs, 2 per SIMD when the
-  // frame alone takes 128 VGPRs (16 waves at N = 1024, 114 VGPRs, measured no faster: power-bound)
-#ifdef AMCX_EXP_WAVES16
-  static constexpr int kWavesPerWG = kSplit ? 8 : 16;
+  // waves per workgroup = waves per CU: 2 per SIMD when the frame alone takes 128 VGPRs (N >= 4096), 3 per SIMD for
+  // the short frames (16 waves at N = 1024, 114 VGPRs, measured no faster), 4 per SIMD at N = 2048: the kernel fits
+  // 128 VGPRs there without a spill, the fourth wave hides 4.3 % of the SIMD's cycles and the power cap gives 2.5 %
+  // of them back as clock -- +1.8 % frames/s in five alternating same-box rounds (profiles/r3_waves16_ab.txt)
+#if defined(AMCX_EXP_WAVES12)
+  static constexpr int kWavesPerWG = kSplit ? 8 : 12;
 #elif defined(AMCX_EXP_8192_W4)
   static constexpr int kWavesPerWG = kSplit2 ? 4 : kSplit ? 8 : 12;
 #else
-  static constexpr int kWavesPerWG = kSplit ? 8 : 12;
+  static constexpr int kWavesPerWG = kSplit ? 8 : (N == 2048 ? 16 : 12);
 #endif
   static constexpr int kThreads = 64 * kWavesPerWG;
   static constexpr int kTailFrames = kWavesPerWG * kFramesPerWave;
