@@ -1,0 +1,17 @@
+#!/bin/bash
+# Copy the condensed results of `bash tools/profile_all.sh TAG` (gpurun_out/, scratch) into profiles/ (tracked).
+#   bash tools/collect_profiles.sh r3
+TAG=${1:-r3}
+cd "$(dirname "$0")/.."
+for N in 2048 4096 1024 8192; do
+  D=gpurun_out/prof_${TAG}_n$N
+  [ -d $D ] || { echo "no $D"; continue; }
+  cp $D/summary.txt profiles/${TAG}_n${N}_summary.json
+  cp $D/pmc_traffic.json profiles/${TAG}_n${N}_pmc_traffic.json
+  cp $D/bench_trace.json profiles/${TAG}_bench_under_rocprof_n$N.json
+  cp "$(ls -t $(find $D/trace -name '*kernel_stats.csv') | head -1)" profiles/${TAG}_n${N}_kernel_stats.csv
+done
+for f in bench_all_sizes.jsonl bench_default.json wave_clock.txt; do
+  [ -f gpurun_out/${TAG}_$f ] && cp gpurun_out/${TAG}_$f profiles/${TAG}_$f
+done
+ls -la profiles/${TAG}_n2048_* profiles/${TAG}_bench_default.json
