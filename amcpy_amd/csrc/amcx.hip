@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <chrono>
 #include <new>
@@ -237,6 +238,18 @@ struct amcx_ctx {
   hipEvent_t slab_free[2] = {nullptr, nullptr};
   float* out_pin = nullptr; size_t out_pin_cap = 0;   // the result lands in pinned memory first
   amcx_upload_stats stats = {};
+  // small row-major calls (a loop of per-frame calculate_features calls): the copy in, the launches and the copy
+  // out as ONE instantiated graph per (frames, frame size, variant, element type, buffers), relaunched
+  struct SmallGraph {
+    hipGraphExec_t exec = nullptr;
+    int64_t frames = 0; int32_t frame_size = 0, variant = 0; bool c128 = false;
+    const void* pin = nullptr; const void* slab = nullptr; const void* out = nullptr; const void* out_pin = nullptr;
+    size_t slot = 0;
+  };
+  SmallGraph graphs[4];
+  int graph_next = 0;               // slot the next capture replaces
+  int graph_hits = 0, graph_misses = 0;
+  bool graphs_ok = true;            // false: capture failed once, or the calls vary too much for a cache of four
 };
 
 }  // extern "C"
@@ -382,6 +395,88 @@ int ctx_run_strided(amcx_ctx* c, amcx::Source src, int64_t S, int64_t K,
 
   hipError_t e = hipSuccess;
   const double t_loop = wall_now();
+  // ---- small row-major calls: one graph launch ------------------------------------------------------------------
+  // A per-frame loop (the reference's calculate_features per queue item, features.py:214-232) is launch-bound: copy in,
+  // one or two conversions / kernels, the range pass, copy out, a synchronisation -- eight runtime calls around 10 us of
+  // GPU work.  Captured once per shape into a graph on the compute stream, a call is: stage into the pinned slot,
+  // hipGraphLaunch, hipStreamSynchronize.  Anything that does not fit (several chunks, planes, staging threads) and any
+  // failure to capture takes the general path below.
+  if (rows && !threaded && total_staged <= slot && c->graphs_ok && getenv("AMCX_NO_GRAPH") == nullptr) {   // one chunk
+    char* pinned = c->pin;
+    char* dev = static_cast<char*>(c->d_slab);
+    const size_t bytes = (size_t)n_units * (size_t)unit * esz;
+    const size_t out_bytes = sizeof(float) * AMCX_NUM_FEATURES * (size_t)F;
+    double t0 = wall_now();
+    amcx::stage_runs(inline_pool, pinned, src, map, 0, n_units, as_c128);
+    st.seconds_staging += wall_now() - t0;
+    if (io_error.load() != 0) {
+      snprintf(g_hip_err, sizeof g_hip_err, "reading the container's file: %s", strerror(io_error.load()));
+      return AMCX_EIO;
+    }
+    amcx_ctx::SmallGraph* g = nullptr;
+    for (auto& cand : c->graphs)
+      if (cand.exec && cand.frames == F && cand.frame_size == N && cand.variant == v && cand.c128 == as_c128 &&
+          cand.pin == pinned && cand.slab == dev && cand.out == c->d_out && cand.out_pin == c->out_pin && cand.slot == slot)
+        g = &cand;
+    if (g != nullptr) {
+      ++c->graph_hits;
+    } else {
+      ++c->graph_misses;
+      if (c->graph_misses > 64 && c->graph_misses > 4 * c->graph_hits) c->graphs_ok = false;   // shapes keep changing
+      amcx_ctx::SmallGraph& slot_g = c->graphs[c->graph_next];
+      hipGraph_t graph = nullptr;
+      hipGraphExec_t exec = nullptr;
+      int crc = AMCX_OK;
+      hipError_t ce = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
+      if (ce == hipSuccess) {
+        ce = hipMemcpyAsync(dev, pinned, bytes, hipMemcpyHostToDevice, c->stream);
+        const void* d_rows = dev;
+        if (ce == hipSuccess && as_c128) {
+          float2* rounded = reinterpret_cast<float2*>(dev + slot);
+          hipLaunchKernelGGL(amcx::amcx_c128_to_c64_kernel, dim3(2048), dim3(256), 0, c->stream,
+                             reinterpret_cast<const double2*>(dev), (long long)F, (int)N, (long long)N, rounded);
+          ce = hipGetLastError();
+          d_rows = rounded;
+        }
+        if (ce == hipSuccess) crc = amcx_features18_c64_ex(d_rows, F, N, N, c->d_out, AMCX_NUM_FEATURES, c->stream, v);
+        if (ce == hipSuccess && crc == AMCX_OK)
+          ce = hipMemcpyAsync(c->out_pin, c->d_out, out_bytes, hipMemcpyDeviceToHost, c->stream);
+        const hipError_t ee = hipStreamEndCapture(c->stream, &graph);      // always ends the capture
+        if (ce == hipSuccess) ce = ee;
+      }
+      if (ce == hipSuccess && crc == AMCX_OK && graph != nullptr) ce = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+      if (graph != nullptr) (void)hipGraphDestroy(graph);
+      if (ce != hipSuccess || crc != AMCX_OK || exec == nullptr) {
+        (void)hipGetLastError();
+        c->graphs_ok = false;                 // the general path takes this call and every later one
+      } else {
+        if (slot_g.exec) (void)hipGraphExecDestroy(slot_g.exec);
+        slot_g.exec = exec; slot_g.frames = F; slot_g.frame_size = N; slot_g.variant = v; slot_g.c128 = as_c128;
+        slot_g.pin = pinned; slot_g.slab = dev; slot_g.out = c->d_out; slot_g.out_pin = c->out_pin; slot_g.slot = slot;
+        c->graph_next = (c->graph_next + 1) % 4;
+        g = &slot_g;
+      }
+    }
+    if (g != nullptr) {
+      st.seconds_prepare = t_loop - t_start;
+      const double t_tail = wall_now();
+      e = hipGraphLaunch(g->exec, c->stream);
+      const hipError_t e2 = hipStreamSynchronize(c->stream);
+      if (e != hipSuccess || e2 != hipSuccess) return hip_fail(e != hipSuccess ? e : e2, "amcx_ctx_features18 (graph launch)");
+      if (out_row_stride == AMCX_NUM_FEATURES) {
+        memcpy(out_host, c->out_pin, out_bytes);
+      } else {
+        for (int64_t gi = 0; gi < F; ++gi)
+          memcpy(out_host + (size_t)gi * (size_t)out_row_stride, c->out_pin + (size_t)gi * AMCX_NUM_FEATURES,
+                 sizeof(float) * AMCX_NUM_FEATURES);
+      }
+      st.pcie_bytes = (int64_t)bytes; st.chunks = 1;
+      st.seconds_tail = wall_now() - t_tail;
+      st.seconds = wall_now() - t_start;
+      c->stats = st;
+      return AMCX_OK;
+    }
+  }
   const int64_t units_per_slot = (int64_t)(slot / ((size_t)unit * esz));
   int64_t u = 0;
   for (int ch = 0; u < n_units && rc == AMCX_OK; ++ch) {
@@ -528,6 +623,7 @@ int amcx_ctx_destroy(amcx_ctx* c) {
   if (c->d_frames) (void)hipFree(c->d_frames);
   if (c->pin) (void)hipHostFree(c->pin);
   if (c->out_pin) (void)hipHostFree(c->out_pin);
+  for (auto& g : c->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
   delete c;                                     // joins the staging threads
   return AMCX_OK;
 }

@@ -1219,3 +1219,55 @@ def test_engine_reads_the_container_from_its_file(tmp_path):
         eng(FrameRows(broken, S, K))
     assert np.array_equal(eng(FrameRows(fx, S, K)), eng(FrameRows(loaded, S, K)), equal_nan=True)
     eng.close()
+
+
+def test_small_host_calls_replay_a_graph():
+    """Small row-major host calls (the per-frame loop of calculate_features, features.py:214-232) run as one cached
+    graph per shape -- copy in, kernels, copy out captured once, then hipGraphLaunch + one synchronisation.  Same
+    bits as the general path (AMCX_NO_GRAPH=1) for complex64 and complex128, several frame sizes and frame counts
+    in turn (more shapes than the cache holds), a padded output, and after a large call has made the context
+    reallocate its buffers; and it is the faster of the two."""
+    import time
+    from amcpy_amd import _lib
+    from amcpy_amd.features import features18_host
+    rng = np.random.default_rng(61)
+    frames = {(F, N, dt): (rng.standard_normal((F, N)) + 1j * rng.standard_normal((F, N))).astype(dt)
+              for F, N in [(1, 2048), (3, 2048), (1, 1024), (2, 4096), (1, 1000), (5, 256)] for dt in (np.complex64, np.complex128)}
+
+    def run_all():
+        return {k: features18_host(x) for k, x in frames.items()}
+
+    os.environ["AMCX_NO_GRAPH"] = "1"
+    try:
+        want = run_all()
+    finally:
+        del os.environ["AMCX_NO_GRAPH"]
+    for rep in range(3):                                        # twelve shapes through a cache of four, three times over
+        got = run_all()
+        for k in frames:
+            assert np.array_equal(got[k], want[k], equal_nan=True), (rep, k)
+    big = (rng.standard_normal((3000, 2048)) + 1j * rng.standard_normal((3000, 2048))).astype(np.complex64)
+    ref_big = features18_host(big)                               # 49 MB: buffers grow, the graphs' addresses are stale
+    assert np.array_equal(features18_host(frames[(1, 2048, np.complex64)]), want[(1, 2048, np.complex64)], equal_nan=True)
+    assert np.array_equal(ref_big[:3], features18_host(big[:3]), equal_nan=True)
+    # the per-frame loop, with and without the graph
+    x = frames[(1, 2048, np.complex64)]
+    ctx = _lib.HostContext(0)
+    out = np.empty((1, 18), dtype=np.float32)
+    def loop(n=300):
+        t0 = time.perf_counter()
+        for _ in range(n):
+            ctx.run_strided(x.ctypes.data, None, _lib.SRC_C64, 1, 1, 2048, (0, 2048, 1), out)
+        return (time.perf_counter() - t0) / n
+    loop(20)
+    with_graph = min(loop(), loop())
+    os.environ["AMCX_NO_GRAPH"] = "1"
+    try:
+        loop(20)
+        without = min(loop(), loop())
+    finally:
+        del os.environ["AMCX_NO_GRAPH"]
+    print(f"\nper 2048-sample frame through the context: {with_graph * 1e6:.1f} us as a graph, {without * 1e6:.1f} us as separate calls")
+    assert np.array_equal(out, want[(1, 2048, np.complex64)], equal_nan=True)
+    assert with_graph < without
+    ctx.close()
