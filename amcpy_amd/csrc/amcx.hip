@@ -242,7 +242,7 @@ struct amcx_ctx {
   // out as ONE instantiated graph per (frames, frame size, variant, element type, buffers), relaunched
   struct SmallGraph {
     hipGraphExec_t exec = nullptr;
-    int64_t frames = 0; int32_t frame_size = 0, variant = 0; bool c128 = false;
+    int64_t frames = 0; int32_t frame_size = 0, variant = 0; bool c128 = false, zero_copy = false;
     const void* pin = nullptr; const void* slab = nullptr; const void* out = nullptr; const void* out_pin = nullptr;
     size_t slot = 0;
   };
@@ -413,9 +413,13 @@ int ctx_run_strided(amcx_ctx* c, amcx::Source src, int64_t S, int64_t K,
       snprintf(g_hip_err, sizeof g_hip_err, "reading the container's file: %s", strerror(io_error.load()));
       return AMCX_EIO;
     }
+    // a few frames of complex64: the kernels read the pinned slot and write the pinned result themselves (host memory
+    // from hipHostMalloc is mapped into the device's address space) -- two copy nodes fewer in the graph
+    const bool zero_copy = !as_c128 && bytes <= (size_t(64) << 10) && getenv("AMCX_NO_ZERO_COPY") == nullptr;
     amcx_ctx::SmallGraph* g = nullptr;
     for (auto& cand : c->graphs)
       if (cand.exec && cand.frames == F && cand.frame_size == N && cand.variant == v && cand.c128 == as_c128 &&
+          cand.zero_copy == zero_copy &&
           cand.pin == pinned && cand.slab == dev && cand.out == c->d_out && cand.out_pin == c->out_pin && cand.slot == slot)
         g = &cand;
     if (g != nullptr) {
@@ -428,7 +432,11 @@ int ctx_run_strided(amcx_ctx* c, amcx::Source src, int64_t S, int64_t K,
       hipGraphExec_t exec = nullptr;
       int crc = AMCX_OK;
       hipError_t ce = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
-      if (ce == hipSuccess) {
+      if (ce == hipSuccess && zero_copy) {
+        crc = amcx_features18_c64_ex(pinned, F, N, N, c->out_pin, AMCX_NUM_FEATURES, c->stream, v);
+        const hipError_t ee = hipStreamEndCapture(c->stream, &graph);
+        ce = ee;
+      } else if (ce == hipSuccess) {
         ce = hipMemcpyAsync(dev, pinned, bytes, hipMemcpyHostToDevice, c->stream);
         const void* d_rows = dev;
         if (ce == hipSuccess && as_c128) {
@@ -452,6 +460,7 @@ int ctx_run_strided(amcx_ctx* c, amcx::Source src, int64_t S, int64_t K,
       } else {
         if (slot_g.exec) (void)hipGraphExecDestroy(slot_g.exec);
         slot_g.exec = exec; slot_g.frames = F; slot_g.frame_size = N; slot_g.variant = v; slot_g.c128 = as_c128;
+        slot_g.zero_copy = zero_copy;
         slot_g.pin = pinned; slot_g.slab = dev; slot_g.out = c->d_out; slot_g.out_pin = c->out_pin; slot_g.slot = slot;
         c->graph_next = (c->graph_next + 1) % 4;
         g = &slot_g;
