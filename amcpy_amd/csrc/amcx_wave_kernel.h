@@ -50,7 +50,8 @@
 // One workgroup per CU.  N <= 1024: 768 threads = 12 waves = 3 per SIMD.  N = 2048: 1024 threads = 16 waves = 4 per
 // SIMD (128 VGPRs, no spill; the exchange buffer at its exact 8672 bytes and batches of four frames make
 // the LDS fit): 4.3 % fewer SIMD cycles per frame than with 12 waves, of which the power cap takes 2.5 % back
-// as clock -- +1.8 % frames/s (-DAMCX_EXP_WAVES12 builds the 12-wave form).
+// as clock -- +1.2 ... +1.9 % frames/s for the kernel alone, +0.5 % through the library's step (DESIGN.md section 4.1;
+// -DAMCX_EXP_WAVES12 builds the 12-wave form).
 // (Two 6-wave workgroups did NOT co-reside at the 160 VGPRs of round 1a: their waves
 // landed 2,2,1,1 on the SIMDs, profiles/r1a.)  LDS per workgroup at N = 2048:
 // factor tables 1920 + 14336 B, 16 x 8672 B exchange, 16 x 528 B stash = 159.6 KB.
@@ -106,7 +107,8 @@ struct Cfg {
   // waves per workgroup = waves per CU: 2 per SIMD when the frame alone takes 128 VGPRs (N >= 4096), 3 per SIMD for
   // the short frames (16 waves at N = 1024, 114 VGPRs, measured no faster), 4 per SIMD at N = 2048: the kernel fits
   // 128 VGPRs there without a spill, the fourth wave hides 4.3 % of the SIMD's cycles and the power cap gives 2.5 %
-  // of them back as clock -- +1.8 % frames/s in five alternating same-box rounds (profiles/r3_waves16_ab.txt)
+  // of them back as clock -- +1.2 ... +1.9 % frames/s for the kernel alone in alternating same-box rounds, +0.5 % through
+  // the library's step (profiles/r3_waves16_ab.txt)
 #if defined(AMCX_EXP_WAVES12)
   static constexpr int kWavesPerWG = kSplit ? 8 : 12;
 #elif defined(AMCX_EXP_8192_W4)
@@ -951,7 +953,9 @@ __device__ __forceinline__ void wave_exact_frequency(const float2* __restrict__ 
   // which frequency_features turns into central moments -- in fp64 a shift within a few standard deviations of
   // the mean costs nothing.  The frame's last sample has no step: lane 63's last one is computed on a clamped
   // neighbour and weighted 0.
-  constexpr int kPer = N / 64, U = kPer < 8 ? kPer : 8, kTrips = kPer / U;     // N = 128: two steps per lane
+  // (four per trip where the kernel runs four waves per SIMD: 128 registers hold eight loads, not sixteen, without a spill)
+  constexpr int kUmax = Cfg<N>::kWavesPerWG >= 16 ? 4 : 8;
+  constexpr int kPer = N / 64, U = kPer < kUmax ? kPer : kUmax, kTrips = kPer / U;     // N = 128: two steps per lane
   static_assert(kPer >= 1 && kPer % U == 0, "frame sizes are powers of two >= 128");
   const double Kw = (double)Kw_f;
   double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;

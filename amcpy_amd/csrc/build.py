@@ -36,7 +36,8 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = True) -
         return LIB
     LIB_DIR.mkdir(exist_ok=True)
     tmp_lib = LIB.with_name(f"{LIB.name}.{os.getpid()}.tmp")     # linked aside, renamed when complete
-    cmd = [HIPCC, *FLAGS, *map(str, SOURCES), "-o", str(tmp_lib)]
+    # AMCX_EXTRA_FLAGS: experiment macros for same-box A/B runs of the whole library (e.g. -DAMCX_EXP_WAVES12)
+    cmd = [HIPCC, *FLAGS, *os.environ.get("AMCX_EXTRA_FLAGS", "").split(), *map(str, SOURCES), "-o", str(tmp_lib)]
     cwd = HERE
     if save_temps:                       # the intermediate files (.s, .bc, ...) land in csrc/build/, which is git- and gpurun-ignored
         cwd = HERE / "build"
