@@ -953,9 +953,7 @@ __device__ __forceinline__ void wave_exact_frequency(const float2* __restrict__ 
   // which frequency_features turns into central moments -- in fp64 a shift within a few standard deviations of
   // the mean costs nothing.  The frame's last sample has no step: lane 63's last one is computed on a clamped
   // neighbour and weighted 0.
-  // (four per trip where the kernel runs four waves per SIMD: 128 registers hold eight loads, not sixteen, without a spill)
-  constexpr int kUmax = Cfg<N>::kWavesPerWG >= 16 ? 4 : 8;
-  constexpr int kPer = N / 64, U = kPer < kUmax ? kPer : kUmax, kTrips = kPer / U;     // N = 128: two steps per lane
+  constexpr int kPer = N / 64, U = kPer < 8 ? kPer : 8, kTrips = kPer / U;     // N = 128: two steps per lane
   static_assert(kPer >= 1 && kPer % U == 0, "frame sizes are powers of two >= 128");
   const double Kw = (double)Kw_f;
   double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
