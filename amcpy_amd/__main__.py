@@ -2,4 +2,4 @@ import sys
 
 from .main import main
 
-sys.exit(main())
+sys.exit(main(skip_torch=True))

@@ -76,18 +76,22 @@ class AmcxError(RuntimeError):
 
 
 def torch_wanted() -> bool:
-    """False only when AMCX_SKIP_TORCH=1 and torch has not been imported yet: the host-buffer path (containers,
-    files, calculate_features) needs neither torch nor its HIP runtime, and a process that never touches torch
-    tensors -- the `extract` command line -- starts a second faster without the import."""
+    """False when the library was loaded on the system HIP runtime (``load(skip_torch=True)``, or AMCX_SKIP_TORCH=1 in
+    the environment) and torch has not been imported: the host-buffer path (containers, files, calculate_features)
+    needs neither torch nor its HIP runtime, and a process that never touches torch tensors -- the `extract`
+    command line -- starts a second faster without the import."""
     import sys
-    return "torch" in sys.modules or os.environ.get("AMCX_SKIP_TORCH", "0") != "1"
+    if "torch" in sys.modules:
+        return True
+    return not _loaded_without_torch and os.environ.get("AMCX_SKIP_TORCH", "0") != "1"
 
 
-def load() -> C.CDLL:
+def load(skip_torch: bool = False) -> C.CDLL:
     """Load libamcx.so once.  torch (if installed) is imported first so that the
     library binds to the HIP runtime torch ships and device pointers are shared
-    (unless the process opted out of torch, see :func:`torch_wanted`: importing torch AFTER the library
-    has loaded the system runtime would put two HIP runtimes into one process)."""
+    (unless the caller opts out -- ``skip_torch``, the command line's choice, or AMCX_SKIP_TORCH=1 -- see
+    :func:`torch_wanted`: importing torch AFTER the library has loaded the system runtime would put two HIP
+    runtimes into one process).  The opt-out is a property of this first call, not of the environment."""
     global _lib, _loaded_without_torch
     if _lib is not None:
         return _lib
@@ -95,7 +99,8 @@ def load() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python amcpy_amd/csrc/build.py` "
             "(hipcc, gfx950). amcpy_amd has no CPU fallback.")
-    if torch_wanted():
+    import sys
+    if "torch" in sys.modules or (not skip_torch and os.environ.get("AMCX_SKIP_TORCH", "0") != "1"):
         try:
             import torch  # noqa: F401  (side effect: loads torch's libamdhip64.so.7)
         except Exception:
@@ -116,8 +121,9 @@ def load() -> C.CDLL:
 def require_torch_runtime() -> None:
     """The tensor entry points hand torch's device pointers to the library: both must sit on ONE HIP runtime."""
     if _loaded_without_torch:
-        raise RuntimeError("libamcx.so was loaded with AMCX_SKIP_TORCH=1 (the system HIP runtime); torch tensors belong to "
-                           "the runtime torch ships. Unset AMCX_SKIP_TORCH, or import torch before amcpy_amd loads the library.")
+        raise RuntimeError("libamcx.so was loaded without torch (load(skip_torch=True) / AMCX_SKIP_TORCH=1: the system HIP "
+                           "runtime); torch tensors belong to the runtime torch ships. Import torch before amcpy_amd loads "
+                           "the library, or do not opt out.")
 
 
 def check(code: int) -> None:

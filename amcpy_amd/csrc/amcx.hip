@@ -283,28 +283,7 @@ struct DeviceGuard {
 // ---- strided host containers ----------------------------------------------------------------------
 constexpr int kPinSlots = 3;
 
-// which axis is contiguous decides how a container goes up: rows (a frame's samples contiguous) or sample
-// planes (the snr or the frame axis contiguous); false: no axis has unit stride
-bool classify_layout(int64_t S, int64_t K, int32_t N, int64_t ss, int64_t sk, int64_t sn, bool* rows,
-                     bool* inner_snr, amcx::RunMap* map) {
-  const int64_t F = S * K;
-  *rows = sn == 1;
-  *inner_snr = false;
-  if (*rows) {                        // run = one frame's N samples; run index = g = s * K + k
-    map->cnt_b = K; map->stride_a = ss; map->stride_b = sk; map->run_len = N;
-  } else if (sk == 1 && K > 1) {      // plane position j = s * K + k = g; runs of K frames
-    map->cnt_b = S; map->stride_a = sn; map->stride_b = ss; map->run_len = K;
-    if (ss == K) { map->cnt_b = 1; map->run_len = F; }          // the plane is one run
-  } else if (ss == 1 || S == 1) {     // plane position j = k * S + s; runs of S snr values
-    *inner_snr = true;
-    map->cnt_b = K; map->stride_a = sn; map->stride_b = sk; map->run_len = S;
-    if (sk == S) { map->cnt_b = 1; map->run_len = F; }
-  } else {
-    return false;
-  }
-  return true;
-}
-
+using amcx::classify_layout;      // amcx_upload.h: which axis is contiguous decides how a container goes up
 
 double wall_now() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();

@@ -158,6 +158,29 @@ struct RunMap {
   int64_t offset(int64_t i) const { return (i / cnt_b) * stride_a + (i % cnt_b) * stride_b; }
 };
 
+// which axis is contiguous decides how a container of (S, K) frames of N samples with element strides (ss, sk, sn)
+// goes up: rows (a frame's samples contiguous) or sample planes (the snr or the frame axis contiguous); false: no axis
+// has unit stride.  Host-only logic (tests/host_san/stage_fuzz.cc runs it under the sanitizers).
+inline bool classify_layout(int64_t S, int64_t K, int32_t N, int64_t ss, int64_t sk, int64_t sn, bool* rows,
+                            bool* inner_snr, RunMap* map) {
+  const int64_t F = S * K;
+  *rows = sn == 1;
+  *inner_snr = false;
+  if (*rows) {                        // run = one frame's N samples; run index = g = s * K + k
+    map->cnt_b = K; map->stride_a = ss; map->stride_b = sk; map->run_len = N;
+  } else if (sk == 1 && K > 1) {      // plane position j = s * K + k = g; runs of K frames
+    map->cnt_b = S; map->stride_a = sn; map->stride_b = ss; map->run_len = K;
+    if (ss == K) { map->cnt_b = 1; map->run_len = F; }          // the plane is one run
+  } else if (ss == 1 || S == 1) {     // plane position j = k * S + s; runs of S snr values
+    *inner_snr = true;
+    map->cnt_b = K; map->stride_a = sn; map->stride_b = sk; map->run_len = S;
+    if (sk == S) { map->cnt_b = 1; map->run_len = F; }
+  } else {
+    return false;
+  }
+  return true;
+}
+
 // The two conversions that carry the real-data path, written out for SSE2 (baseline x86-64): doubles are
 // rounded with cvtpd2ps (round to nearest even under the default MXCSR, as numpy's astype and the GPU's
 // conversion do) and the result leaves with non-temporal stores -- a pinned slot is written once and read

@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Build libamcx.so for gfx950 in-tree (amcpy_amd/lib/libamcx.so).
 
-    python amcpy_amd/csrc/build.py [--force] [--save-temps]
+    python amcpy_amd/csrc/build.py [--force] [--save-temps] [--output OTHER.so]
+
+The product library is always built from the sources alone.  An experiment build (AMCX_EXTRA_FLAGS, e.g.
+-DAMCX_EXP_WAVES12 for a same-box A/B) goes to ANOTHER file -- `--output amcpy_amd/lib/libamcx_exp.so`, selected at
+run time with AMCX_LIB=... -- and never replaces libamcx.so: extra flags without --output are refused.
 
 hipcc cross-compiles without a GPU.  The library links only the HIP runtime
 (libamdhip64.so.7); in a process that has imported torch first, the loader
@@ -31,13 +35,22 @@ def stale() -> bool:
     return any(p.stat().st_mtime > t for p in SOURCES + HEADERS + [Path(__file__)])
 
 
-def build(force: bool = False, save_temps: bool = False, verbose: bool = True) -> Path:
-    if not force and not stale():
-        return LIB
-    LIB_DIR.mkdir(exist_ok=True)
-    tmp_lib = LIB.with_name(f"{LIB.name}.{os.getpid()}.tmp")     # linked aside, renamed when complete
-    # AMCX_EXTRA_FLAGS: experiment macros for same-box A/B runs of the whole library (e.g. -DAMCX_EXP_WAVES12)
-    cmd = [HIPCC, *FLAGS, *os.environ.get("AMCX_EXTRA_FLAGS", "").split(), *map(str, SOURCES), "-o", str(tmp_lib)]
+def build(force: bool = False, save_temps: bool = False, verbose: bool = True, output=None) -> Path:
+    extra = os.environ.get("AMCX_EXTRA_FLAGS", "").split()
+    if output is None:
+        if extra:
+            raise SystemExit("AMCX_EXTRA_FLAGS builds an experiment: give it its own file (--output amcpy_amd/lib/libamcx_exp.so, "
+                             "run with AMCX_LIB=that file); libamcx.so is only ever the product build")
+        if not force and not stale():
+            return LIB
+        target = LIB
+    else:
+        target = Path(output).resolve()
+        if target == LIB.resolve():
+            raise SystemExit("--output must not be the product library")
+    target.parent.mkdir(exist_ok=True)
+    tmp_lib = target.with_name(f"{target.name}.{os.getpid()}.tmp")     # linked aside, renamed when complete
+    cmd = [HIPCC, *FLAGS, *extra, *map(str, SOURCES), "-o", str(tmp_lib)]
     cwd = HERE
     if save_temps:                       # the intermediate files (.s, .bc, ...) land in csrc/build/, which is git- and gpurun-ignored
         cwd = HERE / "build"
@@ -47,16 +60,17 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = True) -
         print("+", " ".join(cmd), file=sys.stderr)
     try:
         subprocess.run(cmd, check=True, cwd=str(cwd))
-        os.replace(tmp_lib, LIB)
+        os.replace(tmp_lib, target)
     finally:
         if tmp_lib.exists():
             tmp_lib.unlink()
-    return LIB
+    return target
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--save-temps", action="store_true")
+    ap.add_argument("--output", default=None, help="build to this file instead of the product library (experiments)")
     a = ap.parse_args()
-    print(build(a.force, a.save_temps))
+    print(build(a.force, a.save_temps, output=a.output))

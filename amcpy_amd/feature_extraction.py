@@ -34,6 +34,10 @@ What is different underneath:
   memory.  Either way every rank uploads its own contiguous frame range over its
   own PCIe link, and rank 0 gathers the (F x 18) rows and writes the files
   (amcpy_amd/sharding.py).  No collective touches the IQ data;
+* several GPUs need no launcher: ``run_extraction(cfg, devices=[0, 1, ...])`` (``python -m amcpy_amd extract
+  --devices all``) drives one engine per device from one host thread each inside ONE process
+  (:class:`DeviceFanOut`): every device takes its share of the frame axis, reads it from the file over its own
+  staging threads and PCIe link, and writes its rows straight into the result -- no process group, no gather;
 * a failure raises, on every rank: the reference's worker threads swallow
   exceptions and leave zero rows behind (feature_extraction.py:33-39), and its
   parent ignores the children's exit codes (:96-97).
@@ -396,6 +400,97 @@ def release_engines() -> None:
         _ENGINES.popitem()[1].close()
 
 
+class DeviceFanOut:
+    """``engine(rows) -> (F, 18) float32`` over SEVERAL devices from one process: one :class:`HipEngine` (context,
+    streams, pinned slots, staging threads) per entry of ``devices`` and one host thread each -- the native call
+    releases the GIL, ``hipSetDevice`` is per thread (the C ABI's host entries take the device index).  Where the
+    reference forks a process per modulation and threads inside it (feature_extraction.py:58-61,89-97), this cuts
+    every modulation over the devices: along its FRAME axis when that balances (``sharding.shard_by_frames`` -- one
+    contiguous run per sample plane of a column-major .mat), along the snr-major flattening otherwise.  Each device's
+    rows land directly in the result; no process group and no gather are involved.  A device may be listed twice
+    (two contexts on it: how the one-GPU test box exercises the path)."""
+
+    def __init__(self, frame_size: int, devices, threads: Optional[int] = None, chunk_bytes: int = 32 << 20):
+        devices = [int(d) for d in devices]
+        if not devices:
+            raise ValueError("DeviceFanOut needs at least one device")
+        have = _lib.load().amcx_device_count()
+        bad = [d for d in devices if d < 0 or (have > 0 and d >= have)]
+        if bad:
+            raise ValueError(f"device index {bad[0]} out of range: {have} gfx950 device(s) visible")
+        self.N, self.devices = int(frame_size), devices
+        # the staging threads of all devices share the host's cores
+        per = max(1, min(int(threads or 8), (os.cpu_count() or 1) // len(devices) or 1))
+        self.engines = [HipEngine(frame_size, d, chunk_bytes, threads=per) for d in devices]
+        self.threads = per
+        self._pool = ThreadPoolExecutor(max_workers=len(devices), thread_name_prefix="amcx-device")
+        self.stats = {}
+
+    def shares(self, rows: FrameRows):
+        """[(rows of device i, where they go)]: ``("columns", k_lo, k_hi)`` or ``("rows", lo, hi)``."""
+        W = len(self.engines)
+        whole = type(rows) is FrameRows and rows.lo == 0 and rows.hi == rows.n_snr * rows.n_frames
+        if whole and shard_by_frames(rows.n_snr, rows.n_frames, W):
+            cuts = [shard_range(rows.n_frames, r, W) for r in range(W)]
+            return [(FrameColumns(rows.parsed, rows.n_snr, rows.n_frames, a, b), ("columns", a, b)) for a, b in cuts]
+        F = rows.shape[0]
+        cuts = [shard_range(F, r, W) for r in range(W)]
+        return [(rows.slice(a, b), ("rows", a, b)) for a, b in cuts]
+
+    def __call__(self, frames) -> np.ndarray:
+        if not isinstance(frames, FrameRows):
+            arr = np.asarray(frames)
+            if arr.ndim != 2:
+                raise ValueError(f"expected (F, L) frames, got shape {arr.shape}")
+            frames = FrameRows(arr[None], 1, arr.shape[0])
+        rows = frames
+        F = rows.shape[0]
+        out = np.empty((F, 18), dtype=np.float32)
+        if F == 0:
+            return out
+        t0 = time.perf_counter()
+        shares = self.shares(rows)
+
+        def one(i):
+            part, where = shares[i]
+            return self.engines[i](part) if part.shape[0] else np.empty((0, 18), dtype=np.float32)
+
+        futs = [self._pool.submit(one, i) for i in range(len(shares))]
+        failures = []
+        for i, fut in enumerate(futs):                      # every device finishes (or fails) before anything is raised
+            try:
+                blk = fut.result()
+            except Exception as exc:
+                failures.append(f"device {self.devices[i]}: {type(exc).__name__}: {exc}")
+                continue
+            kind, a, b = shares[i][1]
+            if kind == "rows":
+                out[a:b] = blk
+            elif b > a:
+                out.reshape(rows.n_snr, rows.n_frames, 18)[:, a:b] = blk.reshape(rows.n_snr, b - a, 18)
+        if failures:
+            raise RuntimeError("feature extraction failed on " + "; ".join(failures))
+        self.stats = {"seconds": time.perf_counter() - t0, "devices": list(self.devices),
+                      "frames_per_device": [sh[0].shape[0] for sh in shares],
+                      "bytes_uploaded": sum(e.stats.get("bytes_uploaded", 0) for e in self.engines),
+                      "source_bytes": sum(e.stats.get("source_bytes", 0) for e in self.engines)}
+        return out
+
+    def close(self) -> None:
+        self._pool.shutdown(wait=True)
+        for e in self.engines:
+            getattr(e, "close", lambda: None)()
+
+
+def default_fanout(frame_size: int, devices, threads: Optional[int] = None) -> DeviceFanOut:
+    """The process's :class:`DeviceFanOut` for (frame_size, devices, threads), kept like :func:`default_engine`'s."""
+    key = (int(frame_size), tuple(int(d) for d in devices), max(1, int(threads or 8)))
+    eng = _ENGINES.get(key)
+    if eng is None:
+        eng = _ENGINES[key] = DeviceFanOut(frame_size, devices, threads)
+    return eng
+
+
 def _check_container(parsed, cfg: Config):
     n_snr = len(cfg.signals.snr_values)
     n_frames = cfg.signals.num_frames
@@ -626,16 +721,31 @@ def _read_ahead(inflated_bytes: int, n_variables: int) -> int:
     return int(max(1, min(6, n_variables, (os.cpu_count() or 2) - 1, fit)))
 
 
-def _same_host(world: int) -> bool:
+def _placement(world: int, device: Optional[int]) -> bool:
+    """One all-gather of (host name, device index) per run: True when every rank is on one host (rank 0 then decodes
+    for all).  Two ranks on the SAME device of the same host -- a launcher whose ranks never called
+    ``set_device(LOCAL_RANK)`` -- would be silently correct and ``world`` times slow: that raises on every rank
+    unless AMCX_SHARE_GPU=1 says it is meant (rehearsals on a one-GPU box).  ``device`` None: an injected engine."""
     import torch.distributed as dist
-    hosts = [None] * world
-    dist.all_gather_object(hosts, socket.gethostname())
-    return len(set(hosts)) == 1
+    where = [None] * world
+    dist.all_gather_object(where, (socket.gethostname(), device))
+    if device is not None and os.environ.get("AMCX_SHARE_GPU", "0") != "1":
+        seen = {}
+        for r, hd in enumerate(where):
+            if hd[1] is not None and hd in seen:
+                raise RuntimeError(f"ranks {seen[hd]} and {r} both compute on device {hd[1]} of {hd[0]}: give every rank "
+                                   f"its own GPU (torch.cuda.set_device(LOCAL_RANK) before run_extraction, or device=), "
+                                   f"or set AMCX_SHARE_GPU=1 if sharing is intended")
+            seen[hd] = r
+    return len({h for h, _ in where}) == 1
 
 
-def run_extraction(cfg: Config, *, compute=None, device: Optional[int] = None, verbose: bool = True) -> None:
+def run_extraction(cfg: Config, *, compute=None, device: Optional[int] = None, devices=None,
+                   verbose: bool = True) -> None:
     """Drop-in for the reference's ``run_extraction(cfg)``: writes one
-    ``{mod}_features.mat`` per entry of ``cfg.signals.modulations_with_noise``."""
+    ``{mod}_features.mat`` per entry of ``cfg.signals.modulations_with_noise``.
+    ``devices``: several GPU indices driven from THIS process (:class:`DeviceFanOut`; not together with a process
+    group of several ranks, where every rank has its one ``device``)."""
     import scipy.io
 
     rank, world = _rank_world()
@@ -643,7 +753,21 @@ def run_extraction(cfg: Config, *, compute=None, device: Optional[int] = None, v
     mat_path = cfg.paths.mat_data / cfg.paths.mat_filename
     N = cfg.signals.frame_size
     threads = max(1, int(cfg.signals.num_threads))
-    engine = compute if compute is not None else default_engine(N, device, threads)
+    if devices is not None:
+        devices = [int(d) for d in devices]
+        if compute is not None or device is not None:
+            raise ValueError("devices= stands in for device= / compute=")
+        if world > 1:
+            raise ValueError("devices= drives several GPUs from one process; with a process group of several ranks "
+                             "every rank takes its one device=")
+        if len(devices) == 1:
+            device, devices = devices[0], None
+    if compute is not None:
+        engine = compute
+    elif devices:
+        engine = default_fanout(N, devices, threads)
+    else:
+        engine = default_engine(N, device, threads)
     mods = list(cfg.signals.modulations_with_noise)
     t_start = time.perf_counter()
 
@@ -691,7 +815,7 @@ def run_extraction(cfg: Config, *, compute=None, device: Optional[int] = None, v
                 writes.append(writer.submit(save, mod, key, feats, t0))
         else:
             import torch.distributed as dist
-            shared_host = _same_host(world)
+            shared_host = _placement(world, getattr(engine, "device", None))
             mapped = {}                                 # rank 0: variables its reader thread has already mapped
 
             def decode_and_publish(mod):                # rank 0's reader thread

@@ -182,6 +182,7 @@ def _find(mm, size: int, key: str, path):
     """Walk the top-level elements for the variable ``key``: ``("matrix", class, is_complex, dims, data offset, end)``
     for a plain miMATRIX element, ``("compressed", offset, byte count, inflated size)`` for a compressed one."""
     pos = 128
+    unnamed = 0                                                 # elements whose name could not be read
     while pos + 8 <= size:
         t, n, d, nxt = _tag(mm, pos)
         if t == MI_COMPRESSED:
@@ -189,13 +190,18 @@ def _find(mm, size: int, key: str, path):
             name, inflated = _peek(memoryview(mm)[d:d + n])
             if name == key:
                 return "compressed", d, n, inflated
+            unnamed += name is None
         elif t == MI_MATRIX and n >= 48:
             cls, cplx, dims, name, data_pos = _matrix_header(mm, d, d + n)
             if name == key:
                 return "matrix", cls, cplx, dims, data_pos, d + n
+        elif t == MI_MATRIX:
+            unnamed += 1                                        # too short for a header this reader knows (an empty array)
         if nxt <= pos:
             raise _Unsupported("corrupt element tag")
         pos = nxt
+    if unnamed:                                                 # it may be one of those: scipy.io.loadmat decides
+        raise _Unsupported(f"{unnamed} element(s) of {path} could not be identified")
     raise KeyError(f"{path} has no variable {key!r}")
 
 

@@ -3,8 +3,16 @@
 frames (BASELINE.json metric), on N MI355X of one node.
 
     python bench.py                       # N=1, defaults finish in ~2-3 min
+    python bench.py --gpus N              # starts its own N ranks (one fresh child process per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+
+`--gpus N` without a launcher's WORLD_SIZE in the environment launches itself, as the
+reference's run_extraction forks its own workers (feature_extraction.py:89-97): the parent
+touches neither HIP nor torch.cuda, starts N children with RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* set, passes rank 0's JSON line through, exits non-zero if any child does and takes
+the children down with it (signal, time limit, or its own death).  Under an external launcher
+the ranks are the launcher's.
 
 A *step* is one pass of the hot path over one rank's resident shard: the
 BASELINE configs[1] shape -- 6 modulations x 26 SNR x 4096 frames x 2048
@@ -141,9 +149,9 @@ def cpu_baseline(max_procs: int | None = None, seconds: float = 10.0):
     return {
         "value": value, "unit": "frames/s", "cores": procs, "kind": "port", "cpu_model": _cpu_model(),
         "one_core_frames_per_s": one_core, "effective_cores": value / one_core,
-        "sample": f"{procs} worker processes, each cycling over 64 frames of one (modulation, SNR) block of the "
-                  f"BASELINE configs[0] shape ({n_mods} mods x {n_snr} SNR x {n_frames} x {N}, complex128 input, "
-                  f"oracle.calculate_features per frame) for {wall:.1f} s after pool warm-up: {frames} frames",
+        "sample": f"{procs} processes x {wall:.1f} s after warm-up, each cycling over 64 frames of one (mod, SNR) block "
+                  f"of configs[0] ({n_mods} x {n_snr} x {n_frames} x {N} complex128), oracle.calculate_features per "
+                  f"frame: {frames} frames",
         "extrapolated_configs1_seconds": N_MODS * N_SNR * N_FRAMES / value,
     }
 
@@ -201,9 +209,9 @@ def cpu_baseline_reference_shaped(n_threads: int = 8):
     return {
         "value": value, "unit": "frames/s", "cores": min(n_mods, _host_cores()), "kind": "reference-shaped",
         "cpu_model": _cpu_model(),
-        "sample": f"BASELINE configs[0] whole ({n_mods} mods x {n_snr} SNR x {n_frames} x {N}, complex128): "
-                  f"{n_mods} processes x {n_threads} threads fed by a Queue, as feature_extraction.py:58-61,89-97; "
-                  f"slowest process {compute_wall:.1f} s (pool wall {wall:.1f} s incl. data generation)",
+        "sample": f"configs[0] whole ({n_mods} x {n_snr} x {n_frames} x {N} complex128): {n_mods} processes x "
+                  f"{n_threads} threads fed by a Queue (feature_extraction.py:58-61,89-97); slowest process "
+                  f"{compute_wall:.1f} s",
         "extrapolated_configs1_seconds": N_MODS * N_SNR * N_FRAMES / value,
     }
 
@@ -224,12 +232,15 @@ def _pmc_traffic(frames_per_launch: int, frame_size: int):
 
 
 def _parity_block():
-    """Replayed from the committed sweep (tests/manual/parity_sweep.py on the GPU box, builder-run), NOT measured
-    in this run -- the live parity gate is `pytest -m gpu`."""
-    for name in ("r3_parity_summary.json", "r2_parity_summary.json"):
+    """Three numbers per frame size, replayed from the committed sweep (tests/manual/parity_sweep.py on the GPU box,
+    builder-run), NOT measured in this run -- the live parity gate is `pytest -m gpu`; the per-feature arrays stay in
+    the profile file."""
+    for name in ("r4_parity_summary.json", "r3_parity_summary.json", "r2_parity_summary.json"):
         d = _committed_json(name)
         if d is not None:
-            return {"source": f"profiles/{name} (committed; replayed, not measured in this run)", **d}
+            return {"source": f"profiles/{name} (replayed, not measured in this run)",
+                    "worst_scaled": {n: float(f"{v['worst_scaled']:.3g}") for n, v in d.get("sizes", {}).items()},
+                    "beyond_unfloored": {n: v.get("beyond_unfloored") for n, v in d.get("sizes", {}).items()}}
     return None
 
 
@@ -275,23 +286,21 @@ def h2d_path(dev, frame_size: int = FRAME_SIZE, big: bool = True):
         F = rows.shape[0]
         return {"GBps": reps * F * N * 16 / wall / 1e9, "pcie_GBps": reps * eng.stats["pcie_bytes"] / wall / 1e9,
                 "frames_per_s": reps * F / wall, "seconds": wall, "chunks_per_call": eng.stats["chunks"],
-                "staging_threads": eng.stats["gather_threads"],
-                "caller_staging_s": eng.stats["seconds_staging"], "caller_waiting_s": eng.stats["seconds_waiting"]}
+                "staging_threads": eng.stats["gather_threads"]}
 
     small = FrameRows(_fortran_container(n_snr, n_frames, N), n_snr, n_frames)
     rec = timed(HipEngine(N, dev.index), small, 2 * n_mods)  # the six modulations run_extraction loops over, twice
-    rec["what"] = (f"HipEngine on 2 x {n_mods} x ({n_snr}, {n_frames}, {N}) complex128 Fortran-ordered arrays (BASELINE "
-                   f"configs[0] as loadmat returns it), GBps = container bytes / wall: planes staged + rounded to "
-                   f"complex64 by host threads -> pinned -> H2D -> device transposition -> kernel -> D2H; "
-                   f"loadmat/savemat not included")
+    rec["what"] = (f"2 x {n_mods} x ({n_snr}, {n_frames}, {N}) complex128 Fortran-ordered (configs[0] as loadmat returns "
+                   f"it); GBps = container bytes / wall: host threads round + stage planes -> pinned -> H2D -> device "
+                   f"transposition -> kernel -> D2H")
     rec["round_on_device"] = timed(HipEngine(N, dev.index, round_on_device=True), small, 2 * n_mods)
-    rec["round_on_device"]["what"] = "same, doubles sent over PCIe as they are and rounded by the device kernel"
+    rec["round_on_device"]["what"] = "same, doubles over PCIe, rounded on the device"
     if big:
         try:
             rows = FrameRows(_fortran_container(N_SNR, N_FRAMES, N), N_SNR, N_FRAMES)
             rec["configs1_modulation"] = timed(HipEngine(N, dev.index), rows, 2)
-            rec["configs1_modulation"]["what"] = (f"one BASELINE configs[1] modulation, ({N_SNR}, {N_FRAMES}, {N}) complex128 "
-                                                  f"Fortran-ordered = {N_SNR * N_FRAMES * N * 16 / 1e9:.2f} GB, twice")
+            rec["configs1_modulation"]["what"] = (f"one configs[1] modulation, ({N_SNR}, {N_FRAMES}, {N}) complex128 "
+                                                  f"= {N_SNR * N_FRAMES * N * 16 / 1e9:.2f} GB, twice")
             del rows
         except Exception as exc:                           # a host short of 3.5 GB: reported, never fatal to the headline
             rec["configs1_modulation"] = {"error": repr(exc)}
@@ -395,6 +404,87 @@ def _config_label(frame_size, n_frames, n_mods, world):
     return "not a BASELINE config"
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _die_with_parent():
+    """preexec of a rank: its own process group (so the parent can take the whole rank down, helper processes
+    included) and SIGKILL when the parent goes away however that happens."""
+    import ctypes
+    import signal
+    os.setsid()
+    try:
+        ctypes.CDLL(None, use_errno=True).prctl(1, signal.SIGKILL, 0, 0, 0)      # PR_SET_PDEATHSIG
+    except Exception:
+        pass
+
+
+def self_launch(n: int, argv, time_limit: float, script=None, build: bool = True) -> int:
+    """`bench.py --gpus N` started by hand: N fresh child ranks of this script (the reference's caller runs ONE
+    command and the parallelism happens inside, feature_extraction.py:89-97).  This process never initialises HIP or
+    torch.cuda -- it builds the library if it is stale (hipcc only), starts the children with the launcher variables
+    set, lets rank 0 write the one JSON line straight to this process's stdout (the other ranks' stdout goes to
+    stderr), and returns the first non-zero exit code, killing whatever is still running ten seconds after a rank
+    failed, at `time_limit`, or on SIGTERM / SIGINT / SIGHUP."""
+    import signal
+    import subprocess
+    if build:
+        _ensure_library(0)                                 # before the ranks exist: none of them waits for a build
+    env = dict(os.environ)
+    env.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               AMCX_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    script = str(Path(__file__).resolve() if script is None else script)      # (another script: the process-handling tests)
+    procs = []
+
+    def kill_all(sig=signal.SIGKILL):
+        for pr in procs:
+            if pr.poll() is None:
+                try:
+                    os.killpg(pr.pid, sig)
+                except (ProcessLookupError, PermissionError):
+                    pass
+
+    def on_signal(signum, _frame):
+        kill_all()
+        raise SystemExit(128 + signum)
+
+    for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sg, on_signal)
+    sys.stdout.flush()
+    try:
+        for r in range(n):
+            e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+            procs.append(subprocess.Popen([sys.executable, script, *argv], env=e, stdin=subprocess.DEVNULL,
+                                          stdout=None if r == 0 else sys.stderr, preexec_fn=_die_with_parent))
+        deadline = time.time() + time_limit
+        first_bad, bad_at = 0, None
+        while any(pr.poll() is None for pr in procs):
+            for r, pr in enumerate(procs):
+                rc = pr.poll()
+                if rc not in (None, 0) and first_bad == 0:
+                    first_bad, bad_at = rc, time.time()
+                    print(f"bench.py: rank {r} exited with {rc}; stopping the others", file=sys.stderr)
+            if bad_at is not None and time.time() - bad_at > 10.0:
+                kill_all()
+            if time.time() > deadline:
+                print(f"bench.py: ranks still running after {time_limit:.0f} s; killing them", file=sys.stderr)
+                kill_all()
+                first_bad = first_bad or 124
+            time.sleep(0.05)
+        for pr in procs:
+            rc = pr.wait()
+            if rc != 0 and first_bad == 0:
+                first_bad = rc
+        return first_bad if first_bad >= 0 else 128 - first_bad      # a rank killed by a signal
+    finally:
+        kill_all()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -424,38 +514,48 @@ def main():
                          "run, e.g. two ranks sharing one GPU)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal: ranks take device local_rank %% device_count instead of one GPU each")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0,
+                    help="self-launched ranks (--gpus N without a launcher) are killed after this many seconds")
     args = ap.parse_args()
     FS = args.frame_size
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs {args.gpus} ranks: launch with "
-                             "python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N")
-        world, rank, local_rank = 1, 0, 0
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ      # torch.distributed.run, or our own parent
+    world = int(os.environ.get("WORLD_SIZE", "1")) if launched else 1
+    rank = int(os.environ.get("RANK", "0")) if launched else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if launched else 0
+    if launched and args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} under a launcher that started WORLD_SIZE={world} ranks: the two must agree "
+                         f"(python bench.py --gpus N starts its own ranks when no launcher did)")
+    if not launched and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:], args.launch_timeout))
 
     cpu = cpu_ref_shaped = None
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.cpu_procs, args.cpu_seconds)      # before the GPU is touched
         cpu_ref_shaped = cpu_baseline_reference_shaped()
 
-    _ensure_library(local_rank)
+    if os.environ.get("AMCX_BENCH_SELF_LAUNCHED") != "1":
+        _ensure_library(local_rank)
     import torch
     import torch.distributed as dist
     from amcpy_amd import _lib, synth
     from amcpy_amd.features import features18
 
     dev_index = local_rank % max(1, torch.cuda.device_count()) if args.share_gpu else local_rank
+    if dev_index >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU of its own ({torch.cuda.device_count()} visible); "
+                         "--share-gpu rehearses several ranks on one device")
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    use_dist = world > 1 or "RANK" in os.environ        # launched by torch.distributed.run
+    use_dist = launched
     # stdout carries exactly one JSON line: RCCL prints a version banner to fd 1 when the
     # communicator comes up, so everything until the final print goes to stderr instead
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    rccl_ranks = 1
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -463,6 +563,10 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+        # the world size as the first collective sees it (every rank contributes 1)
+        one = torch.ones(1, dtype=torch.int32, device=dev if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(one)
+        rccl_ranks = int(one.item())
 
     # ---- resident shard: (mods, snr, frames, N) complex64 arena in HBM --------
     n_mods = args.mods
@@ -575,21 +679,30 @@ def main():
 
     # N > 1: the one cross-rank step of the real path -- rank 0 collecting every rank's (F x 18) block
     # (amcpy_amd/sharding.py: one padded float32 tensor gather; device tensors over RCCL) -- timed once, outside
-    # the timed region, so that a multi-GPU run also shows what the gather costs.  Never fatal to the headline.
+    # the timed region, so that a multi-GPU run also shows what the gather costs.  Never fatal to the headline, and
+    # never a hang: every rank reports whether it can take part BEFORE the collective (as run_extraction does), and
+    # all of them skip it if one cannot.
     gather = None
     if use_dist and world > 1:
+        from amcpy_amd.sharding import gather_rows
+        local, problem = None, None
         try:
-            from amcpy_amd.sharding import gather_rows
             local = out.reshape(-1, 18).cpu().numpy()
+        except Exception as exc:
+            problem = f"rank {rank}: {exc!r}"
+        problems = [None] * world
+        dist.all_gather_object(problems, problem)
+        problems = [q for q in problems if q]
+        if problems:
+            gather = {"error": "; ".join(problems)}
+        else:
             dist.barrier()
             t_g = time.perf_counter()
-            full = gather_rows(local, local.shape[0] * world, rank, world)
+            full = gather_rows(local, local.shape[0] * world, rank, world)      # a failure here is a bug: let it propagate
             dist.barrier()
             gather = {"ms": (time.perf_counter() - t_g) * 1e3, "bytes_per_rank": int(local.nbytes),
                       "rows_on_rank0": None if full is None else int(full.shape[0]),
-                      "what": "sharding.gather_rows of one step's result from host memory, all ranks -> rank 0"}
-        except Exception as exc:
-            gather = {"error": repr(exc)}
+                      "what": "sharding.gather_rows, one step's result, all ranks -> rank 0"}
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -603,6 +716,8 @@ def main():
     alg_bytes = (8 * FS + 72) * frames_per_launch
     traffic, traffic_src = _pmc_traffic(frames_per_launch, FS)
     achieved = alg_bytes / mean_launch_s / 1e9
+    # about 3.5 KB: the driver keeps only the tail of a long line, and round 3's 7 KB `parity` block pushed h2d /
+    # wall_incl_d2h_ms out of its record
     rec = {
         "metric": f"IQ frames/sec (18 features, {FS}-sample complex64)",
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -617,6 +732,9 @@ def main():
             "kernel": _lib.kernel_name(FS, _lib.VARIANTS[args.variant]),
             "sharding": f"frames x{world}, no collective on the data path",
         },
+        "rccl_ranks": rccl_ranks,
+        "launcher": ("none" if not launched else
+                     "self" if os.environ.get("AMCX_BENCH_SELF_LAUNCHED") == "1" else "external") + f"/{args.dist_backend}",
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
@@ -631,13 +749,24 @@ def main():
         "wall_incl_d2h_ms": wall_d2h_ms,
         "h2d": h2d,
         "gather": gather,
-        "parity": _parity_block(),
         "cpu_baseline": cpu,
         "cpu_baseline_reference_shaped": cpu_ref_shaped,
+        "parity": _parity_block(),
     }
     sys.stdout.flush()
     os.dup2(real_stdout, 1)
-    print(json.dumps(rec), flush=True)
+    print(json.dumps(_rounded(rec)), flush=True)
+
+
+def _rounded(x):
+    """Six significant digits are more than any of these measurements has: a shorter line."""
+    if isinstance(x, float):
+        return float(f"{x:.6g}")
+    if isinstance(x, dict):
+        return {k: _rounded(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_rounded(v) for v in x]
+    return x
 
 
 if __name__ == "__main__":

@@ -72,7 +72,7 @@ def _assert_parity(got, golden_f64, frames, what, large_sample=False):
     assert plain[:, strict].max() <= TOL
     if not large_sample:
         assert worst.max() <= TOL, f"{what}: feature {int(worst.argmax()) + 1} off by {worst.max():.3e}"
-        return
+        return np.zeros(len(scaled), dtype=bool)
     over = (scaled > TOL).any(axis=1)
     print(f"[{what}] frames beyond the unfloored criterion: {int(over.sum())} of {len(over)}"
           f" (worst {scaled.max():.2e})")
@@ -82,6 +82,26 @@ def _assert_parity(got, golden_f64, frames, what, large_sample=False):
     S_floor = np.maximum(S, SUM_FLOOR * orc.conditioning_scales(frames, absolute=True))
     _, scaled_f = orc.parity_errors(got, golden_f64.astype(np.float32), S_floor)
     assert scaled_f.max() <= TOL, f"{what}: feature {int(scaled_f.max(axis=0).argmax()) + 1} off by {scaled_f.max():.3e}"
+    return over
+
+
+def test_oracle_pin_holds_on_this_box(golden_frames):
+    """The checker checked where it is used: this box's numpy / scipy are not the build container's, and every test
+    below trusts oracle.features18_batch.  The same comparisons tests/test_oracle.py makes on the CPU -- the oracle's
+    reference-shaped and fused evaluators against what the imported reference produced (tests/golden, captured by
+    oracle/capture_golden.py) -- run here too."""
+    from tests import test_oracle as pin
+    pin.test_reference_shaped_matches_reference_outputs(golden_frames)
+    pin.test_fused_matches_reference_outputs(golden_frames)
+    pin.test_moments_match_reference(golden_frames)
+
+
+def test_oracle_pin_edges_and_known_answers_on_this_box(golden_edges, kat):
+    """... and the degenerate frames and the reference's own known-answer table (features.py:286-305)."""
+    from tests import test_oracle as pin
+    pin.test_kat_reference_shaped(kat)
+    pin.test_kat_fused(kat)
+    pin.test_edges_fused_vs_reference(golden_edges)
 
 
 def test_library_loads_and_sees_gpu():
@@ -486,7 +506,7 @@ def test_two_ranks_run_extraction_sharded(tmp_path):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), AMCX_REPO=repo, AMCX_ROOT=str(roots["sharded"]),
                    AMCX_NFRAMES=str(n_frames), AMCX_FS=str(fs), PYTHONDONTWRITEBYTECODE="1",
-                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", AMCX_SHARE_GPU="1")      # both ranks on the box's one GPU, on purpose
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=300)[0] for p in procs]
@@ -770,10 +790,22 @@ def test_run_extraction_on_a_container_of_genuine_doubles(tmp_path):
                        f"genuine doubles {m}")
 
 
+# Frames of the configs[0] container (synth.host_frames, the seeds of SURVEY 8d) that miss the UNFLOORED criterion
+# |got - golden64| <= 1e-5 max(|golden64|, S) with the kernels of this round: {modulation: flat frame indices}.  Every
+# other one of the 6 000 frames meets it -- configs[0] is judged by the strict rule too, not only by the large-sample
+# one.  (A frame lands here when a whole sixth-order moment cancels by chance -- |mean x^6| = 0.003 where mean |x|^6 = 7
+# -- so that S collapses; its absolute error is 1e-8 of the summands' scale.  DESIGN.md section 2.)
+CLI_UNFLOORED_EXCEPTIONS = {"WGN": []}
+
+
 def test_extract_cli_on_the_configs0_shape(tmp_path):
     """`python -m amcpy_amd extract` as a subprocess on BASELINE configs[0]: 6 modulations x 2 SNR
     x 500 frames x 2048 samples in mat-data/all_modulations.mat -> six {mod}_features.mat, checked
-    against the oracle (reference CLI: main.py:32,85-87,160-175)."""
+    against the oracle (reference CLI: main.py:32,85-87,160-175).  Then the SAME command over several devices --
+    `--devices 0,0`: two engines inside the one process, frames cut across them -- and as two ranks of an external
+    launcher (torch.distributed.run; every rank takes its LOCAL_RANK's GPU and joins the process group itself):
+    both must write files bit-identical to the single-device run."""
+    import socket
     import subprocess
     import sys
     import scipy.io
@@ -787,20 +819,58 @@ def test_extract_cli_on_the_configs0_shape(tmp_path):
     scipy.io.savemat(str(cfg.paths.mat_data / cfg.paths.mat_filename),
                      {cfg.signals.mat_info[m]: blocks[m] for m in synth.MODS6})
     repo = str(Path(__file__).resolve().parents[1])
-    env = dict(os.environ, PYTHONPATH=repo + os.pathsep + os.environ.get("PYTHONPATH", ""),
-               PYTHONDONTWRITEBYTECODE="1")
-    r = subprocess.run([sys.executable, "-m", "amcpy_amd", "extract", "--root", str(tmp_path),
-                        "--num-frames", str(n_frames), "--frame-size", str(fs), "--snr-values", "0", "10"],
-                       env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    env = _launcher_free_env()
+    env["PYTHONPATH"] = repo + os.pathsep + os.environ.get("PYTHONPATH", "")
+    base = [sys.executable, "-m", "amcpy_amd", "extract", "--root", str(tmp_path),
+            "--num-frames", str(n_frames), "--frame-size", str(fs), "--snr-values", "0", "10"]
+    r = subprocess.run(base, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "All feature calculations complete!" in r.stdout
+
+    def read_all():
+        out = {}
+        for m in synth.MODS6:
+            d = scipy.io.loadmat(str(cfg.paths.calculated_features / f"{m}_features.mat"))
+            assert sorted(k for k in d if not k.startswith("__")) == sorted(["Modulation", cfg.signals.mat_info[m]])
+            out[m] = d[cfg.signals.mat_info[m]]
+            (cfg.paths.calculated_features / f"{m}_features.mat").unlink()
+        return out
+
+    single = read_all()
     for m in synth.MODS6:
-        d = scipy.io.loadmat(str(cfg.paths.calculated_features / f"{m}_features.mat"))
-        assert sorted(k for k in d if not k.startswith("__")) == sorted(["Modulation", cfg.signals.mat_info[m]])
-        arr = d[cfg.signals.mat_info[m]]
+        arr = single[m]
         assert arr.dtype == np.float32 and arr.shape == (n_snr, n_frames, 18)
         x = blocks[m].reshape(-1, fs)
-        _assert_parity(arr.reshape(-1, 18), orc.features18_batch(x), x, f"CLI extract {m}", large_sample=True)
+        over = _assert_parity(arr.reshape(-1, 18), orc.features18_batch(x), x, f"CLI extract {m}", large_sample=True)
+        # ... and the strict rule on every frame that is not a pinned exception
+        extra = sorted(set(np.flatnonzero(over).tolist()) - set(CLI_UNFLOORED_EXCEPTIONS.get(m, [])))
+        assert not extra, f"{m}: frames {extra} miss the unfloored criterion and are not pinned exceptions"
+    # several devices from the one process
+    r = subprocess.run(base + ["--devices", "0,0"], env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    fanned = read_all()
+    for m in synth.MODS6:
+        assert np.array_equal(single[m].view(np.int32), fanned[m].view(np.int32)), m
+    # two ranks of an external launcher (gloo + one shared GPU on this box; RCCL and one GPU each on a node)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "amcpy_amd", *base[3:]]
+    r = subprocess.run(cmd, env=dict(env, AMCX_SHARE_GPU="1", AMCX_DIST_BACKEND="gloo"), cwd=str(tmp_path),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    ranked = read_all()
+    for m in synth.MODS6:
+        assert np.array_equal(single[m].view(np.int32), ranked[m].view(np.int32)), m
+    # the same launch WITHOUT saying that the GPU is shared is refused on every rank (one GPU on this box)
+    if _torch().cuda.device_count() == 1:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            cmd[cmd.index("--master-port") + 1] = str(sk.getsockname()[1])
+        r = subprocess.run(cmd, env=dict(env, AMCX_DIST_BACKEND="gloo"), cwd=str(tmp_path),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode != 0 and "no GPU 1" in (r.stdout + r.stderr), r.stdout[-2000:] + r.stderr[-2000:]
     bad = subprocess.run([sys.executable, "-m", "amcpy_amd", "extract", "--root", str(tmp_path / "nowhere")],
                          env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0                                                # a missing container is an error
@@ -1046,40 +1116,71 @@ def test_no_worse_than_the_references_own_complex64_path(N):
         assert bad.size == 0, (variant, [(int(i), ids[j] + 1, got[i, ids[j]], g64[i, ids[j]], g32[i, ids[j]]) for i, j in bad[:5]])
 
 
-def test_bench_two_ranks_on_one_gpu(tmp_path):
-    """bench.py's N > 1 branch before the driver runs it on a real node: two ranks under
-    torch.distributed.run, launched exactly as the driver does, rehearsed on the box's one GPU (gloo for
-    the barrier / MAX since RCCL refuses two ranks on one device; --share-gpu maps both ranks to it).
-    Exactly one JSON line reaches stdout, it says n_gpus 2, and value x wall equals the frames both
-    ranks processed."""
+def _check_two_rank_line(stdout):
     import json
-    import socket
-    import subprocess
-    import sys
-    repo = Path(__file__).resolve().parents[1]
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONDONTWRITEBYTECODE="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), str(repo / "bench.py"),
-           "--gpus", "2", "--steps", "3", "--warmup", "2", "--frames", "64", "--dist-backend", "gloo", "--share-gpu"]
-    r = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1, r.stdout
+    lines = [ln for ln in stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, stdout
+    assert len(lines[0]) <= 4096, len(lines[0])                 # the driver keeps only the tail of a long line
     rec = json.loads(lines[0])
     per_rank = 6 * 26 * 64
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 2 and rec["scaling"] == "weak"
+    assert rec["rccl_ranks"] == 2
     assert rec["config"]["frames_per_gpu_per_step"] == per_rank and rec["cpu_baseline"] is None and rec["h2d"] is None
     total = rec["value"] * rec["ms_per_step"] * 1e-3 * rec["steps"]
     assert abs(total - 2 * per_rank * 3) < 1e-3 * total, (total, rec["value"], rec["ms_per_step"])
     assert rec["roofline"]["launch_ms_min"] <= rec["roofline"]["launch_ms_median"] <= rec["roofline"]["launch_ms_max"]
     assert rec["gather"]["rows_on_rank0"] == 2 * per_rank and rec["gather"]["bytes_per_rank"] == per_rank * 72, rec["gather"]
-    # and a mismatch between --gpus and the launch is refused, not silently run as one rank
-    bad = subprocess.run([sys.executable, str(repo / "bench.py"), "--gpus", "2", "--no-cpu-baseline"], env=env,
+    return rec
+
+
+def _launcher_free_env():
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                        "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID", "AMCX_BENCH_SELF_LAUNCHED")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONDONTWRITEBYTECODE="1")
+    return env
+
+
+def test_bench_two_ranks_on_one_gpu(tmp_path):
+    """bench.py's N > 1 branch before the driver runs it on a real node, rehearsed on the box's one GPU (gloo for the
+    barrier / MAX since RCCL refuses two ranks on one device; --share-gpu maps both ranks to it), started BOTH ways:
+    `python bench.py --gpus 2` from a launcher-free environment -- the script starts its own two ranks, as the
+    reference's run_extraction forks its own workers (feature_extraction.py:89-97) -- and under torch.distributed.run
+    as the driver's multi-GPU command line does.  Either way exactly one JSON line of at most 4 KB reaches stdout, it
+    says n_gpus 2 and rccl_ranks 2, and value x wall equals the frames both ranks processed."""
+    import socket
+    import subprocess
+    import sys
+    repo = Path(__file__).resolve().parents[1]
+    env = _launcher_free_env()
+    flags = ["--gpus", "2", "--steps", "3", "--warmup", "2", "--frames", "64", "--dist-backend", "gloo", "--share-gpu"]
+    # 1. by itself
+    r = subprocess.run([sys.executable, str(repo / "bench.py"), *flags], env=env, cwd=str(tmp_path),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert _check_two_rank_line(r.stdout)["launcher"] == "self/gloo"
+    # 2. under the external launcher
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(repo / "bench.py"), *flags]
+    r = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert _check_two_rank_line(r.stdout)["launcher"] == "external/gloo"
+    # 3. a launcher that started a different number of ranks than --gpus says is refused, not silently run
+    bad = subprocess.run([sys.executable, str(repo / "bench.py"), "--gpus", "2", "--no-cpu-baseline"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
                          cwd=str(tmp_path), capture_output=True, text=True, timeout=120)
-    assert bad.returncode != 0 and "torch.distributed.run" in (bad.stdout + bad.stderr)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in (bad.stdout + bad.stderr)
+    # 4. a rank that fails takes the job down with its exit code and leaves no rank behind (two ranks, no
+    #    --share-gpu: rank 1 has no GPU of its own on this one-GPU box and says so)
+    if _torch().cuda.device_count() == 1:
+        bad = subprocess.run([sys.executable, str(repo / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                              "--frames", "8", "--dist-backend", "gloo", "--launch-timeout", "120"],
+                             env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+        assert bad.returncode != 0 and "no GPU of its own" in bad.stderr, bad.stderr[-2000:]
+        assert not [ln for ln in bad.stdout.splitlines() if ln.strip()], bad.stdout
 
 
 def test_strided_engine_on_random_layouts():

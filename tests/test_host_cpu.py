@@ -497,6 +497,15 @@ def test_mat_reader_returns_views_equal_to_loadmat(tmp_path):
         assert np.array_equal(load_variable(path, "ints"), ref["ints"])           # ... scipy's
         with pytest.raises(KeyError):
             load_variable(path, "signal_nope")
+    # an element the fast reader cannot even name (an empty array: its inflated header is under 64 bytes) must not turn
+    # "I do not know" into "no such variable": scipy reads it
+    for compress in (False, True):
+        path = tmp_path / f"tiny_{int(compress)}.mat"
+        scipy.io.savemat(str(path), {"tiny": np.zeros((0, 0)), "signal_bpsk": c128}, do_compression=compress)
+        assert load_variable(path, "tiny").shape == (0, 0)
+        assert np.array_equal(load_variable(path, "signal_bpsk")[:, :, :], c128)
+        with pytest.raises(KeyError):
+            load_variable(path, "signal_nope")
     junk = tmp_path / "junk.mat"
     junk.write_bytes(b"not a mat file at all" * 20)
     with pytest.raises(Exception):
@@ -708,13 +717,15 @@ def test_native_staging_on_random_layouts():
 
 
 def test_opting_out_of_torch_is_all_or_nothing(tmp_path):
-    """AMCX_SKIP_TORCH=1 (what `python -m amcpy_amd extract` sets for itself): the library loads without importing
-    torch, the host-container path works from there, and the tensor entry point refuses instead of handing torch's
-    device pointers to a second HIP runtime."""
+    """Loading the library without torch -- ``_lib.load(skip_torch=True)``, what `python -m amcpy_amd` does for
+    itself, or AMCX_SKIP_TORCH=1 in the environment: the library loads without importing torch, the host-container
+    path works from there, and the tensor entry point refuses instead of handing torch's device pointers to a second
+    HIP runtime.  The opt-out belongs to that first load: ``main([...])`` called in-process neither skips torch nor
+    writes to os.environ, so tensors keep working afterwards."""
     code = textwrap.dedent("""
-        import sys
+        import os, sys
         from amcpy_amd import _lib
-        _lib.load()
+        _lib.load(skip_torch=%r)
         assert "torch" not in sys.modules, "the library pulled torch in"
         from amcpy_amd.feature_extraction import _rank_world
         assert _rank_world() == (0, 1) and "torch" not in sys.modules
@@ -722,12 +733,31 @@ def test_opting_out_of_torch_is_all_or_nothing(tmp_path):
         try:
             features18(None)
         except RuntimeError as exc:
-            assert "AMCX_SKIP_TORCH" in str(exc)
+            assert "skip_torch" in str(exc)
             print("REFUSED")
     """)
-    env = dict(os.environ, AMCX_SKIP_TORCH="1", PYTHONPATH=str(REPO), PYTHONDONTWRITEBYTECODE="1")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
-    assert r.returncode == 0 and "REFUSED" in r.stdout, r.stdout + r.stderr
+    base = {k: v for k, v in os.environ.items() if k != "AMCX_SKIP_TORCH"}
+    base.update(PYTHONPATH=str(REPO), PYTHONDONTWRITEBYTECODE="1")
+    for env, flag in ((dict(base, AMCX_SKIP_TORCH="1"), False), (base, True)):
+        r = subprocess.run([sys.executable, "-c", code % flag], env=env, capture_output=True, text=True, timeout=300,
+                           cwd=str(tmp_path))
+        assert r.returncode == 0 and "REFUSED" in r.stdout, r.stdout + r.stderr
+    # in-process use of the command line's entry point: no opt-out, nothing written to the environment
+    code = textwrap.dedent("""
+        import os, sys
+        from amcpy_amd.main import main
+        try:
+            main(["extract", "--root", %r, "--num-frames", "1", "--frame-size", "128", "--snr-values", "0"])
+        except Exception as exc:                       # no container there (and no GPU here): the point is what came before
+            print("RAISED", type(exc).__name__)
+        from amcpy_amd import _lib
+        assert "AMCX_SKIP_TORCH" not in os.environ
+        assert "torch" in sys.modules and _lib.torch_wanted()
+        _lib.require_torch_runtime()
+        print("TENSORS-OK")
+    """) % str(tmp_path)
+    r = subprocess.run([sys.executable, "-c", code], env=base, capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert r.returncode == 0 and "TENSORS-OK" in r.stdout, r.stdout + r.stderr
 
 
 def test_eight_rank_run_extraction_over_gloo(tmp_path):
@@ -943,3 +973,273 @@ def test_read_ahead_depth_follows_the_container(tmp_path, monkeypatch):
     assert fe._read_ahead(1 << 50, 6) == 1                      # a variable that does not fit: one at a time
     monkeypatch.setenv("AMCX_READ_AHEAD", "4")
     assert fe._read_ahead(0, 6) == 4
+
+
+def _alive(pid: int) -> bool:
+    try:
+        os.kill(pid, 0)
+    except ProcessLookupError:
+        return False
+    try:                                   # a zombie still answers kill(0)
+        return open(f"/proc/{pid}/stat").read().split(")")[1].split()[0] != "Z"
+    except OSError:
+        return False
+
+
+def test_bench_self_launch_process_handling(tmp_path):
+    """`python bench.py --gpus N` without a launcher starts its own ranks (bench.self_launch; the reference's
+    run_extraction forks its own workers, feature_extraction.py:89-97).  The process handling, on stand-in rank
+    scripts (no GPU here): every rank gets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, only rank 0 owns stdout, a rank's
+    non-zero exit becomes the job's and the ranks still running are killed, a time limit kills them all, and a
+    clean run returns 0."""
+    import time
+    sys.path.insert(0, str(REPO))
+    import bench
+    script = tmp_path / "rank.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys, time, pathlib
+        r, w = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        assert os.environ["LOCAL_RANK"] == str(r) and os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0
+        pathlib.Path(sys.argv[2], f"pid{r}").write_text(str(os.getpid()))
+        print(f"line from rank {r} of {w}", flush=True)
+        mode = sys.argv[1]
+        if mode == "ok":
+            sys.exit(0)
+        if mode == "fail1" and r == 1:
+            sys.exit(7)
+        time.sleep(600)
+    """))
+
+    def run(mode, n, limit):
+        d = tmp_path / mode
+        d.mkdir()
+        code = ("import sys; sys.path.insert(0, %r); import bench; "
+                "sys.exit(bench.self_launch(%d, [%r, %r], %r, script=%r, build=False))"
+                % (str(REPO), n, mode, str(d), limit, str(script)))
+        t0 = time.time()
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+        pids = [int((d / f"pid{k}").read_text()) for k in range(n)]
+        return r, pids, time.time() - t0
+
+    r, pids, _ = run("ok", 3, 60.0)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.splitlines() == ["line from rank 0 of 3"]                       # ranks 1, 2 speak on stderr
+    assert "line from rank 1 of 3" in r.stderr and "line from rank 2 of 3" in r.stderr
+    r, pids, took = run("fail1", 2, 60.0)
+    assert r.returncode == 7 and "rank 1 exited with 7" in r.stderr, (r.returncode, r.stderr)
+    assert took < 40 and not any(_alive(p) for p in pids), pids                  # rank 0 was asleep for 600 s
+    r, pids, took = run("hang", 2, 2.0)
+    assert r.returncode == 124 and not any(_alive(p) for p in pids), (r.returncode, r.stderr)
+    # the parent dying takes the ranks with it (PR_SET_PDEATHSIG)
+    d = tmp_path / "orphan"
+    d.mkdir()
+    code = ("import sys; sys.path.insert(0, %r); import bench; "
+            "sys.exit(bench.self_launch(2, ['hang', %r], 300.0, script=%r, build=False))" % (str(REPO), str(d), str(script)))
+    parent = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    deadline = time.time() + 30
+    while time.time() < deadline and not ((d / "pid0").exists() and (d / "pid1").exists()):
+        time.sleep(0.05)
+    time.sleep(0.2)
+    pids = [int((d / f"pid{k}").read_text()) for k in range(2)]
+    parent.kill()
+    parent.wait()
+    deadline = time.time() + 10
+    while time.time() < deadline and any(_alive(p) for p in pids):
+        time.sleep(0.05)
+    assert not any(_alive(p) for p in pids), pids
+
+
+def test_bench_refuses_a_launch_that_disagrees_with_gpus(tmp_path):
+    """--gpus 2 under a launcher that started one rank is an error (nothing is silently run as one rank); --gpus 2 with
+    no launcher starts two ranks, which on a box without GPUs say so and exit non-zero, leaving nothing behind."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    bad = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--no-cpu-baseline"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), cwd=str(tmp_path),
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr
+    import torch
+    if torch.cuda.device_count() == 0:
+        r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--dist-backend", "gloo",
+                            "--launch-timeout", "100"], env=env, cwd=str(tmp_path), capture_output=True, text=True,
+                           timeout=200)
+        assert r.returncode != 0 and "no GPU of its own" in r.stderr and not r.stdout.strip(), (r.stdout, r.stderr[-1500:])
+
+
+def _marker_features(block):
+    """A stand-in engine: 18 columns that depend on every sample of the frame."""
+    block = np.asarray(block)
+    base = np.abs(block).sum(axis=1, dtype=np.float64) + np.real(block[:, 0])
+    return (base[:, None] * np.arange(1, 19)[None, :]).astype(np.float32)
+
+
+@pytest.mark.parametrize("n_snr,n_frames,devices", [(3, 40, [0, 1, 2, 3]), (5, 3, [0, 1, 2, 3]), (2, 9, [0, 0]),
+                                                    (1, 1, [0, 1, 2])])
+def test_device_fan_out_cuts_and_reassembles(n_snr, n_frames, devices):
+    """feature_extraction.DeviceFanOut -- several GPUs from ONE process, what `extract --devices` drives -- with
+    stand-in engines (no GPU here): a whole container is cut along its frame axis when that balances and along the
+    snr-major flattening otherwise, every frame is computed exactly once, and the rows come back in the snr-major
+    order of a single engine's result, from Fortran- and C-ordered containers alike."""
+    from amcpy_amd import feature_extraction as fe
+    from amcpy_amd.sharding import shard_by_frames
+    rng = np.random.default_rng(5)
+    N = 12
+    full = rng.standard_normal((n_snr, n_frames + 2, N + 3)) + 1j * rng.standard_normal((n_snr, n_frames + 2, N + 3))
+    for parsed in (np.asfortranarray(full), np.ascontiguousarray(full)):
+        fan = fe.DeviceFanOut(N, devices, threads=2)
+        seen = []
+
+        class Stub:
+            def __init__(self, dev):
+                self.device, self.stats = dev, {}
+
+            def __call__(self, rows):
+                arr = rows.to_array()[:, :N]
+                seen.append((self.device, type(rows).__name__, arr.shape[0]))
+                return _marker_features(arr)
+
+        fan.engines = [Stub(d) for d in devices]
+        rows = fe.FrameRows(parsed, n_snr, n_frames)
+        got = fan(rows)
+        want = _marker_features(rows.to_array()[:, :N])
+        assert got.shape == (n_snr * n_frames, 18) and np.array_equal(got, want)
+        assert sum(n for _, _, n in seen) == n_snr * n_frames
+        by_frames = shard_by_frames(n_snr, n_frames, len(devices))
+        assert {t for _, t, n in seen if n} == ({"FrameColumns"} if by_frames else {"FrameRows"})
+        # a range that starts inside an snr row goes by the flattening
+        part = rows.slice(1, n_snr * n_frames)
+        assert np.array_equal(fan(part), want[1:])
+        fan.close()
+
+
+def test_device_fan_out_reports_every_failing_device():
+    from amcpy_amd import feature_extraction as fe
+    fan = fe.DeviceFanOut(8, [0, 1, 2], threads=1)
+
+    def ok(rows):
+        return np.zeros((rows.shape[0], 18), np.float32)
+
+    def boom(rows):
+        raise OSError("no such device")
+
+    fan.engines = [ok, boom, boom]
+    x = np.zeros((1, 9, 8), np.complex64)
+    with pytest.raises(RuntimeError) as err:
+        fan(fe.FrameRows(x, 1, 9))
+    assert "device 1: OSError" in str(err.value) and "device 2: OSError" in str(err.value)
+    fan.close()
+    with pytest.raises(ValueError):
+        fe.DeviceFanOut(8, [])
+    with pytest.raises(ValueError):
+        fe.DeviceFanOut(8, [-1])
+
+
+def test_extract_cli_device_arguments(tmp_path):
+    from amcpy_amd import main as cli
+    assert cli._parse_devices("0,1,3") == [0, 1, 3] and cli._parse_devices("2") == [2] and cli._parse_devices("0,0") == [0, 0]
+    for bad in ("", "a,b", "0,-1"):
+        with pytest.raises(SystemExit):
+            cli._parse_devices(bad)
+    import torch
+    if torch.cuda.device_count() == 0:
+        with pytest.raises(SystemExit):
+            cli._parse_devices("all")                            # says that no device is visible
+    with pytest.raises(SystemExit):
+        cli.main(["extract", "--root", str(tmp_path), "--device", "0", "--devices", "0,1"])
+    from amcpy_amd.config import Config, Paths
+    from amcpy_amd.feature_extraction import run_extraction
+    with pytest.raises(ValueError):
+        run_extraction(Config(paths=Paths(root=tmp_path)), devices=[0, 1], device=0)
+
+
+_PLACEMENT_WORKER = textwrap.dedent('''
+    import os, sys
+    import numpy as np
+    import torch.distributed as dist
+    sys.path.insert(0, os.environ["AMCX_REPO"])
+    from pathlib import Path
+    from amcpy_amd.config import Config, Paths, SignalConfig
+    from amcpy_amd import feature_extraction as fe
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class OnDevice:                                   # an engine that says which GPU it computes on
+        device = int(os.environ["AMCX_TEST_DEVICES"].split(",")[rank])
+        def __call__(self, rows):
+            return np.zeros((rows.shape[0], 18), dtype=np.float32)
+
+    fe.default_engine = lambda *a, **k: OnDevice()
+    cfg = Config(paths=Paths(root=Path(os.environ["AMCX_ROOT"])),
+                 signals=SignalConfig(snr_values={0: "0", 1: "10", 2: "20"}, num_frames=7, frame_size=16))
+    try:
+        fe.run_extraction(cfg, verbose=False)
+    except RuntimeError as exc:
+        print("RAISED", rank, exc)
+        dist.destroy_process_group()
+        sys.exit(3)
+    print("NO ERROR", rank)
+    dist.destroy_process_group()
+''')
+
+
+def test_ranks_sharing_a_device_are_refused(tmp_path):
+    """Several ranks whose engines sit on ONE device of one host (a launcher whose ranks never chose their GPU) would be
+    silently correct and world-size times slow: run_extraction all-gathers (host, device) once and every rank raises,
+    unless AMCX_SHARE_GPU=1 says the sharing is meant.  Distinct devices pass."""
+    import scipy.io
+    from amcpy_amd.config import Config, Paths, SignalConfig
+    rng = np.random.default_rng(3)
+    cfg = Config(paths=Paths(root=tmp_path),
+                 signals=SignalConfig(snr_values={0: "0", 1: "10", 2: "20"}, num_frames=7, frame_size=16))
+    cfg.paths.ensure_dirs()
+    scipy.io.savemat(str(cfg.paths.mat_data / cfg.paths.mat_filename),
+                     {cfg.signals.mat_info[m]: (rng.standard_normal((3, 7, 16)) + 1j * rng.standard_normal((3, 7, 16)))
+                      for m in cfg.signals.modulations_with_noise})
+    script = tmp_path / "placement_worker.py"
+    script.write_text(_PLACEMENT_WORKER)
+
+    def run(devices, share):
+        port = _free_port()
+        procs = []
+        for r in range(2):
+            env = {k: v for k, v in os.environ.items() if k != "AMCX_SHARE_GPU"}
+            env.update(RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AMCX_REPO=str(REPO),
+                       AMCX_ROOT=str(tmp_path), AMCX_TEST_DEVICES=devices, PYTHONDONTWRITEBYTECODE="1")
+            if share:
+                env["AMCX_SHARE_GPU"] = "1"
+            procs.append(subprocess.Popen([sys.executable, str(script)], env=env,
+                                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        outs = [p.communicate(timeout=120)[0] for p in procs]
+        return [p.returncode for p in procs], outs
+
+    codes, outs = run("0,0", share=False)
+    assert codes == [3, 3], "\n".join(outs)
+    assert all("ranks 0 and 1 both compute on device 0" in o for o in outs), outs
+    codes, outs = run("0,0", share=True)
+    assert codes == [0, 0] and all("NO ERROR" in o for o in outs), "\n".join(outs)
+    codes, outs = run("0,1", share=False)
+    assert codes == [0, 0] and all("NO ERROR" in o for o in outs), "\n".join(outs)
+
+
+@pytest.mark.parametrize("name,flags", [
+    ("asan_ubsan", ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all"]),
+    ("tsan", ["-O1", "-g", "-fsanitize=thread"]),
+    ("plain", ["-O2"])])
+def test_staging_half_under_the_sanitizers(tmp_path, name, flags):
+    """The host half of the real-data path -- amcx_upload.h: the hand-rolled fork-join Pool, stage_runs over memory
+    and FILE sources, the layout classifier -- compiled with g++ alone (no HIP) and run under AddressSanitizer +
+    UBSan, under ThreadSanitizer, and as the product builds it: 60 random layouts against an element-by-element
+    restatement (30 of them also read from a file, and from that file cut short), 1 000 back-to-back Pool::run calls
+    with resizes and sleeping workers in between, three pools staging at once (one per device: DeviceFanOut).  The
+    reference's own defect on this path is a threading one (feature_extraction.py:22-39,74)."""
+    exe = tmp_path / f"stage_fuzz_{name}"
+    cmd = ["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-pthread", *flags,
+           str(REPO / "tests" / "host_san" / "stage_fuzz.cc"), "-o", str(exe)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-4000:]
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 second_deadlock_stack=1", ASAN_OPTIONS="detect_leaks=1",
+               UBSAN_OPTIONS="print_stacktrace=1")
+    for seed in ("2026", "7"):
+        r = subprocess.run([str(exe), seed], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "STAGE_FUZZ_OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-6000:])
+        assert "WARNING: ThreadSanitizer" not in r.stderr and "ERROR: AddressSanitizer" not in r.stderr \
+            and "runtime error" not in r.stderr, r.stderr[-6000:]
