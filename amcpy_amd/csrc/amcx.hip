@@ -12,6 +12,9 @@
 #include "amcx_block_kernel.h"
 #include "amcx_wave_kernel.h"
 #include "amcx_quad_kernel.h"
+#ifdef AMCX_EXP_PAIR4096      // experiment: two waves per frame at N = 4096 (measured 1.7 % slower: profiles/r4_pair_vs_wave4096_ab.txt)
+#include "amcx_pair_kernel.h"
+#endif
 #include "amcx_fixup_kernel.h"
 #include "amcx_post_kernels.h"
 #include "amcx_pack_kernel.h"
@@ -192,9 +195,15 @@ int amcx_features18_c64_ex(const void* iq_dev, int64_t n_frames, int32_t frame_s
   const float2* iq = static_cast<const float2*>(iq_dev);
   if (v == AMCX_VARIANT_WAVE) {
     // N = 8192: four waves per frame (amcx_quad_kernel.h); every other wave size: one wave per frame
-    hipError_t e = frame_size == amcx::quad::kN
-        ? amcx::quad::launch_quad(iq, n_frames, row_stride_elems, out_dev, out_row_stride, stream, cu_count())
-        : amcx::launch_wave(iq, n_frames, frame_size, row_stride_elems, out_dev, out_row_stride, stream, cu_count());
+    hipError_t e;
+    if (frame_size == amcx::quad::kN)
+      e = amcx::quad::launch_quad(iq, n_frames, row_stride_elems, out_dev, out_row_stride, stream, cu_count());
+#ifdef AMCX_EXP_PAIR4096
+    else if (frame_size == amcx::pair::kN)
+      e = amcx::pair::launch_pair(iq, n_frames, row_stride_elems, out_dev, out_row_stride, stream, cu_count());
+#endif
+    else
+      e = amcx::launch_wave(iq, n_frames, frame_size, row_stride_elems, out_dev, out_row_stride, stream, cu_count());
     if (e != hipSuccess) return hip_fail(e, "wave kernel launch");
     // frames the fp32 kernel flagged as outside its range (f5 = -inf): the range pass of the same wave machine
     // on a power-of-two pre-scaled copy (N = 1024, 2048, 4096), or the block kernel's fp64-sum routine (other N).

@@ -187,27 +187,9 @@ __global__ __launch_bounds__(kThreads, 2) void amcx_features18_quad_kernel(
   float* stash_q = reinterpret_cast<float*>(smem + kOffStash);
   float* mu_part = reinterpret_cast<float*>(smem + kOffMu);
 
-  // ---- tables of the 2048-point register FFT (as amcx_wave_kernel.h builds them for N = 2048) ----
-  auto w_nf = [](int e) {
-    float sn, cs;
-    sincospif((float)(e & (C2::kFftN - 1)) * (2.0f / (float)C2::kFftN), &sn, &cs);
-    return make_float2(cs, -sn);
-  };
+  // ---- tables of the 2048-point register FFT ----
   constexpr int R = C2::kFftRows;                           // 16
-  for (int e = tid; e < 8 * C2::kPhases * 15; e += kThreads) {
-    const int slot = e / 15, i = e % 15;
-    const int k1 = 2 * (slot & 7) + (slot >> 3);
-    const int sidx = i < 1 ? 0 : i < 3 ? 1 : i < 7 ? 2 : 3;
-    const int k = i - ((1 << sidx) - 1), Lp = 2 << sidx, d = 16 / Lp;
-    reinterpret_cast<float2*>(t2)[e] = w_nf(8 * k1 * d + k * (C2::kFftN / Lp));
-  }
-  for (int e = tid; e < C2::kPhases * 2 * 7 * 64; e += kThreads) {
-    const int ln = e & 63, i = (e >> 6) % 7, c = e / (7 * 64);
-    const int k1 = 2 * (ln >> 3) + (c >> 1), k2 = (ln & 7) + 8 * (c & 1);
-    const int sidx = i < 1 ? 0 : i < 3 ? 1 : 2;
-    const int k = i - ((1 << sidx) - 1), Lp = 2 << sidx, d = 8 / Lp;
-    reinterpret_cast<float2*>(t3)[e] = w_nf((R * k2 + k1) * d + k * (C2::kFftN / Lp));
-  }
+  build_fft_tables<C2::kFftN>(t2, t3, tid, kThreads);
   // this lane's twiddles of the radix-4 stage: W_8192^(q (2 l + b)), b = 0, 1
   float4 lw;
   {
@@ -221,7 +203,6 @@ __global__ __launch_bounds__(kThreads, 2) void amcx_features18_quad_kernel(
   const int kkL = lane >> 3, n3L = lane & 7;
   char* ex = fb + q * kRegionBytes;                         // this wave's region: a round's rows, then its FFT exchange buffer
   LaneAddr la;
-  la.t1c = nullptr; la.t2c = nullptr;
   la.tw2 = t2 + kkL * kTw2Stride;
   la.tw3 = t3 + lane * 8;
   la.ex1_w = ex + lane * 8;

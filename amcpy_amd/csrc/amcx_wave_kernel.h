@@ -1,5 +1,6 @@
 // AMCX_VARIANT_WAVE: one wavefront (64 lanes) per frame, frame held in registers.
-// Instantiated for the power-of-two frame sizes 128 ... 8192.
+// Instantiated for the power-of-two frame sizes 128 ... 4096; N = 8192 runs four waves per frame on this header's
+// machinery (amcx_quad_kernel.h), and so does the two-wave experiment at N = 4096 (amcx_pair_kernel.h).
 //
 // Why not "one 256-thread workgroup per frame": this path is bound by the board's power cap
 // and by VALU issue, not by HBM (~105 fp32 VALU instructions per sample; DESIGN.md section
@@ -39,16 +40,17 @@
 // branch: L2 holds 4 MiB per XCD against 12 MiB of frames in flight, so the second
 // read came over the fabric -- FETCH_SIZE 2.0x the algorithmic bytes and 23 % of
 // wave-cycles waiting on it, profiles/r1d_n4096_summary.json.)
-// N = 8192 (64 KiB, more than a wave's registers) puts a second split in front of that:
-//   X[2k] = FFT_4096(x[n] + x[n+4096]),  X[2k+1] = FFT_4096((x[n] - x[n+4096]) W_8192^n).
-// The statistics sweep streams the frame through a rolled loop (unrolled it alone would be
-// 60 KB of code against a 64 KB instruction cache) and each branch re-reads the frame from
-// L2 / Infinity Cache straight into the first butterflies of the 4096-point stage.
+// (Round 4 built the alternative -- two waves per frame at the N = 2048 kernel's 128 registers and 4 waves per SIMD,
+// the halves crossing through LDS: amcx_pair_kernel.h, -DAMCX_EXP_PAIR4096 -- and measured it 1.7 % SLOWER on the same
+// box, profiles/r4_pair_vs_wave4096_ab.txt.  Rounds 1-3 also carried a one-wave N = 8192: two splits, the frame
+// streamed three times, 3.44x the algorithmic traffic, 75 spilled registers; the quad kernel replaced it in round 3
+// and the code was removed in round 4.)
 // Every ds_write_b64 / ds_read_b64 / ds_read_b128 of the exchanges and twiddle
 // tables is bank-conflict free and addressed as lane_base + immediate.
 //
 // One workgroup per CU.  N <= 1024: 768 threads = 12 waves = 3 per SIMD.  N = 2048: 1024 threads = 16 waves = 4 per
-// SIMD (128 VGPRs, no spill; the exchange buffer at its exact 8672 bytes and batches of four frames make
+// SIMD (128 VGPRs; one fp64 value of the per-batch finaliser is spilled -- a scratch store and a load per four frames,
+// none in the frame body: amcpy_amd/csrc/kernel_resources.json; the exchange buffer at its exact 8672 bytes and batches of four frames make
 // the LDS fit): 4.3 % fewer SIMD cycles per frame than with 12 waves, of which the power cap takes 2.5 % back
 // as clock -- +1.2 ... +1.9 % frames/s for the kernel alone, +0.5 % through the library's step (DESIGN.md section 4.1;
 // -DAMCX_EXP_WAVES12 builds the 12-wave form).
@@ -79,10 +81,8 @@ constexpr int kTw3Row = 64 * 8;                        // pass 3: [phase][j][7][
 
 template <int N>
 struct Cfg {
-  static_assert(N == 128 || N == 256 || N == 512 || N == 1024 || N == 2048 || N == 4096 || N == 8192,
-                "wave kernel frame sizes");
-  static constexpr bool kSplit = N >= 4096;            // radix-2 DIF split in front of a 2048 FFT
-  static constexpr bool kSplit2 = N == 8192;           // ... and a second one in front of that
+  static_assert(N == 128 || N == 256 || N == 512 || N == 1024 || N == 2048 || N == 4096, "wave kernel frame sizes");
+  static constexpr bool kSplit = N == 4096;            // radix-2 DIF split in front of a 2048 FFT
   // frames per wave per batch, finalised together one frame per lane: the fp64 algebra costs
   // the same per batch whatever N is, so short frames come in larger batches
   // (N = 2048 runs 16 waves per CU, below: batches of four are what its LDS then holds)
@@ -92,9 +92,9 @@ struct Cfg {
   static constexpr int kFramesPerWave = N == 2048 ? 4 : N >= 1024 ? 8 : (N == 512 ? 16 : 32);
 #endif
   // how many times per frame the per-lane fp32 sums are reduced into the stash and started
-  // afresh (the finaliser adds the rows in fp64): at N = 8192 a lane would otherwise run 128
-  // samples into one accumulator, and C40 reached 1.1e-5 of its conditioning scale
-  static constexpr int kFlushes = N == 8192 ? 4 : (N == 4096 ? 2 : 1);
+  // afresh (the finaliser adds the rows in fp64): a lane that runs 64 samples into one accumulator
+  // moves the worst scaled error of the N = 4096 sweep from 5.8e-6 to 6.9e-6
+  static constexpr int kFlushes = N == 4096 ? 2 : 1;
   static constexpr int kStashBytes = kFramesPerWave * kFlushes * kStashStride * 4;
   // next frame of the chunk loaded into a second register set while this one is processed
   static constexpr bool kPrefetch = N <= 1024;
@@ -111,29 +111,20 @@ struct Cfg {
   // the library's step (profiles/r3_waves16_ab.txt)
 #if defined(AMCX_EXP_WAVES12)
   static constexpr int kWavesPerWG = kSplit ? 8 : 12;
-#elif defined(AMCX_EXP_8192_W4)
-  static constexpr int kWavesPerWG = kSplit2 ? 4 : kSplit ? 8 : 12;
 #else
   static constexpr int kWavesPerWG = kSplit ? 8 : (N == 2048 ? 16 : 12);
 #endif
   static constexpr int kThreads = 64 * kWavesPerWG;
   static constexpr int kTailFrames = kWavesPerWG * kFramesPerWave;
   static constexpr int kRows = N / 128;                // rows of 128 samples per frame
-  static constexpr int kHeldRows = kSplit2 ? 32 : kRows;   // rows a wave holds in registers (N = 8192: the lower half)
+  static constexpr int kHeldRows = kRows;              // rows a wave holds in registers
   static constexpr int kFftRows = kSplit ? 16 : kRows; // R: rows one register FFT holds
   static constexpr int kFftN = 128 * kFftRows;
   static constexpr int kPhases = kFftRows >= 8 ? kFftRows / 8 : 1;   // exchange phases of 8 k1 slots
   static constexpr int kT2Bytes = 8 * kPhases * kTw2Stride;          // [k1 slot][15] complex
   static constexpr int kT3Bytes = kPhases * 2 * 7 * kTw3Row;         // [phase][j][7][lane] complex
   static constexpr int kT4Bytes = kSplit ? 64 * 16 : 0;       // [lane][b] complex: W_4096^(2l+b)
-  static constexpr int kT8Bytes = kSplit2 ? 64 * 16 : 0;      // [lane][b] complex: W_8192^(2l+b)
-  // N = 8192 keeps the classic form of passes 2 / 3 (separate twiddle multiplications, fft_peak_classic):
-  // its FFTs run next to 64 live registers of the other branch, and the fused butterflies' extra
-  // operands turned 66 spilled registers into 360 there (28.6 -> 17 M frames/s)
-  static constexpr bool kClassicFft = kSplit2;
-  static constexpr int kT1cBytes = kClassicFft ? 15 * 64 * 16 : 0;   // classic T1 [k1-1][lane][b] complex
-  static constexpr int kT2cBytes = kClassicFft ? 15 * 8 * 8 : 0;     // classic T2 [k2-1][n3] complex
-  static constexpr int kTableBytes = (kClassicFft ? kT1cBytes + kT2cBytes : kT2Bytes + kT3Bytes) + kT4Bytes + kT8Bytes;
+  static constexpr int kTableBytes = kT2Bytes + kT3Bytes + kT4Bytes;
   static constexpr int kCounterOffset = kTableBytes + kWavesPerWG * (kExchangeBytes + kStashBytes);
   static constexpr int kLdsBytes = kCounterOffset + 16;       // + the workgroup's two work counters
   static_assert(kLdsBytes <= 163840, "one workgroup per CU must fit in 160 KiB of LDS");
@@ -528,8 +519,6 @@ struct Stats {
 
 // LDS addresses that depend only on the lane (bytes)
 struct LaneAddr {
-  const char* t1c;    // classic tables (N = 8192 only): T1 + lane*16, T2 + (lane&7)*8
-  const char* t2c;
   const char* tw2;    // pass-2 twiddles of this lane's k1 slot: T2 + (lane>>3)*kTw2Stride
   const char* tw3;    // pass-3 twiddles: T3 + lane*8
   char* ex1_w;        // exchange + lane*8
@@ -690,6 +679,106 @@ __device__ __forceinline__ float fft_peak(const float (&xr)[2 * R], const float 
     }
   }
   float peak = 0.f;
+#if defined(AMCX_ABL_FFT_TAIL) || defined(AMCX_ABL_FFT_TAIL_MFMA)
+  // DIAGNOSTIC builds (tools/wave_clock.hip; results wrong on purpose) for the round-4 question "can passes 2-3 be
+  // replaced by something cheaper that nominates candidate bins?" (tools/coarse_spectrum_model.py):
+  //   AMCX_ABL_FFT_TAIL       pass 1 as it is, passes 2-3 and both exchanges REMOVED (|.|^2 and the maximum kept): the
+  //                           upper bound of any scheme that keeps pass 1 exact;
+  //   AMCX_ABL_FFT_TAIL_MFMA  ... and in their place the instruction mix of the one variant whose candidate count
+  //                           survives a proven error bound: inter-pass twiddles in fp32 (2 x 32 complex products per
+  //                           lane), 2 x 32 conversions to packed fp16, both exchanges through LDS at half width, the
+  //                           matrix operands read back, 8 v_mfma_f32_32x32x16_f16 (pass 2) + 16 v_mfma_f32_16x16x16_f16
+  //                           (pass 3) on those operands, |.|^2 and maximum, a candidate scan and two exact
+  //                           candidate evaluations from the pass-1 output (2 complex multiply-adds + a wave sum each).
+  static_for<PH>([&](auto gg) {
+    constexpr int gph = decltype(gg)::value;
+    dif<8, 8 * gph>(v0r, v0i);
+    dif<8, 8 * gph>(v1r, v1i);
+  });
+#if defined(AMCX_ABL_FFT_TAIL_MFMA)
+  {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef float f16v __attribute__((ext_vector_type(16)));
+    const char* const tw = la.tw3;                       // any per-lane table: 16 x ds_read_b128 of "twiddles" per glue stage
+    h2 zs[32];
+    // glue 1: T1 (fp32 complex products) + conversion
+    static_for<16>([&](auto ii) {
+      constexpr int i = decltype(ii)::value;
+      const float4 t = *reinterpret_cast<const float4*>(tw + (i % 14) * kTw3Row);
+      const float ar = __builtin_fmaf(v0r[i], t.x, -(v0i[i] * t.y)), ai = __builtin_fmaf(v0r[i], t.y, v0i[i] * t.x);
+      const float br = __builtin_fmaf(v1r[i], t.z, -(v1i[i] * t.w)), bi = __builtin_fmaf(v1r[i], t.w, v1i[i] * t.z);
+      zs[2 * i] = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(ar, ai));
+      zs[2 * i + 1] = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(br, bi));
+    });
+    lds_wave_fence();
+    static_for<16>([&](auto ii) {                        // exchange 1 at half width: 16 x ds_write_b64
+      constexpr int i = decltype(ii)::value;
+      *reinterpret_cast<float2*>(la.ex1_w + i * 512) = make_float2(__builtin_bit_cast(float, zs[2 * i]), __builtin_bit_cast(float, zs[2 * i + 1]));
+    });
+    lds_wave_fence();
+    // pass 2: [32 x 32] DFT-16 matrix (two K halves, resident) times 4 column blocks: 8 MFMAs, operands 8 x ds_read_b128
+    const h8 a_lo = *reinterpret_cast<const h8*>(tw), a_hi = *reinterpret_cast<const h8*>(tw + kTw3Row);
+    h2 us[32];
+    static_for<4>([&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      const h8 b0 = *reinterpret_cast<const h8*>(la.ex1_w + c * 2048), b1 = *reinterpret_cast<const h8*>(la.ex1_w + c * 2048 + 1024);
+      f16v d = {};
+      d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b0, d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b1, d, 0, 0, 0);
+      // glue 2: T2 on the block's 8 complex results + conversion
+      const float4 t0 = *reinterpret_cast<const float4*>(tw + (2 * c) * kTw3Row), t1 = *reinterpret_cast<const float4*>(tw + (2 * c + 1) * kTw3Row);
+      static_for<8>([&](auto jj) {
+        constexpr int j = decltype(jj)::value;
+        const float tr = (j & 1) ? t0.x : t1.z, ti = (j & 2) ? t0.y : t1.w;
+        const float ur = __builtin_fmaf(d[j], tr, -(d[j + 8] * ti)), ui = __builtin_fmaf(d[j], ti, d[j + 8] * tr);
+        us[8 * c + j] = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(ur, ui));
+      });
+    });
+    lds_wave_fence();
+    static_for<16>([&](auto ii) {                        // exchange 2 at half width
+      constexpr int i = decltype(ii)::value;
+      *reinterpret_cast<float2*>(la.ex2_w + i * 512) = make_float2(__builtin_bit_cast(float, us[2 * i]), __builtin_bit_cast(float, us[2 * i + 1]));
+    });
+    lds_wave_fence();
+    // pass 3: [16 x 16] DFT-8 matrix times 16 column blocks: 16 MFMAs, operands 16 x ds_read_b64; |.|^2 and maximum
+    const h4 a8 = *reinterpret_cast<const h4*>(tw + 2 * kTw3Row);
+    float mag[32];
+    static_for<16>([&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      const h4 b = *reinterpret_cast<const h4*>(la.ex2_w + c * 512);
+      f4 d = {};
+      d = __builtin_amdgcn_mfma_f32_16x16x16f16(a8, b, d, 0, 0, 0);
+      mag[2 * c] = __builtin_fmaf(d[0], d[0], d[1] * d[1]);
+      mag[2 * c + 1] = __builtin_fmaf(d[2], d[2], d[3] * d[3]);
+      peak = __builtin_fmaxf(__builtin_fmaxf(peak, mag[2 * c]), mag[2 * c + 1]);
+    });
+    // candidate scan: the wave maximum, a threshold, 32 comparisons; then two exact candidates from the pass-1 output
+    const float thr = bcast_l63(wave_max_l63(peak)) * 0.96f;
+    unsigned long long any = 0;
+    static_for<32>([&](auto ee) { any |= __builtin_amdgcn_ballot_w64(mag[decltype(ee)::value] >= thr); });
+    static_for<2>([&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      const float4 t = *reinterpret_cast<const float4*>(tw + (((int)(any >> (8 * c)) & 7) + c) * kTw3Row);
+      float sr = __builtin_fmaf(v0r[c], t.x, -(v0i[c] * t.y)), si = __builtin_fmaf(v0r[c], t.y, v0i[c] * t.x);
+      sr = __builtin_fmaf(v1r[c], t.z, __builtin_fmaf(-v1i[c], t.w, sr));
+      si = __builtin_fmaf(v1r[c], t.w, __builtin_fmaf(v1i[c], t.z, si));
+      sr = wave_sum_l63(sr); si = wave_sum_l63(si);
+      peak = __builtin_fmaxf(peak, __builtin_fmaf(sr, sr, si * si));
+    });
+  }
+#else
+  static_for<R>([&](auto ii) {
+    constexpr int i = decltype(ii)::value;
+    peak = __builtin_fmaxf(__builtin_fmaxf(peak, __builtin_fmaf(v0r[i], v0r[i], v0i[i] * v0i[i])),
+                           __builtin_fmaf(v1r[i], v1r[i], v1i[i] * v1i[i]));
+  });
+#endif
+  lds_wave_fence();
+  return peak;
+#endif
   static_for<PH>([&](auto gg) {
     constexpr int gph = decltype(gg)::value;
     if constexpr (kPkPass1) {
@@ -766,95 +855,6 @@ __device__ __forceinline__ float fft_peak(const float (&xr)[2 * R], const float 
   return peak;
 }
 
-// Round-1 form of the same transform, kept for N = 8192 (Cfg::kClassicFft): pass 1, T1 =
-// W_2048^((2l+b) k1) as a separate complex multiplication, exchange 1 (phase g = k1 >> 3), pass 2
-// (decimation in frequency), T2 = W_128^(n3 k2), exchange 2, pass 3.
-template <int R>
-__device__ __forceinline__ float fft_peak_classic(const float (&xr)[2 * R], const float (&xi)[2 * R],
-                                          const LaneAddr& la) {
-  static_assert(R == 16, "N = 8192 only");
-  constexpr int LOG2R = R == 16 ? 4 : 3;
-  constexpr int PH = R / 8;                  // exchange phases of 8 k1 values
-  // pass 1 (both b groups), twiddle T1, exchange 1
-  float v0r[R], v0i[R], v1r[R], v1i[R];
-  static_for<R>([&](auto ii) {
-    constexpr int i = decltype(ii)::value;
-    v0r[i] = xr[2 * i]; v0i[i] = xi[2 * i]; v1r[i] = xr[2 * i + 1]; v1i[i] = xi[2 * i + 1];
-  });
-  dif<R, 0>(v0r, v0i);
-  dif<R, 0>(v1r, v1i);
-  static_for<R - 1>([&](auto kk1) {
-    constexpr int k1 = decltype(kk1)::value + 1;
-    constexpr int p = bitrev(k1, LOG2R);
-    const float4 t = *reinterpret_cast<const float4*>(la.t1c + (k1 - 1) * 1024);
-    float r = v0r[p], im = v0i[p];
-    v0r[p] = __builtin_fmaf(r, t.x, -(im * t.y));
-    v0i[p] = __builtin_fmaf(r, t.y, im * t.x);
-    r = v1r[p]; im = v1i[p];
-    v1r[p] = __builtin_fmaf(r, t.z, -(im * t.w));
-    v1i[p] = __builtin_fmaf(r, t.w, im * t.z);
-  });
-  float zr[PH][16], zi[PH][16];
-  static_for<PH>([&](auto gg) {
-    constexpr int gph = decltype(gg)::value;
-    lds_wave_fence();
-    static_for<8>([&](auto kk_) {
-      constexpr int kk = decltype(kk_)::value;
-      constexpr int p = bitrev(8 * gph + kk, LOG2R);
-      *reinterpret_cast<float2*>(la.ex1_w + (kk * kEx1StrideKK) * 8) = make_float2(v0r[p], v0i[p]);
-      *reinterpret_cast<float2*>(la.ex1_w + (kk * kEx1StrideKK + kEx1StrideB) * 8) = make_float2(v1r[p], v1i[p]);
-    });
-    lds_wave_fence();
-    static_for<16>([&](auto nn) {
-      constexpr int n2 = decltype(nn)::value;
-      const float2 v = *reinterpret_cast<const float2*>(la.ex1_r + n2 * 32);
-      zr[gph][n2] = v.x; zi[gph][n2] = v.y;
-    });
-  });
-  asm volatile("; MARK fft2");   // not only a marker for tools/isa.sh: without this asm statement the scheduler
-  __builtin_amdgcn_sched_barrier(0);   // merges the two halves and the N = 8192 kernel spills 374 registers instead of 66
-  // pass 2, twiddle T2, exchange 2, pass 3
-  static_for<PH>([&](auto gg) { dif<16, 0>(zr[decltype(gg)::value], zi[decltype(gg)::value]); });
-  static_for<15>([&](auto kk2) {
-    constexpr int k2 = decltype(kk2)::value + 1;
-    constexpr int p = bitrev(k2, 4);
-    const float2 t = *reinterpret_cast<const float2*>(la.t2c + (k2 - 1) * 64);
-    static_for<PH>([&](auto gg) {
-      constexpr int gph = decltype(gg)::value;
-      const float r = zr[gph][p], im = zi[gph][p];
-      zr[gph][p] = __builtin_fmaf(r, t.x, -(im * t.y));
-      zi[gph][p] = __builtin_fmaf(r, t.y, im * t.x);
-    });
-  });
-  float peak = 0.f;
-  static_for<PH>([&](auto gg) {
-    constexpr int gph = decltype(gg)::value;
-    lds_wave_fence();
-    static_for<16>([&](auto kk2) {
-      constexpr int k2 = decltype(kk2)::value;
-      constexpr int p = bitrev(k2, 4);
-      *reinterpret_cast<float2*>(la.ex2_w + (k2 * kEx2StrideK2) * 8) = make_float2(zr[gph][p], zi[gph][p]);
-    });
-    lds_wave_fence();
-    static_for<2>([&](auto jj) {
-      constexpr int j = decltype(jj)::value;
-      float ur[8], ui[8];
-      static_for<8>([&](auto nn) {
-        constexpr int n3 = decltype(nn)::value;
-        const float2 v = *reinterpret_cast<const float2*>(la.ex2_r + (j * 8 * kEx2StrideK2 + n3) * 8);
-        ur[n3] = v.x; ui[n3] = v.y;
-      });
-      dif<8, 0>(ur, ui);
-      static_for<8>([&](auto pp) {
-        constexpr int p = decltype(pp)::value;
-        peak = __builtin_fmaxf(peak, __builtin_fmaf(ur[p], ur[p], ui[p] * ui[p]));
-      });
-    });
-  });
-  lds_wave_fence();
-  return peak;
-}
-
 // The same machine in two halves for R < 8 (one exchange phase), so that 8/R frames can share
 // the second half.  fft_front: pass 1 + exchange-1 write of one frame into k1 slots
 // [SLOT0, SLOT0 + R).
@@ -924,6 +924,39 @@ __device__ __forceinline__ float fft_back(const LaneAddr& la) {
   });
   lds_wave_fence();
   return peak;
+}
+
+// ---------------------------------------------------------------------------
+// Twiddle tables of the NF-point register FFT (NF = 128 R: 128 ... 2048), built once per workgroup by all of its
+// threads.  W_NF^e = exp(-2 pi i e / NF) with an integer exponent: exact argument reduction.
+//   t2 [k1 slot][15]: pass 2 (16 points over n2, slot k1' = 8 g + kk holding frame-local k1 = k1' mod R): factor i of
+//      stage s (L = 2^(s+1), d = 16 / L):  (W_(NF/8)^k1)^d W_L^k  =  W_NF^(8 k1 d + k NF / L)
+//   t3 [phase][j][7][lane]: pass 3 (8 points over n3; lane = (kk, k2 low), combination c = 2 g + j: k2 = (lane & 7) + 8 j):
+//      (W_NF^(R k2 + k1))^d W_L^k = W_NF^((R k2 + k1) d + k NF / L), L = 2^(s+1), d = 8 / L
+// Shared by the wave kernels, the pair kernel (N = 4096) and the quad kernel (N = 8192).
+// ---------------------------------------------------------------------------
+template <int NF>
+__device__ __forceinline__ void build_fft_tables(char* t2, char* t3, int tid, int n_threads) {
+  constexpr int R = NF / 128, PH = R >= 8 ? R / 8 : 1;
+  auto w_nf = [](int e) {
+    float sn, cs;
+    sincospif((float)(e & (NF - 1)) * (2.0f / (float)NF), &sn, &cs);
+    return make_float2(cs, -sn);
+  };
+  for (int e = tid; e < 8 * PH * 15; e += n_threads) {
+    const int slot = e / 15, i = e % 15;
+    const int k1 = PH == 2 ? 2 * (slot & 7) + (slot >> 3) : slot % R;   // two phases: by parity of k1
+    const int sidx = i < 1 ? 0 : i < 3 ? 1 : i < 7 ? 2 : 3;
+    const int k = i - ((1 << sidx) - 1), Lp = 2 << sidx, d = 16 / Lp;
+    reinterpret_cast<float2*>(t2)[e] = w_nf(8 * k1 * d + k * (NF / Lp));
+  }
+  for (int e = tid; e < PH * 2 * 7 * 64; e += n_threads) {
+    const int ln = e & 63, i = (e >> 6) % 7, c = e / (7 * 64);
+    const int k1 = PH == 2 ? 2 * (ln >> 3) + (c >> 1) : (ln >> 3) % R, k2 = (ln & 7) + 8 * (c & 1);
+    const int sidx = i < 1 ? 0 : i < 3 ? 1 : 2;
+    const int k = i - ((1 << sidx) - 1), Lp = 2 << sidx, d = 8 / Lp;
+    reinterpret_cast<float2*>(t3)[e] = w_nf((R * k2 + k1) * d + k * (NF / Lp));
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1003,10 +1036,7 @@ __device__ __forceinline__ void wave_body(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   char* t2 = smem;                                        // pass-2 twiddles [k1 slot][15] complex
   char* t3 = smem + C::kT2Bytes;                          // pass-3 twiddles [phase][j][7][lane] complex
-  char* t1c = smem;                                       // classic tables instead (N = 8192)
-  char* t2c = smem + C::kT1cBytes;
-  char* t4 = smem + C::kTableBytes - C::kT4Bytes - C::kT8Bytes;   // [64][2] complex (N >= 4096 only)
-  char* t8 = t4 + C::kT4Bytes;                            // [64][2] complex (N = 8192 only)
+  char* t4 = smem + C::kTableBytes - C::kT4Bytes;         // [64][2] complex (N = 4096 only)
   char* ex = smem + C::kTableBytes + wave * kExchangeBytes;
   float* stash = reinterpret_cast<float*>(smem + C::kTableBytes + kWavesPerWG * kExchangeBytes) +
                  wave * (kFramesPerWave * C::kFlushes * kStashStride);
@@ -1036,40 +1066,7 @@ __device__ __forceinline__ void wave_body(
   }
 
   // ---- twiddle tables, once per workgroup -----------------------------------
-  // W_NF^e = exp(-2 pi i e / NF) with an integer exponent: exact argument reduction
-  auto w_nf = [](int e) {
-    float sn, cs;
-    sincospif((float)(e & (C::kFftN - 1)) * (2.0f / (float)C::kFftN), &sn, &cs);
-    return make_float2(cs, -sn);
-  };
-  if constexpr (C::kClassicFft) {
-    for (int e = tid; e < 15 * 128; e += kThreads) {       // T1[k1-1][l][b] = W_NF^((2l+b) k1)
-      const int k1 = e / 128 + 1, lb = e % 128;
-      reinterpret_cast<float2*>(t1c)[e] = w_nf(lb * k1);
-    }
-    for (int e = tid; e < 15 * 8; e += kThreads) {         // T2[k2-1][n3] = W_128^(n3 k2) = W_NF^(16 n3 k2)
-      const int k2 = e / 8 + 1, n3 = e % 8;
-      reinterpret_cast<float2*>(t2c)[e] = w_nf(n3 * k2 * (C::kFftN / 128));
-    }
-  }
-  // pass 2 (16 points over n2, slot k1' = 8 g + kk holding frame-local k1 = k1' mod R): factor i of
-  // stage s (L = 2^(s+1), d = 16 / L):  (W_(NF/8)^k1)^d W_L^k  =  W_NF^(8 k1 d + k NF / L)
-  for (int e = tid; !C::kClassicFft && e < 8 * C::kPhases * 15; e += kThreads) {
-    const int slot = e / 15, i = e % 15;
-    const int k1 = C::kPhases == 2 ? 2 * (slot & 7) + (slot >> 3) : slot % R;   // two phases: by parity of k1
-    const int sidx = i < 1 ? 0 : i < 3 ? 1 : i < 7 ? 2 : 3;
-    const int k = i - ((1 << sidx) - 1), Lp = 2 << sidx, d = 16 / Lp;
-    reinterpret_cast<float2*>(t2)[e] = w_nf(8 * k1 * d + k * (C::kFftN / Lp));
-  }
-  // pass 3 (8 points over n3; lane = (kk, k2 low), combination c = 2 g + j: k2 = (lane & 7) + 8 j):
-  // (W_NF^(R k2 + k1))^d W_L^k = W_NF^((R k2 + k1) d + k NF / L), L = 2^(s+1), d = 8 / L
-  for (int e = tid; !C::kClassicFft && e < C::kPhases * 2 * 7 * 64; e += kThreads) {
-    const int ln = e & 63, i = (e >> 6) % 7, c = e / (7 * 64);
-    const int k1 = C::kPhases == 2 ? 2 * (ln >> 3) + (c >> 1) : (ln >> 3) % R, k2 = (ln & 7) + 8 * (c & 1);
-    const int sidx = i < 1 ? 0 : i < 3 ? 1 : 2;
-    const int k = i - ((1 << sidx) - 1), Lp = 2 << sidx, d = 8 / Lp;
-    reinterpret_cast<float2*>(t3)[e] = w_nf((R * k2 + k1) * d + k * (C::kFftN / Lp));
-  }
+  build_fft_tables<C::kFftN>(t2, t3, tid, kThreads);
   if constexpr (C::kSplit) {
     for (int e = tid; e < 128; e += kThreads) {            // T4[l][b] = W_4096^(2l+b)
       float sn, cs;
@@ -1077,20 +1074,11 @@ __device__ __forceinline__ void wave_body(
       reinterpret_cast<float2*>(t4)[e] = make_float2(cs, -sn);
     }
   }
-  if constexpr (C::kSplit2) {
-    for (int e = tid; e < 128; e += kThreads) {            // T8[l][b] = W_8192^(2l+b)
-      float sn, cs;
-      sincospif((float)e * (1.0f / 4096.0f), &sn, &cs);
-      reinterpret_cast<float2*>(t8)[e] = make_float2(cs, -sn);
-    }
-  }
   __syncthreads();
 
   // lane-constant LDS byte addresses
   const int kkL = lane >> 3, n3L = lane & 7;
   LaneAddr la;
-  la.t1c = t1c + lane * 16;
-  la.t2c = t2c + n3L * 8;
   la.tw2 = t2 + kkL * kTw2Stride;
   la.tw3 = t3 + lane * 8;
   la.ex1_w = ex + lane * 8;
@@ -1186,7 +1174,7 @@ __device__ __forceinline__ void wave_body(
 #ifdef AMCX_EXP_PLAIN_LOADS   // experiment (tools/wave_clock.hip): default cache policy instead of nt
         const v4f v = *p;
 #else
-        const v4f v = C::kSplit2 ? *p : __builtin_nontemporal_load(p);   // N = 8192 visits a frame twice
+        const v4f v = __builtin_nontemporal_load(p);
 #endif
         xr[2 * i] = v.x; xi[2 * i] = v.y; xr[2 * i + 1] = v.z; xi[2 * i + 1] = v.w;
       });
@@ -1269,8 +1257,7 @@ __device__ __forceinline__ void wave_body(
       Stats S;
       float sa_flushed = 0.f;                    // this lane's sum of |x| over the stretches flushed so far
       float av[kAInRegs ? 2 * ROWS : 1];
-      const float2* const src2 = iq + (f0 + g) * row_stride + 2 * lane;
-      if constexpr (!C::kSplit2) {
+      {
         static_for<ROWS>([&](auto ii) {
           constexpr int i = decltype(ii)::value;
           float a0, a1;
@@ -1299,48 +1286,13 @@ __device__ __forceinline__ void wave_body(
             __builtin_amdgcn_sched_barrier(0);
           }
         });
-      } else {
-        // N = 8192: 64 rows unrolled would be 60 KB of code and, with the FFTs, overflow the
-        // 64 KB instruction cache (measured: half the issue rate).  The sweep streams the frame
-        // through a rolled loop instead, four rows in flight; the FFT branches re-read it
-        // (L2 / Infinity Cache) into registers afterwards.
-        auto ld = [&](int r) { return *reinterpret_cast<const float4*>(src2 + 128 * r); };
-        static_assert(C::kFlushes == 4 && C::kRows == 64, "flush points of the rolled sweep");
-        float a0, a1;
-        float4 ring[4];
-        const float4 first = ld(0);
-        static_for<4>([&](auto kk) { ring[decltype(kk)::value] = ld(1 + decltype(kk)::value); });
-        S.template row<true, false>(first.x, first.y, first.z, first.w, lane, a0, a1);
-#pragma clang loop unroll(disable)
-        for (int i = 1; i < C::kRows - 3; i += 4) {          // rows 1 .. kRows-4
-          static_for<4>([&](auto kk) {
-            constexpr int k = decltype(kk)::value;
-            const float4 cur = ring[k];
-            const int nx = i + 4 + k;
-            ring[k] = ld(nx < C::kRows ? nx : C::kRows - 1);
-            S.template row<false, false>(cur.x, cur.y, cur.z, cur.w, lane, a0, a1);
-          });
-          if (i + 3 < C::kRows - 4 && ((i + 3) & 15) == 0) {     // rows 0..16 | ..32 | ..48 | ..63
-            sa_flushed += S.sa;
-            float r28[28] = {S.sA, S.sBh, S.sP, S.sAA, S.sX4, S.sAB, S.sAP, S.sBP, S.sAAA, S.sABB,
-                             S.sAAB, S.sBBB, S.sAAP, S.sX4P, S.sABP, S.sa, 0.f, 0.f, 0.f,
-                             S.st1, S.st2, S.sab1, S.sab2, S.sw1, S.sw2, S.sw3, S.sw4, 0.f};
-            float q7[7];
-            reduce_sums(r28, q7);
-            store_sums(q7, stash + (g * C::kFlushes + ((i + 3) >> 4) - 1) * kStashStride);
-            S.clear_sums();
-          }
-        }
-        S.template row<false, false>(ring[0].x, ring[0].y, ring[0].z, ring[0].w, lane, a0, a1);
-        S.template row<false, false>(ring[1].x, ring[1].y, ring[1].z, ring[1].w, lane, a0, a1);
-        S.template row<false, true>(ring[2].x, ring[2].y, ring[2].z, ring[2].w, lane, a0, a1);
       }
       asm volatile("; MARK envelope");
       AMCX_STAMP(0);
       __builtin_amdgcn_sched_barrier(0);
-      // envelope second sweep about the exact mean (N = 8192: during the second visit below)
+      // envelope second sweep about the exact mean
       const float mu = bcast_l63(wave_sum_l63(S.sa + sa_flushed)) * (1.0f / (float)N);
-      if constexpr (!C::kSplit2) {
+      {
         static_for<2 * ROWS>([&](auto ee) {
           constexpr int e = decltype(ee)::value;
           if constexpr (kAInRegs) {
@@ -1416,54 +1368,15 @@ __device__ __forceinline__ void wave_body(
             di[lo] = __builtin_fmaf(d0r, w4.y, d0i * w4.x);
             dr[lo + 1] = __builtin_fmaf(d1r, w4.z, -(d1i * w4.w));
             di[lo + 1] = __builtin_fmaf(d1r, w4.w, d1i * w4.z);
-            if constexpr (C::kSplit2 && i % 4 == 3) __builtin_amdgcn_sched_barrier(0);   // 16 loads in flight, not 64
           });
-          if constexpr (C::kClassicFft) {
-            float pk4 = fft_peak_classic<R>(sr, si, la);
-            __builtin_amdgcn_sched_barrier(0);
-            return __builtin_fmaxf(pk4, fft_peak_classic<R>(dr, di, la));
-          } else {
-            float pk4 = fft_peak<R>(sr, si, la);
-            __builtin_amdgcn_sched_barrier(0);
-            return __builtin_fmaxf(pk4, fft_peak<R>(dr, di, la));
-          }
-        };
-        if constexpr (!C::kSplit2) {
-          peak = fft4096([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            return make_float4(xr[2 * i], xi[2 * i], xr[2 * i + 1], xi[2 * i + 1]);
-          });
-        } else {
-          // first re-read (L2 / Infinity Cache): even bins = FFT_4096(x[n] + x[n+4096])
-          peak = fft4096([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            const float4 l4 = *reinterpret_cast<const float4*>(src2 + 128 * i);
-            const float4 h4 = *reinterpret_cast<const float4*>(src2 + 128 * (C::kRows / 2 + i));
-            return make_float4(l4.x + h4.x, l4.y + h4.y, l4.z + h4.z, l4.w + h4.w);
-          });
+          float pk4 = fft_peak<R>(sr, si, la);
           __builtin_amdgcn_sched_barrier(0);
-          // second re-read: the envelope's second sweep, and the odd bins =
-          // FFT_4096((x[n] - x[n+4096]) * W_8192^n),  W_8192^n = W_64^i * W_8192^(2l+b)
-          const float4 w8 = *reinterpret_cast<const float4*>(t8 + lane * 16);
-          const float odd = fft4096([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            const float4 l4 = *reinterpret_cast<const float4*>(src2 + 128 * i);
-            const float4 h4 = *reinterpret_cast<const float4*>(src2 + 128 * (C::kRows / 2 + i));
-            S.envelope(__builtin_amdgcn_sqrtf(__builtin_fmaf(l4.x, l4.x, __builtin_fmaf(l4.y, l4.y, kTinyPower))), mu);
-            S.envelope(__builtin_amdgcn_sqrtf(__builtin_fmaf(l4.z, l4.z, __builtin_fmaf(l4.w, l4.w, kTinyPower))), mu);
-            S.envelope(__builtin_amdgcn_sqrtf(__builtin_fmaf(h4.x, h4.x, __builtin_fmaf(h4.y, h4.y, kTinyPower))), mu);
-            S.envelope(__builtin_amdgcn_sqrtf(__builtin_fmaf(h4.z, h4.z, __builtin_fmaf(h4.w, h4.w, kTinyPower))), mu);
-            float d0r = l4.x - h4.x, d0i = l4.y - h4.y, d1r = l4.z - h4.z, d1i = l4.w - h4.w;
-            mul_w64<i>(d0r, d0i);
-            mul_w64<i>(d1r, d1i);
-            return make_float4(__builtin_fmaf(d0r, w8.x, -(d0i * w8.y)), __builtin_fmaf(d0r, w8.y, d0i * w8.x),
-                               __builtin_fmaf(d1r, w8.z, -(d1i * w8.w)), __builtin_fmaf(d1r, w8.w, d1i * w8.z));
-          });
-          peak = __builtin_fmaxf(peak, odd);
-          // the three envelope sums join the stash row now (the 24 others went before the FFTs)
-          const float e1 = wave_sum_l63(S.sad1), e2 = wave_sum_l63(S.sad2), e4 = wave_sum_l63(S.sad4);
-          if (lane == 63) { row[16] = e1; row[17] = e2; row[18] = e4; }
-        }
+          return __builtin_fmaxf(pk4, fft_peak<R>(dr, di, la));
+        };
+        peak = fft4096([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          return make_float4(xr[2 * i], xi[2 * i], xr[2 * i + 1], xi[2 * i + 1]);
+        });
       }
 
       const float pk = wave_max_l63(peak);
@@ -1613,7 +1526,7 @@ __device__ __forceinline__ void wave_body(
     } else {
       for (int g = 0; g < n_here; ++g) {
         float xr[2 * ROWS], xi[2 * ROWS];
-        if constexpr (!C::kSplit2) load_frame(xr, xi, f0 + g);   // N = 8192 streams the frame itself
+        load_frame(xr, xi, f0 + g);
         frame(xr, xi, g, Slot0{});
       }
     }
@@ -1668,7 +1581,11 @@ inline const char* wave_kernel_name(int frame_size) {
     case 512: return "amcx_features18_wave_kernel<512>";
     case 1024: return "amcx_features18_wave_kernel<1024>";
     case 2048: return "amcx_features18_wave_kernel<2048>";
+#ifdef AMCX_EXP_PAIR4096
+    case 4096: return "amcx_features18_pair_kernel";
+#else
     case 4096: return "amcx_features18_wave_kernel<4096>";
+#endif
     case 8192: return "amcx_features18_quad_kernel";
     default: return "";
   }
@@ -1714,8 +1631,7 @@ inline hipError_t launch_wave(const float2* iq, int64_t n_frames, int32_t frame_
     case 1024: return launch_wave_n<1024>(iq, n_frames, row_stride, out, out_stride, stream, cus);
     case 2048: return launch_wave_n<2048>(iq, n_frames, row_stride, out, out_stride, stream, cus);
     case 4096: return launch_wave_n<4096>(iq, n_frames, row_stride, out, out_stride, stream, cus);
-    case 8192: return launch_wave_n<8192>(iq, n_frames, row_stride, out, out_stride, stream, cus);
-    default: return hipErrorNotSupported;
+    default: return hipErrorNotSupported;       // 8192 has a kernel of its own (amcx.hip)
   }
 }
 

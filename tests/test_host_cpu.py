@@ -1243,3 +1243,27 @@ def test_staging_half_under_the_sanitizers(tmp_path, name, flags):
         assert r.returncode == 0 and "STAGE_FUZZ_OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-6000:])
         assert "WARNING: ThreadSanitizer" not in r.stderr and "ERROR: AddressSanitizer" not in r.stderr \
             and "runtime error" not in r.stderr, r.stderr[-6000:]
+
+
+def test_kernel_resources_match_the_committed_table():
+    """The register / spill / scratch claims made in DESIGN.md section 4 and in the kernel headers are read off the
+    BUILT library (its gfx950 code object's metadata, tools/resource_usage.py) and held to
+    amcpy_amd/csrc/kernel_resources.json: a kernel that starts to spill, grows past a wave-per-SIMD step (128 / 168 /
+    256 VGPRs) or appears / disappears without the table being updated fails here.  Product kernels only: the library
+    must hold no experiment (no pair kernel, no one-wave N = 8192)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("resource_usage", REPO / "tools" / "resource_usage.py")
+    ru = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ru)
+    got = {k: {f: v[f] for f in ("vgpr", "spill", "scratch")} for k, v in ru.read().items()}
+    want = __import__("json").loads((REPO / "amcpy_amd" / "csrc" / "kernel_resources.json").read_text())
+    assert sorted(got) == sorted(want), (sorted(set(got) ^ set(want)))
+    drift = {k: (got[k], want[k]) for k in want if got[k] != want[k]}
+    assert not drift, f"kernel resources differ from amcpy_amd/csrc/kernel_resources.json (python tools/resource_usage.py --update after a deliberate change): {drift}"
+    names = " ".join(got)
+    assert "pair_kernel" not in names and "wave_kernel<8192>" not in names
+    # the throughput kernels' occupancy steps, as the headers state them
+    assert got["amcx_features18_wave_kernel<2048>"]["vgpr"] <= 128            # 4 waves per SIMD
+    assert got["amcx_features18_wave_kernel<1024>"]["vgpr"] <= 168            # 3 waves per SIMD
+    assert got["amcx_features18_wave_kernel<4096>"]["vgpr"] <= 256            # 2 waves per SIMD
+    assert got["amcx_features18_wave_kernel<2048>"]["scratch"] <= 16          # one fp64 value in the per-batch finaliser

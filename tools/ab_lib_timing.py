@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Feature-kernel step time through the library (features18 on a resident arena) on two kinds of data: the bench's
 synthetic modulations and plain Gaussian noise (what tools/wave_clock feeds the kernel).  For same-box A/B of library
-builds: run once per build (tools/ab_bench_d2h.sh style)."""
+builds: run once per build (tools/ab_lib.sh; AMCX_LIB selects the library file)."""
 import sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
@@ -10,7 +10,8 @@ from amcpy_amd import synth
 from amcpy_amd.features import features18
 
 dev = torch.device("cuda", 0)
-N, S, K, M = 2048, 26, 4096, 6
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048          # frame size: python tools/ab_lib_timing.py [N]
+S, K, M = 26, 4096, 6
 arena = torch.empty((M, S, K, N), dtype=torch.complex64, device=dev)
 for mi in range(M):
     synth.device_frames(synth.MODS6[mi], S, K, N, device=dev, rank=0, mod_idx=mi, out=arena[mi])

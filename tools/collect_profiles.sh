@@ -1,7 +1,7 @@
 #!/bin/bash
 # Copy the condensed results of `bash tools/profile_all.sh TAG` (gpurun_out/, scratch) into profiles/ (tracked).
 #   bash tools/collect_profiles.sh r3
-TAG=${1:-r3}
+TAG=${1:-r4}
 cd "$(dirname "$0")/.."
 for N in 2048 4096 1024 8192; do
   D=gpurun_out/prof_${TAG}_n$N

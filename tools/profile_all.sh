@@ -2,7 +2,7 @@
 # The round's committed evidence in one gpurun call: rocprofv3 passes at the BASELINE frame sizes (+ 8192), the
 # default bench line with both CPU baselines, every size un-profiled, the in-kernel clock.
 #   bash tools/profile_all.sh r3     -> gpurun_out/prof_r3_n*/, gpurun_out/r3_*.json*
-TAG=${1:-r3}
+TAG=${1:-r4}
 for N in 2048 4096 1024 8192; do
   bash tools/profile.sh ${TAG}_n$N --frame-size $N > gpurun_out/${TAG}_n${N}_profile.log 2>&1 || { echo "profile N=$N failed"; tail -5 gpurun_out/${TAG}_n${N}_profile.log; exit 1; }
   echo "profiled N=$N: $(python3 -c "

@@ -127,6 +127,10 @@ int main(int argc, char** argv) {
   printf("# build: v_rcp_f32 of the half-angle quotient removed (AMCX_ABL_NORCP)\n");
 #elif defined(AMCX_ABL_NOSQRT)
   printf("# build: v_sqrt_f32 of the envelope removed (AMCX_ABL_NOSQRT)\n");
+#elif defined(AMCX_ABL_FFT_TAIL_MFMA)
+  printf("# build: FFT passes 2-3 replaced by the instruction mix of the coarse-spectrum scheme: fp32 twiddles, fp16 conversions, 8 + 16 MFMAs, candidate scan, 2 exact candidates (AMCX_ABL_FFT_TAIL_MFMA; results wrong on purpose)\n");
+#elif defined(AMCX_ABL_FFT_TAIL)
+  printf("# build: FFT passes 2-3 and both exchanges removed, pass 1 kept (AMCX_ABL_FFT_TAIL; results wrong on purpose)\n");
 #elif defined(AMCX_EXP_PK_FFT)
   printf("# build: packed-fp32 FFT butterflies, all passes (AMCX_EXP_PK_FFT)\n");
 #elif defined(AMCX_EXP_PK_PASS1_ONLY)
@@ -141,7 +145,6 @@ int main(int argc, char** argv) {
     case 1024: all<1024>(F); break;
     case 2048: all<2048>(F); break;
     case 4096: all<4096>(F); break;
-    case 8192: all<8192>(F); break;
     default: printf("frame size 1024, 2048 or 4096\n"); return 2;
   }
   return 0;
