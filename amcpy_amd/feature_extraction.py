@@ -740,12 +740,30 @@ def _placement(world: int, device: Optional[int]) -> bool:
     return len({h for h, _ in where}) == 1
 
 
+def _already_extracted(out_path: Path, key: str, shape) -> bool:
+    """True if ``out_path`` is a complete feature file for this configuration: it holds ``key`` as a float32 array
+    of ``shape`` (and the ``Modulation`` string).  Only the variable headers are read (``scipy.io.whosmat``); a file
+    that is cut short, or was written for another frame count or SNR grid, does not qualify."""
+    import scipy.io
+    try:
+        seen = {name: (tuple(shp), cls) for name, shp, cls in scipy.io.whosmat(str(out_path))}
+        if seen.get(key) != (tuple(shape), "single") or "Modulation" not in seen:
+            return False
+        size = out_path.stat().st_size
+        return size >= 4 * int(np.prod(shape))             # the array's bytes are really there
+    except Exception:
+        return False
+
+
 def run_extraction(cfg: Config, *, compute=None, device: Optional[int] = None, devices=None,
-                   verbose: bool = True) -> None:
+                   verbose: bool = True, resume: bool = False) -> None:
     """Drop-in for the reference's ``run_extraction(cfg)``: writes one
     ``{mod}_features.mat`` per entry of ``cfg.signals.modulations_with_noise``.
     ``devices``: several GPU indices driven from THIS process (:class:`DeviceFanOut`; not together with a process
-    group of several ranks, where every rank has its one ``device``)."""
+    group of several ranks, where every rank has its one ``device``).
+    ``resume``: modulations whose feature file is already there, complete and of this configuration's shape, are
+    skipped -- the per-modulation file is the path's natural resume unit (the reference recomputes everything,
+    all-or-nothing per file; a file is written by ONE savemat call at the end of its modulation, here as there)."""
     import scipy.io
 
     rank, world = _rank_world()
@@ -769,6 +787,20 @@ def run_extraction(cfg: Config, *, compute=None, device: Optional[int] = None, d
     else:
         engine = default_engine(N, device, threads)
     mods = list(cfg.signals.modulations_with_noise)
+    if resume:
+        todo = mods
+        if rank == 0:
+            shape = (len(cfg.signals.snr_values), cfg.signals.num_frames, 18)
+            todo = [m for m in mods if not _already_extracted(cfg.paths.calculated_features / f"{m}_features.mat",
+                                                              cfg.signals.mat_info[m], shape)]
+            if verbose and len(todo) < len(mods):
+                print(f"resume: {len(mods) - len(todo)} of {len(mods)} feature files are complete, computing {todo}")
+        if world > 1:                                       # every rank loops over the same modulations
+            import torch.distributed as dist
+            box = [todo]
+            dist.broadcast_object_list(box, src=0)
+            todo = box[0]
+        mods = todo
     t_start = time.perf_counter()
 
     def run(rows: FrameRows) -> np.ndarray:
@@ -779,7 +811,14 @@ def run_extraction(cfg: Config, *, compute=None, device: Optional[int] = None, d
 
     def save(mod: str, key: str, feats: np.ndarray, t0: float) -> None:
         out_path = cfg.paths.calculated_features / f"{mod}_features.mat"
-        scipy.io.savemat(str(out_path), {"Modulation": mod, key: feats})
+        # written aside and renamed: an interrupted run never leaves a partial file under the final name (what
+        # resume= and every downstream loader look at)
+        tmp_path = out_path.with_name(f"{out_path.stem}.{os.getpid()}.tmp.mat")
+        try:
+            scipy.io.savemat(str(tmp_path), {"Modulation": mod, key: feats})
+            os.replace(tmp_path, out_path)
+        finally:
+            tmp_path.unlink(missing_ok=True)
         if verbose:
             print(f"[{mod}] {feats.shape[0] * feats.shape[1]} frames in "
                   f"{time.perf_counter() - t0:.2f}s -> {out_path}")
@@ -871,9 +910,15 @@ def run_extraction(cfg: Config, *, compute=None, device: Optional[int] = None, d
                     if by_frames:
                         k_lo, k_hi = shard_range(n_frames, rank, world)
                         local = run(FrameColumns(parsed, n_snr, n_frames, k_lo, k_hi))
+                        expect = n_snr * (k_hi - k_lo)
                     else:
                         lo, hi = shard_range(F, rank, world)
                         local = run(FrameRows(parsed, n_snr, n_frames, lo, hi))
+                        expect = hi - lo
+                    # a wrong row count would raise inside the gather on THIS rank only and leave the others in the
+                    # collective: it is reported with the status word instead
+                    if local.shape != (expect, 18):
+                        raise RuntimeError(f"engine returned {local.shape} for {expect} frames")
                 except Exception as exc:
                     failure = f"{type(exc).__name__}: {exc}"
                 del parsed

@@ -1,5 +1,5 @@
 """`python -m amcpy_amd extract [--root DIR] [--frame-size N] [--num-frames F] [--snr-values L ...]
-                              [--device D | --devices 0,1,...|all]`
+                              [--device D | --devices 0,1,...|all] [--resume]`
 
 The `extract` sub-command of the reference's CLI (src/amcpy/main.py:32,85-87,
 160-175), and only that one: plot/train/eval/quantize are outside the hot path
@@ -34,6 +34,8 @@ def build_parser() -> argparse.ArgumentParser:
     ex.add_argument("--snr-values", nargs="+", default=None, metavar="LABEL",
                     help="SNR labels of the container's first axis, in order (default: the 16 of SignalConfig)")
     ex.add_argument("--device", type=int, default=None, help="GPU index (default: current device)")
+    ex.add_argument("--resume", action="store_true",
+                    help="skip modulations whose {mod}_features.mat is already complete for this configuration")
     ex.add_argument("--devices", default=None, metavar="0,1,...|all",
                     help="several GPUs from this one process, frames cut across them (one engine and host thread each)")
     return ap
@@ -81,7 +83,7 @@ def _run_as_rank(cfg, args) -> None:
     else:
         dist.init_process_group(backend, rank=rank, world_size=world)
     try:
-        run_extraction(cfg, device=dev, verbose=rank == 0)
+        run_extraction(cfg, device=dev, verbose=rank == 0, resume=args.resume)
     finally:
         dist.destroy_process_group()
 
@@ -115,9 +117,9 @@ def main(argv=None, *, skip_torch: bool = False) -> int:
             _lib.load(skip_torch=True)
         from .feature_extraction import run_extraction
         if args.devices is not None:
-            run_extraction(cfg, devices=_parse_devices(args.devices))
+            run_extraction(cfg, devices=_parse_devices(args.devices), resume=args.resume)
         else:
-            run_extraction(cfg, device=args.device)
+            run_extraction(cfg, device=args.device, resume=args.resume)
     return 0
 
 

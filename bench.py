@@ -412,11 +412,10 @@ def _free_port() -> int:
 
 
 def _die_with_parent():
-    """preexec of a rank: its own process group (so the parent can take the whole rank down, helper processes
-    included) and SIGKILL when the parent goes away however that happens."""
+    """preexec of a rank (its own session comes from start_new_session, so that the parent can take the whole rank
+    down, helper processes included): SIGKILL when the parent goes away, however that happens."""
     import ctypes
     import signal
-    os.setsid()
     try:
         ctypes.CDLL(None, use_errno=True).prctl(1, signal.SIGKILL, 0, 0, 0)      # PR_SET_PDEATHSIG
     except Exception:
@@ -460,7 +459,8 @@ def self_launch(n: int, argv, time_limit: float, script=None, build: bool = True
         for r in range(n):
             e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
             procs.append(subprocess.Popen([sys.executable, script, *argv], env=e, stdin=subprocess.DEVNULL,
-                                          stdout=None if r == 0 else sys.stderr, preexec_fn=_die_with_parent))
+                                          stdout=None if r == 0 else sys.stderr, start_new_session=True,
+                                          preexec_fn=_die_with_parent))
         deadline = time.time() + time_limit
         first_bad, bad_at = 0, None
         while any(pr.poll() is None for pr in procs):

@@ -1267,3 +1267,46 @@ def test_kernel_resources_match_the_committed_table():
     assert got["amcx_features18_wave_kernel<1024>"]["vgpr"] <= 168            # 3 waves per SIMD
     assert got["amcx_features18_wave_kernel<4096>"]["vgpr"] <= 256            # 2 waves per SIMD
     assert got["amcx_features18_wave_kernel<2048>"]["scratch"] <= 16          # one fp64 value in the per-batch finaliser
+
+
+def test_run_extraction_resume_skips_complete_files(tmp_path):
+    """``run_extraction(cfg, resume=True)`` / ``extract --resume``: the per-modulation output file is the path's
+    resume unit.  A file that is complete for THIS configuration is skipped; a missing one, one
+    written for another frame count and one cut short are computed again."""
+    import scipy.io
+    from amcpy_amd.config import Config, Paths, SignalConfig
+    from amcpy_amd import feature_extraction as fe
+    rng = np.random.default_rng(8)
+    cfg = Config(paths=Paths(root=tmp_path),
+                 signals=SignalConfig(snr_values={0: "0", 1: "10"}, num_frames=5, frame_size=16))
+    cfg.paths.ensure_dirs()
+    mods = list(cfg.signals.modulations_with_noise)
+    scipy.io.savemat(str(cfg.paths.mat_data / cfg.paths.mat_filename),
+                     {cfg.signals.mat_info[m]: (rng.standard_normal((2, 6, 20)) + 1j * rng.standard_normal((2, 6, 20)))
+                      for m in mods})
+    calls = []
+
+    def compute(block):
+        calls.append(block.shape[0])
+        return _marker_features(np.asarray(block)[:, :16])
+
+    fe.run_extraction(cfg, compute=compute, verbose=False, resume=True)       # nothing there yet: everything is computed
+    assert len(calls) == len(mods)
+    ref = {m: scipy.io.loadmat(str(cfg.paths.calculated_features / f"{m}_features.mat"))[cfg.signals.mat_info[m]] for m in mods}
+    calls.clear()
+    fe.run_extraction(cfg, compute=compute, verbose=False, resume=True)       # everything there: nothing is computed
+    assert calls == []
+    # one missing, one of another shape (a run with fewer frames), one cut short
+    (cfg.paths.calculated_features / f"{mods[0]}_features.mat").unlink()
+    scipy.io.savemat(str(cfg.paths.calculated_features / f"{mods[1]}_features.mat"),
+                     {"Modulation": mods[1], cfg.signals.mat_info[mods[1]]: np.zeros((2, 3, 18), np.float32)})
+    p2 = cfg.paths.calculated_features / f"{mods[2]}_features.mat"
+    p2.write_bytes(p2.read_bytes()[:300])
+    fe.run_extraction(cfg, compute=compute, verbose=False, resume=True)
+    assert len(calls) == 3
+    for m in mods:
+        got = scipy.io.loadmat(str(cfg.paths.calculated_features / f"{m}_features.mat"))[cfg.signals.mat_info[m]]
+        assert got.dtype == np.float32 and np.array_equal(got, ref[m]), m
+    calls.clear()
+    fe.run_extraction(cfg, compute=compute, verbose=False)                    # without resume: the reference's behaviour
+    assert len(calls) == len(mods)
