@@ -1168,6 +1168,20 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     r = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert _check_two_rank_line(r.stdout)["launcher"] == "external/gloo"
+    # 2b. RCCL itself, as far as one GPU allows: ONE rank under the launcher with the nccl backend -- communicator with
+    #     device_id, the all-reduce behind rccl_ranks, the barriers around the timed region, the MAX of the wall times
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(repo / "bench.py"),
+           "--gpus", "1", "--steps", "3", "--warmup", "2", "--frames", "64", "--no-cpu-baseline", "--no-h2d"]
+    r = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout                            # RCCL's banner must not reach stdout
+    one = __import__("json").loads(lines[0])
+    assert one["n_gpus"] == 1 and one["rccl_ranks"] == 1 and one["launcher"] == "external/nccl" and one["gather"] is None
     # 3. a launcher that started a different number of ranks than --gpus says is refused, not silently run
     bad = subprocess.run([sys.executable, str(repo / "bench.py"), "--gpus", "2", "--no-cpu-baseline"],
                          env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
