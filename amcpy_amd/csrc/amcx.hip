@@ -205,14 +205,18 @@ int amcx_features18_c64_ex(const void* iq_dev, int64_t n_frames, int32_t frame_s
     else
       e = amcx::launch_wave(iq, n_frames, frame_size, row_stride_elems, out_dev, out_row_stride, stream, cu_count());
     if (e != hipSuccess) return hip_fail(e, "wave kernel launch");
-    // frames the fp32 kernel flagged as outside its range (f5 = -inf): the range pass of the same wave machine
-    // on a power-of-two pre-scaled copy (N = 1024, 2048, 4096), or the block kernel's fp64-sum routine (other N).
-    // (Frames with a phase step within an angle rounding of +-pi are finished inside the wave kernels.)
-    if (amcx::wave_has_range_pass(frame_size))
-      e = amcx::launch_wave_range(iq, n_frames, frame_size, row_stride_elems, out_dev, out_row_stride, stream, cu_count());
-    else
-      e = amcx::launch_range_fixup(iq, n_frames, frame_size, row_stride_elems, out_dev, out_row_stride, stream, cu_count());
-    if (e != hipSuccess) return hip_fail(e, "range pass launch");
+    // N = 1024, 2048, 4096: the kernel has re-run the frames outside its fp32 sums' range itself -- one launch, rows final.
+    // The other wave sizes (and the pair experiment) marked such frames in band (f5 = -inf): the block kernel's
+    // fp64-sum routine redoes them.  (Frames with a phase step within an angle rounding of +-pi are finished inside
+    // every wave kernel.)
+    if (amcx::wave_redoes_in_kernel(frame_size)
+#ifdef AMCX_EXP_PAIR4096
+        && frame_size != amcx::pair::kN
+#endif
+        )
+      return AMCX_OK;
+    e = amcx::launch_range_fixup(iq, n_frames, frame_size, row_stride_elems, out_dev, out_row_stride, stream, cu_count());
+    if (e != hipSuccess) return hip_fail(e, "range fix-up launch");
     return AMCX_OK;
   }
   return launch_block(iq, n_frames, frame_size, row_stride_elems, out_dev, out_row_stride, stream);
@@ -385,7 +389,7 @@ int ctx_run_strided(amcx_ctx* c, amcx::Source src, int64_t S, int64_t K,
   const double t_loop = wall_now();
   // ---- small row-major calls: one graph launch ------------------------------------------------------------------
   // A per-frame loop (the reference's calculate_features per queue item, features.py:214-232) is launch-bound: copy in,
-  // one or two conversions / kernels, the range pass, copy out, a synchronisation -- eight runtime calls around 10 us of
+  // one or two conversions / kernels, copy out, a synchronisation -- seven runtime calls around 10 us of
   // GPU work.  Captured once per shape into a graph on the compute stream, a call is: stage into the pinned slot,
   // hipGraphLaunch, hipStreamSynchronize.  Anything that does not fit (several chunks, planes, staging threads) and any
   // failure to capture takes the general path below.

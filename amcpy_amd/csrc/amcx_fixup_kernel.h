@@ -1,12 +1,11 @@
-// The launch behind the wave kernel at the frame sizes that have no range pass of their own.
+// The launch behind the wave kernel at the frame sizes whose kernel does not re-run out-of-range frames itself
+// (N = 128 ... 512 and 8192; at 1024, 2048, 4096 the wave kernel does: amcx_wave_kernel.h, kRedoHere).
 // The throughput kernel does its per-sample arithmetic and its sums in fp32; its finaliser marks, in
 // band, the frames it cannot finish -- feature 5 (a standard deviation: >= 0 or NaN) is stored
 //   -infinity : the frame is outside the range in which fp32 sixth-order sums are trustworthy (mean
 //               power outside [kRangeLoPower, kRangeHiPower], or a sum overflowed: |x| >~ 1e5 or
-//               <~ 1e-5, a single huge sample, an infinite sample).  Redone by the wave kernel's own
-//               range pass on a power-of-two pre-scaled copy (amcx_range_wave_kernel, N = 1024, 2048,
-//               4096) or, at the other wave sizes, by amcx_range_fixup_kernel below with the block
-//               kernel's fp64-sum frame routine -- the reference evaluates in complex128
+//               <~ 1e-5, a single huge sample, an infinite sample).  Redone by amcx_range_fixup_kernel
+//               below with the block kernel's fp64-sum frame routine -- the reference evaluates in complex128
 //               (features.py:46-58) and stays finite over the whole complex64 range, overflowing only
 //               in its float32 store.
 // Frames with a phase step within an fp32 ulp of +-pi (amcx_math.h kTieBand) no longer leave the wave

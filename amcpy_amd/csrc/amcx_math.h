@@ -177,7 +177,7 @@ __device__ inline void frequency_features(double Kw, double swd1, double swd2, d
 // stores float32: feature_extraction.py:35,56).  Formulas: features.py:66-185;
 // C60 uses +3*m20^3 and m62 is real-only, as the reference has them
 // (features.py:147,57).
-// SCALED (the range pass of the wave kernel): the sums are those of the frame multiplied by 2^-ex, ex even;
+// SCALED (the wave kernel's re-run of an out-of-range frame): the sums are those of the frame multiplied by 2^-ex, ex even;
 // feature j of the frame itself is the scaled one times 2^(ex * order_j) with order = 2, 0, 0, 0, 0, 1, 1/2, 0, 0, 2, 2,
 // 4, 4, 4, 6, 6, 6, 6 -- applied in fp64 before the float32 store, so that store overflows / underflows exactly where the
 // reference's does (feature_extraction.py:35,56).

@@ -61,8 +61,8 @@
 // With them: no scratch instruction between a frame's load and its FFT peak; 50 spilled dwords in the prologue and
 // the per-chunk fp64 finaliser (tools/resource_usage.py on an experiment build).
 //
-// Frames outside the fp32 sums' range are flagged (f5 = -inf) and redone by amcx_range_wave_kernel<4096>, the
-// one-wave machine on an exactly pre-scaled copy (amcx_wave_kernel.h).
+// Frames outside the fp32 sums' range are flagged (f5 = -inf) and redone by amcx_range_fixup_kernel (the block
+// kernel's fp64-sum routine) in a second launch; the one-wave kernel re-runs them itself (amcx_wave_kernel.h).
 // LDS per workgroup: 16 256 B tables + 16 x (8 672 B region + 528 B stash) + 168 B of sync words = 163 624 B.
 // Algorithmic HBM bytes per frame: 8 * 4096 read + 72 written.
 #pragma once
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerWG / 4) void amcx_features18_pai
         F.gmax_raw = pk;
         F.pi_tie = flagged;
         finalize_features(F, kN, feat);
-        if (is_outside_fp32_range(F, kN)) feat[4] = -__builtin_inff();       // redone by amcx_range_wave_kernel<4096>
+        if (is_outside_fp32_range(F, kN)) feat[4] = -__builtin_inff();       // redone by amcx_range_fixup_kernel
         tie = __builtin_signbitf(feat[4]) && feat[4] == feat[4] && feat[4] != -__builtin_inff();
       }
       unsigned long long ties = __builtin_amdgcn_ballot_w64(tie);

@@ -968,7 +968,7 @@ __device__ __forceinline__ void build_fft_tables(char* t2, char* t3, int tid, in
 // nothing crosses lanes until the fp64 reductions (reference: np.std / scipy kurtosis of the float64
 // frequency array, features.py:88-91,110-113).  In the
 // hot loop this cost 60-760 spilled VGPRs (round 1); as a separate launch it cost a 4-byte-per-frame scan
-// of the result matrix plus 29 us per 639 k frames (round 2).  sc: the power of two the range pass
+// of the result matrix plus 29 us per 639 k frames (round 2).  sc: the power of two a re-run
 // multiplies the frame by (1 in the throughput kernel).
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
@@ -1014,18 +1014,23 @@ __device__ __forceinline__ void wave_exact_frequency(const float2* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------
-// RANGE = false: the throughput kernel.  RANGE = true: the range pass behind it (amcx_range_wave_kernel):
-// the same machine over only the frames the throughput kernel flagged as outside its fp32 range
-// (f5 = -inf), each multiplied by an exact power of two first -- 2^-ex, ex the even-rounded exponent of
-// its largest component, so that every component is below 4 and no sixth-order product can overflow --
-// and un-scaled in the fp64 finaliser through the features' scaling laws (finalize_features<true>).
-// Waves take blocks of up to 64 frames, read their flags with one load and skip blocks without a flag.
-template <int N, bool RANGE>
+// The throughput kernel.  Frames OUTSIDE the fp32 sums' range (mean power outside [1e-10, 1e10], or a sum that is not
+// finite: is_outside_fp32_range) are found by the finaliser and, at N = 1024, 2048, 4096 (kRedoHere), re-run by the same
+// wave right behind its batch, in this launch: each multiplied by an exact power of two first -- 2^-ex, ex the
+// even-rounded exponent of its largest component, so that every component is below 4 and no sixth-order product can
+// overflow -- and un-scaled in the fp64 finaliser through the features' scaling laws (finalize_features<true>).  A row
+// is stored once, final.  (Rounds 2-3 marked such frames in band, f5 = -inf, and re-ran them in a second launch of
+// this machine, amcx_range_wave_kernel: 8 us per step when there was nothing to do, and a consumer that did not order
+// itself behind the call could see marked rows.  Round 4 moved the re-run here: one launch per step, and +1.3 % at
+// N = 2048, +0.6 % at 1024, +-0 at 4096 on the same box, profiles/r4_redo_in_kernel_ab.txt -- with the second copy of
+// the frame code in the kernel the compiler keeps less alive across the finaliser, whose one spilled value is gone.)
+// The other wave sizes still mark in band and leave the re-run to amcx_range_fixup_kernel.
+template <int N>
 __device__ __forceinline__ void wave_body(
     const float2* __restrict__ iq, long long n_frames, long long row_stride,
     float* __restrict__ out, long long out_stride AMCX_STAMP_ARG) {
-  static_assert(!RANGE || (N >= 1024 && N <= 4096), "range pass: the sizes whose frame sits in one register set");
   using C = Cfg<N>;
+  constexpr bool kRedoHere = N >= 1024 && N <= 4096;     // the sizes whose frame sits in one register set
   constexpr int R = C::kFftRows, ROWS = C::kHeldRows;
   constexpr int kWavesPerWG = C::kWavesPerWG, kThreads = C::kThreads, kTailFrames = C::kTailFrames;
   constexpr int kFramesPerWave = C::kFramesPerWave, kTailChunk = C::kTailChunk;
@@ -1058,13 +1063,6 @@ __device__ __forceinline__ void wave_body(
   const long long tail_len = slice_len < kTailFrames ? slice_len : kTailFrames;
   const long long body_len = slice_len - tail_len;          // grabbed kFramesPerWave at a time
 
-  if constexpr (RANGE) {
-    // normally nothing is flagged: look first, and leave before the twiddle tables cost 5 us of sincospif
-    int mine = 0;
-    for (long long k = tid; k < slice_len; k += kThreads) mine |= out[(slice0 + k) * out_stride + 4] == -__builtin_inff();
-    if (!__syncthreads_or(mine)) return;
-  }
-
   // ---- twiddle tables, once per workgroup -----------------------------------
   build_fft_tables<C::kFftN>(t2, t3, tid, kThreads);
   if constexpr (C::kSplit) {
@@ -1096,24 +1094,7 @@ __device__ __forceinline__ void wave_body(
     // grab the next chunk of this workgroup's slice (lane 0 asks, the wave follows)
     long long f0;
     int n_here;
-    [[maybe_unused]] unsigned long long todo = 0;     // range pass: flagged frames of this block of 64
-    if constexpr (RANGE) {
-      // blocks of up to 64 frames (one flag per lane), smaller when the slice is short: at least ~4 blocks per wave,
-      // so that a slice full of flagged frames is still spread over all twelve waves
-      int blk = 64;
-      while (blk > 8 && slice_len < (long long)blk * kWavesPerWG * 4) blk >>= 1;
-      unsigned got = 0;
-      if (lane == 0) got = __hip_atomic_fetch_add(&counters[0], (unsigned)blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      got = __builtin_amdgcn_readfirstlane(got);
-      if ((long long)got >= slice_len) break;
-      f0 = slice0 + got;
-      const long long left = slice_len - got;
-      float flag = 0.f;
-      if (lane < (left < blk ? left : blk)) flag = out[(f0 + lane) * out_stride + 4];
-      todo = __builtin_amdgcn_ballot_w64(flag == -__builtin_inff());
-      if (todo == 0) continue;
-      n_here = 0;
-    } else {
+    {
       unsigned got = 0;
       if (lane == 0) got = __hip_atomic_fetch_add(&counters[0], (unsigned)kFramesPerWave, __ATOMIC_RELAXED,
                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1241,8 +1222,13 @@ __device__ __forceinline__ void wave_body(
         });
       };
       auto store_sums = [&](const float (&r7)[7], float* row) __attribute__((always_inline)) {
-        if ((lane & 15) == 0) {                    // one lane per row: rows hold 4j + {0, 2, 1, 3}
-          const int rsel = lane >> 4;
+        // (with TWO copies of this frame code in the kernel -- kRedoHere -- the compiler hoists the lane-derived offset
+        //  out of both, spills it in the prologue and reloads it here once per frame behind a wait: the lane index
+        //  goes through an empty asm instead, so that the offset is formed where it is used)
+        int ln = lane;
+        if constexpr (kRedoHere) asm volatile("" : "+v"(ln));
+        if ((ln & 15) == 0) {                      // one lane per row: rows hold 4j + {0, 2, 1, 3}
+          const int rsel = ln >> 4;
           float* dst = row + (((rsel & 1) << 1) | (rsel >> 1));
           static_for<7>([&](auto jj) {
             constexpr int j = decltype(jj)::value;
@@ -1384,7 +1370,11 @@ __device__ __forceinline__ void wave_body(
     };
 
     // ---- batch finalisation: lane g turns the sums in stash row g into 18 features ----
-    auto finalise = [&](int count) {
+    // range_tag true: the rows are those of frames re-run on a pre-scaled copy (rerun_scaled below).
+    // Returns the lanes whose frame is outside the fp32 sums' range and has NOT been stored (kRedoHere only).
+    auto finalise = [&](auto range_tag, int count) -> unsigned long long {
+      constexpr bool RG = decltype(range_tag)::value;
+      bool redo = false;
       lds_wave_fence();
       float feat[18];
       long long f = 0;
@@ -1411,7 +1401,7 @@ __device__ __forceinline__ void wave_body(
         F.gmax_raw = row[27]; F.Kt = row[28]; F.Kw = row[29]; F.Ka = row[30];
         F.pi_tie = row[31] != 0.0f;
         kw_shift = row[29];
-        if constexpr (RANGE) {
+        if constexpr (RG) {
           const int code = (int)row[kNumSums + 5];              // (ex + 128) * 64 + index within the block
           const int ex = (code >> 6) - 128;
           finalize_features<true>(F, N, feat, ex);
@@ -1419,11 +1409,14 @@ __device__ __forceinline__ void wave_body(
           f = f0 + (code & 63);
         } else {
           finalize_features(F, N, feat);
-          if (is_outside_fp32_range(F, N)) feat[4] = -__builtin_inff();   // all 18 redone by the range pass
+          if (is_outside_fp32_range(F, N)) {
+            if constexpr (kRedoHere) redo = true;                // re-run below, in this kernel; the row is not stored
+            else feat[4] = -__builtin_inff();                    // all 18 redone by amcx_range_fixup_kernel
+          }
           f = f0 + lane;
         }
-        // flagged by the sweep (f5 came back negated) and neither NaN nor on its way to the range pass
-        tie = __builtin_signbitf(feat[4]) && feat[4] == feat[4] && feat[4] != -__builtin_inff();
+        // flagged by the sweep (f5 came back negated) and neither NaN nor on its way to a re-run
+        tie = __builtin_signbitf(feat[4]) && feat[4] == feat[4] && feat[4] != -__builtin_inff() && !redo;
       }
       // frames with a phase step within an fp32 rounding of +-pi: f5 and f9 again, the wave on one frame at a time
       unsigned long long ties = __builtin_amdgcn_ballot_w64(tie);
@@ -1437,22 +1430,24 @@ __device__ __forceinline__ void wave_body(
         const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)f >> 32), idx);
         const long long ft = (long long)(((unsigned long long)hi << 32) | lo);
         float sct = 1.0f;
-        if constexpr (RANGE) sct = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc), idx));
+        if constexpr (RG) sct = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc), idx));
         const float kwt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, kw_shift), idx));
         float f5x, f9x;
         wave_exact_frequency<N>(iq + ft * row_stride, sct, kwt, lane, f5x, f9x);
         if (lane == idx) { feat[4] = f5x; feat[8] = f9x; }
       }
-      if (lane < count) {
+      if (lane < count && !redo) {
         float* dst = out + f * out_stride;
 #pragma unroll
         for (int j = 0; j < 18; ++j) dst[j] = feat[j];
       }
       lds_wave_fence();
+      return __builtin_amdgcn_ballot_w64(redo);
     };
 
     using Slot0 = std::integral_constant<int, 0>;
-    if constexpr (RANGE) {
+    // frames `todo` (bit i: frame f0 + i) again, each multiplied by 2^-ex first (see the comment above wave_body)
+    auto rerun_scaled = [&](unsigned long long todo) {
       while (todo != 0) {
         int cnt = 0;
         for (; cnt < kFramesPerWave && todo != 0; ++cnt) {
@@ -1477,9 +1472,10 @@ __device__ __forceinline__ void wave_body(
           if (lane == 63)
             stash[(cnt * C::kFlushes + (C::kFlushes - 1)) * kStashStride + kNumSums + 5] = (float)((ex + 128) * 64 + idx);
         }
-        finalise(cnt);
+        finalise(std::true_type{}, cnt);
       }
-    } else if constexpr (C::kGroup > 1) {
+    };
+    if constexpr (C::kGroup > 1) {
       // short frames, ping-pong prefetch as below, kGroup frames per run of FFT passes 2-3
       constexpr int G = C::kGroup;
       float ar[2 * ROWS], ai[2 * ROWS], br[2 * ROWS], bi[2 * ROWS];
@@ -1533,7 +1529,11 @@ __device__ __forceinline__ void wave_body(
 
     AMCX_STAMP(4);
     asm volatile("; MARK finalize");
-    if constexpr (!RANGE) finalise(n_here);
+    [[maybe_unused]] const unsigned long long left_over = finalise(std::false_type{}, n_here);
+    if constexpr (kRedoHere) {
+      asm volatile("; MARK redo");
+      if (left_over != 0) rerun_scaled(left_over);            // frames outside the fp32 sums' range: never on ordinary data
+    }
     AMCX_STAMP(5);
   }
 #ifdef AMCX_WAVE_STAMPS
@@ -1553,20 +1553,11 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, (Cfg<N>::kWavesPerWG + 3) / 4) vo
     const float2* __restrict__ iq, long long n_frames, long long row_stride,
     float* __restrict__ out, long long out_stride AMCX_STAMP_ARG) {
 #ifdef AMCX_WAVE_STAMPS
-  wave_body<N, false>(iq, n_frames, row_stride, out, out_stride, stamp_out);
+  wave_body<N>(iq, n_frames, row_stride, out, out_stride, stamp_out);
 #else
-  wave_body<N, false>(iq, n_frames, row_stride, out, out_stride);
+  wave_body<N>(iq, n_frames, row_stride, out, out_stride);
 #endif
 }
-
-#ifndef AMCX_WAVE_STAMPS
-template <int N>
-__global__ __launch_bounds__(Cfg<N>::kThreads, (Cfg<N>::kWavesPerWG + 3) / 4) void amcx_range_wave_kernel(
-    const float2* __restrict__ iq, long long n_frames, long long row_stride,
-    float* __restrict__ out, long long out_stride) {
-  wave_body<N, true>(iq, n_frames, row_stride, out, out_stride);
-}
-#endif
 
 }  // namespace wave
 
@@ -1592,16 +1583,14 @@ inline const char* wave_kernel_name(int frame_size) {
 }
 
 #ifndef AMCX_WAVE_STAMPS
-// sizes with a range pass of their own (the others' flagged frames go to the block-kernel routine)
-inline bool wave_has_range_pass(int frame_size) { return frame_size == 1024 || frame_size == 2048 || frame_size == 4096; }
+// sizes whose kernel re-runs out-of-range frames itself (wave_body: kRedoHere); the others mark them in band (f5 = -inf)
+// for amcx_range_fixup_kernel
+inline bool wave_redoes_in_kernel(int frame_size) { return frame_size == 1024 || frame_size == 2048 || frame_size == 4096; }
 
-template <int N, bool RANGE = false>
+template <int N>
 inline hipError_t launch_wave_n(const float2* iq, int64_t n_frames, int64_t row_stride, float* out,
                                 int64_t out_stride, hipStream_t stream, int cus) {
-  auto kern = [] {
-    if constexpr (RANGE) return wave::amcx_range_wave_kernel<N>;
-    else return wave::amcx_features18_wave_kernel<N>;
-  }();
+  auto kern = wave::amcx_features18_wave_kernel<N>;
   constexpr int lds = wave::Cfg<N>::kLdsBytes;
   // > 64 KiB of dynamic LDS needs the attribute; it is per device, so once per (kernel, device)
   static bool lds_attr_set[64] = {};
@@ -1635,16 +1624,6 @@ inline hipError_t launch_wave(const float2* iq, int64_t n_frames, int32_t frame_
   }
 }
 
-inline hipError_t launch_wave_range(const float2* iq, int64_t n_frames, int32_t frame_size,
-                                    int64_t row_stride, float* out, int64_t out_stride,
-                                    hipStream_t stream, int cus) {
-  switch (frame_size) {
-    case 1024: return launch_wave_n<1024, true>(iq, n_frames, row_stride, out, out_stride, stream, cus);
-    case 2048: return launch_wave_n<2048, true>(iq, n_frames, row_stride, out, out_stride, stream, cus);
-    case 4096: return launch_wave_n<4096, true>(iq, n_frames, row_stride, out, out_stride, stream, cus);
-    default: return hipErrorNotSupported;
-  }
-}
 #endif
 
 }  // namespace amcx

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Worst case for the range path: a whole data set scaled like raw 24-bit ADC counts (x 1e7), so
 every frame is outside the throughput kernel's fp32 range, is flagged (f5 = -inf) and goes through
-the range pass (amcx_range_wave_kernel: the same machine on a power-of-two pre-scaled copy; frame
+the wave kernel's own re-run (the same machine on a power-of-two pre-scaled copy, inside the launch; frame
 sizes without one: amcx_range_fixup_kernel, fp64 sums).  Prints the rate of that path, of the same
 data pre-scaled by hand into range, and checks both against each other through the features'
 scaling laws."""

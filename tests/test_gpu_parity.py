@@ -704,7 +704,7 @@ def test_complex128_host_entry_chunks_and_rounds_on_device():
 def test_launch_is_graph_capturable():
     """The launch path makes no allocation or synchronisation, so after one warm call
     (which sets the kernel's LDS attribute) it can be captured in a HIP graph and
-    replayed (both launches: wave kernel + range pass)."""
+    replayed (N = 2048: the one launch of the wave kernel)."""
     torch = _torch()
     from amcpy_amd.features import features18
     from amcpy_amd import synth
@@ -1018,7 +1018,7 @@ def test_iq_pair_dataset_through_the_engine():
 
 @pytest.mark.parametrize("N", [1024, 2048, 4096])
 def test_range_pass_mixed_batches_and_scaling_laws(N):
-    """The wave kernel's range pass (frames flagged f5 = -inf redone on a power-of-two pre-scaled copy):
+    """The wave kernel's re-run of out-of-range frames (inside the kernel, on a power-of-two pre-scaled copy):
     in a batch where some frames are in range and others are scaled by 2^30 or 2^-40 (out of range both
     ways), every frame's 18 floats equal what the frame yields alone -- flagged and unflagged frames
     share 8..64-frame scan blocks, with ragged counts -- and a scaled frame equals its in-range

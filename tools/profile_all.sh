@@ -7,8 +7,8 @@ for N in 2048 4096 1024 8192; do
   bash tools/profile.sh ${TAG}_n$N --frame-size $N > gpurun_out/${TAG}_n${N}_profile.log 2>&1 || { echo "profile N=$N failed"; tail -5 gpurun_out/${TAG}_n${N}_profile.log; exit 1; }
   echo "profiled N=$N: $(python3 -c "
 import json; d=json.load(open('gpurun_out/prof_${TAG}_n$N/summary.txt')); b=json.load(open('gpurun_out/prof_${TAG}_n$N/bench_trace.json'))
-k=[v for n,v in d['dispatch_ns'].items() if 'features18' in n][0]; r=[v for n,v in d['dispatch_ns'].items() if 'range' in n][0]
-print(f\"trace: feature kernel {k['mean_of_the_timed_launches']/1e3:.1f} us + range pass {r['mean_of_the_timed_launches']/1e3:.1f} us over the timed launches; events {b['roofline']['mean_launch_ms']*1e3:.1f} us; step {b['ms_per_step']*1e3:.1f} us\")")"
+k=[v for n,v in d['dispatch_ns'].items() if 'features18' in n][0]; r=([v for n,v in d['dispatch_ns'].items() if 'range' in n] or [{'mean_of_the_timed_launches': 0.0}])[0]
+print(f\"trace: feature kernel {k['mean_of_the_timed_launches']/1e3:.1f} us + range fix-up {r['mean_of_the_timed_launches']/1e3:.1f} us over the timed launches; events {b['roofline']['mean_launch_ms']*1e3:.1f} us; step {b['ms_per_step']*1e3:.1f} us\")")"
 done
 bash tools/bench_sizes.sh gpurun_out/${TAG}_bench_all_sizes.jsonl > gpurun_out/${TAG}_bench_all_sizes.txt 2>&1 || exit 1
 cat gpurun_out/${TAG}_bench_all_sizes.txt
