@@ -72,6 +72,31 @@ void run(const char* label, const float2* d_iq, long long F, float* d_out, unsig
     for (unsigned w : o) { hsh ^= w; hsh *= 1099511628211ull; }
     printf(" | out %016llx", hsh);
   }
+  {  // when does each WORKGROUP finish (its slowest wave)?  The kernel lasts as long as the slowest workgroup.  The eight XCDs
+     // run equal slices up to 8 % apart; a pool of frames shared by all workgroups at the end of the launch levels them to
+     // +-3 us and gains 0.7 %, because the power cap hands a finished XCD's budget to the others anyway
+     // (profiles/r4_xcd_pool_ab.txt, tools/experiments/r4_shared_pool.patch)
+    std::vector<double> wg(grid);
+    for (int g = 0; g < grid; ++g) {
+      double m = 0;
+      for (int w = 0; w < kWavesPerWG; ++w) m = std::max(m, life[(size_t)g * kWavesPerWG + w]);
+      wg[g] = m;
+    }
+    std::vector<double> srt = wg;
+    std::sort(srt.begin(), srt.end());
+    double mean = 0;
+    for (double v : wg) mean += v;
+    mean /= grid;
+    printf(" | workgroup finish us min %.0f p10 %.0f med %.0f mean %.0f p90 %.0f max %.0f", srt[0], srt[grid / 10], srt[grid / 2], mean,
+           srt[grid * 9 / 10], srt[grid - 1]);
+    // by XCD (workgroup g runs on XCD g % 8 when the grid is dispatched round-robin)
+    printf(" | mean by g%%8:");
+    for (int x = 0; x < 8; ++x) {
+      double a = 0; int n = 0;
+      for (int g = x; g < grid; g += 8) { a += wg[g]; ++n; }
+      printf(" %.0f", n ? a / n : 0.0);
+    }
+  }
   if (g_valu_per_frame > 0)
     printf(" | VALU issue slots used %.1f %% (%.0f instr x 2 cyc)", 100.0 * g_valu_per_frame * 2.0 / cyc_per_frame_simd,
            g_valu_per_frame);
