@@ -205,10 +205,10 @@ int amcx_features18_c64_ex(const void* iq_dev, int64_t n_frames, int32_t frame_s
     else
       e = amcx::launch_wave(iq, n_frames, frame_size, row_stride_elems, out_dev, out_row_stride, stream, cu_count());
     if (e != hipSuccess) return hip_fail(e, "wave kernel launch");
-    // N = 1024, 2048, 4096: the kernel has re-run the frames outside its fp32 sums' range itself -- one launch, rows final.
-    // The other wave sizes (and the pair experiment) marked such frames in band (f5 = -inf): the block kernel's
-    // fp64-sum routine redoes them.  (Frames with a phase step within an angle rounding of +-pi are finished inside
-    // every wave kernel.)
+    // every wave kernel (N = 128 ... 4096) has re-run the frames outside its fp32 sums' range itself -- one launch, rows
+    // final.  The quad kernel (N = 8192; and the pair experiment) marked such frames in band (f5 = -inf): the block
+    // kernel's fp64-sum routine redoes them.  (Frames with a phase step within an angle rounding of +-pi are finished
+    // inside every throughput kernel.)
     if (amcx::wave_redoes_in_kernel(frame_size)
 #ifdef AMCX_EXP_PAIR4096
         && frame_size != amcx::pair::kN

@@ -1,5 +1,5 @@
-// The launch behind the wave kernel at the frame sizes whose kernel does not re-run out-of-range frames itself
-// (N = 128 ... 512 and 8192; at 1024, 2048, 4096 the wave kernel does: amcx_wave_kernel.h, kRedoHere).
+// The launch behind the quad kernel (N = 8192), which does not re-run out-of-range frames itself (the wave kernels,
+// N = 128 ... 4096, do: amcx_wave_kernel.h).
 // The throughput kernel does its per-sample arithmetic and its sums in fp32; its finaliser marks, in
 // band, the frames it cannot finish -- feature 5 (a standard deviation: >= 0 or NaN) is stored
 //   -infinity : the frame is outside the range in which fp32 sixth-order sums are trustworthy (mean

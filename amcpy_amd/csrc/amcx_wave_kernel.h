@@ -1015,22 +1015,23 @@ __device__ __forceinline__ void wave_exact_frequency(const float2* __restrict__ 
 
 // ---------------------------------------------------------------------------
 // The throughput kernel.  Frames OUTSIDE the fp32 sums' range (mean power outside [1e-10, 1e10], or a sum that is not
-// finite: is_outside_fp32_range) are found by the finaliser and, at N = 1024, 2048, 4096 (kRedoHere), re-run by the same
-// wave right behind its batch, in this launch: each multiplied by an exact power of two first -- 2^-ex, ex the
-// even-rounded exponent of its largest component, so that every component is below 4 and no sixth-order product can
-// overflow -- and un-scaled in the fp64 finaliser through the features' scaling laws (finalize_features<true>).  A row
-// is stored once, final.  (Rounds 2-3 marked such frames in band, f5 = -inf, and re-ran them in a second launch of
-// this machine, amcx_range_wave_kernel: 8 us per step when there was nothing to do, and a consumer that did not order
-// itself behind the call could see marked rows.  Round 4 moved the re-run here: one launch per step, and +1.3 % at
-// N = 2048, +0.6 % at 1024, +-0 at 4096 on the same box, profiles/r4_redo_in_kernel_ab.txt -- with the second copy of
-// the frame code in the kernel the compiler keeps less alive across the finaliser, whose one spilled value is gone.)
-// The other wave sizes still mark in band and leave the re-run to amcx_range_fixup_kernel.
+// finite: is_outside_fp32_range) are found by the finaliser and re-run by the same wave right behind its batch, in this
+// launch: each multiplied by an exact power of two first -- 2^-ex, ex the even-rounded exponent of its largest
+// component, so that every component is below 4 and no sixth-order product can overflow -- and un-scaled in the fp64
+// finaliser through the features' scaling laws (finalize_features<true>).  A row is stored once, final.  (Rounds 2-3
+// marked such frames in band, f5 = -inf, and re-ran them in a second launch -- of this machine at N = 1024, 2048, 4096,
+// amcx_range_wave_kernel, of the block kernel's fp64 routine at the short sizes: 8 us per step when there was nothing
+// to do, and a consumer that did not order itself behind the call could see marked rows.  Round 4 moved the re-run
+// here: one launch per step; same box, through the library: +1.3 % at N = 2048, +0.6 % at 1024, +-0 at 4096, +3.0 % /
+// +0.5 % / +1.8 % at 128 / 256 / 512 -- profiles/r4_redo_in_kernel_ab.txt.  A launch boundary costs more than the 8 us of
+// the second kernel: 4 096 persistent waves drain and ramp up twice per step.)  The short-frame kernels (N < 1024),
+// whose frames share the FFT's back half in groups, re-run a frame as a group of one.
 template <int N>
 __device__ __forceinline__ void wave_body(
     const float2* __restrict__ iq, long long n_frames, long long row_stride,
     float* __restrict__ out, long long out_stride AMCX_STAMP_ARG) {
   using C = Cfg<N>;
-  constexpr bool kRedoHere = N >= 1024 && N <= 4096;     // the sizes whose frame sits in one register set
+  constexpr bool kRedoHere = true;                       // every wave-kernel size (the quad kernel, N = 8192, still marks in band)
   constexpr int R = C::kFftRows, ROWS = C::kHeldRows;
   constexpr int kWavesPerWG = C::kWavesPerWG, kThreads = C::kThreads, kTailFrames = C::kTailFrames;
   constexpr int kFramesPerWave = C::kFramesPerWave, kTailChunk = C::kTailChunk;
@@ -1447,6 +1448,7 @@ __device__ __forceinline__ void wave_body(
 
     using Slot0 = std::integral_constant<int, 0>;
     // frames `todo` (bit i: frame f0 + i) again, each multiplied by 2^-ex first (see the comment above wave_body)
+    [[maybe_unused]] const LaneAddr& la_redo = la;
     auto rerun_scaled = [&](unsigned long long todo) {
       while (todo != 0) {
         int cnt = 0;
@@ -1468,7 +1470,19 @@ __device__ __forceinline__ void wave_body(
             constexpr int e = decltype(ee)::value;
             xr[e] *= sc; xi[e] *= sc;
           });
+          if constexpr (C::kGroup > 1) lds_wave_fence();      // the previous exchange reads are done
           frame(xr, xi, cnt, Slot0{});
+          if constexpr (C::kGroup > 1) {
+            // a group of ONE: the frame's pass-1 output sits in k1 slots [0, R); the shared back half runs over all
+            // eight slots (the others hold stale data) and lanes [0, 8 R) come out with this frame's bins
+            float pk = fft_back(la_redo);
+            pk = __builtin_fmaxf(pk, dpp<kQuadXor1>(pk));
+            pk = __builtin_fmaxf(pk, dpp<kQuadXor2>(pk));
+            pk = __builtin_fmaxf(pk, dpp<kRowHalfMirror>(pk));
+            if constexpr (R >= 2) pk = __builtin_fmaxf(pk, dpp<kRowMirror>(pk));
+            if constexpr (R >= 4) pk = __builtin_fmaxf(pk, dpp<kRowBcast15, 0xa, 0xf, false>(pk));
+            if (lane == 8 * R - 1) stash[cnt * kStashStride + kNumSums] = pk;
+          }
           if (lane == 63)
             stash[(cnt * C::kFlushes + (C::kFlushes - 1)) * kStashStride + kNumSums + 5] = (float)((ex + 128) * 64 + idx);
         }
@@ -1583,9 +1597,9 @@ inline const char* wave_kernel_name(int frame_size) {
 }
 
 #ifndef AMCX_WAVE_STAMPS
-// sizes whose kernel re-runs out-of-range frames itself (wave_body: kRedoHere); the others mark them in band (f5 = -inf)
-// for amcx_range_fixup_kernel
-inline bool wave_redoes_in_kernel(int frame_size) { return frame_size == 1024 || frame_size == 2048 || frame_size == 4096; }
+// sizes whose kernel re-runs out-of-range frames itself (wave_body): every wave-kernel size; the quad kernel (N = 8192)
+// marks them in band (f5 = -inf) for amcx_range_fixup_kernel
+inline bool wave_redoes_in_kernel(int frame_size) { return frame_size <= 4096; }
 
 template <int N>
 inline hipError_t launch_wave_n(const float2* iq, int64_t n_frames, int64_t row_stride, float* out,

@@ -1016,7 +1016,7 @@ def test_iq_pair_dataset_through_the_engine():
     _assert_parity(want, orc.features18_batch(x), x, "RadioML-shaped (I, Q) pairs, N = 1024")
 
 
-@pytest.mark.parametrize("N", [1024, 2048, 4096])
+@pytest.mark.parametrize("N", [128, 256, 512, 1024, 2048, 4096])
 def test_range_pass_mixed_batches_and_scaling_laws(N):
     """The wave kernel's re-run of out-of-range frames (inside the kernel, on a power-of-two pre-scaled copy):
     in a batch where some frames are in range and others are scaled by 2^30 or 2^-40 (out of range both
