@@ -1047,6 +1047,46 @@ def test_range_pass_mixed_batches_and_scaling_laws(N):
     assert np.all(got[kinds == 0] == ref[pick][kinds == 0].astype(np.float32))
 
 
+@pytest.mark.parametrize("N", [512, 1024, 2048])
+def test_out_of_range_frames_scattered_over_a_full_grid(N):
+    """The in-kernel re-run under a FULL grid: 40 000 frames (every workgroup's slice has a body, a tail and batches
+    with none, one or several out-of-range frames), 1 % of them scaled by 2^28 or 2^-36 -- half of those noiseless
+    axis-aligned BPSK, whose every phase step is an exact +-pi tie, so that the same frame is out of range AND
+    tie-flagged.  Every row equals, through the exact scaling laws, the row of its in-range original computed in a
+    small launch of its own: nothing is lost, doubled or left marked whichever wave and chunk a frame lands in."""
+    torch = _torch()
+    from amcpy_amd import synth
+    from amcpy_amd.features import features18
+    rng = np.random.default_rng(77 + N)
+    base = np.concatenate([synth.host_block(m, 6.0, 4, N, seed=900 + i) for i, m in enumerate(synth.MODS6)])     # 24 frames
+    ties = np.tile(np.array([1.0, 1.0, -1.0, 1.0, -1.0, -1.0, 1.0, -1.0], dtype=np.complex64), (4, N // 8))        # +-pi steps
+    ties[1] *= 1j
+    ties[2, ::3] *= -1
+    ties[3] *= (1 + 0j)
+    base = np.concatenate([base, ties]).astype(np.complex64)                                                    # 28 originals
+    F = 40000
+    pick = rng.integers(0, 24, size=F)
+    kinds = np.zeros(F, dtype=np.int64)
+    out_of_range = rng.choice(F, size=F // 100, replace=False)
+    kinds[out_of_range] = rng.integers(1, 3, size=out_of_range.size)
+    pick[out_of_range[::2]] = 24 + rng.integers(0, 4, size=out_of_range[::2].size)      # half of them also tie-flagged
+    scale = np.array([1.0, 2.0 ** 28, 2.0 ** -36])[kinds]
+    batch = torch.from_numpy(base)[torch.from_numpy(pick)].cuda() * torch.from_numpy(scale.astype(np.float32)).cuda()[:, None]
+    got = features18(batch).cpu().numpy()
+    ref = features18(torch.from_numpy(base).cuda()).cpu().numpy().astype(np.float64)
+    assert not np.isneginf(got[:, 4]).any(), "an in-band range mark reached the caller"
+    assert ((got[:, 4] >= 0) | np.isnan(got[:, 4])).all(), "a tie flag (negative f5) reached the caller"
+    order = np.array([2, 0, 0, 0, 0, 1, 0.5, 0, 0, 2, 2, 4, 4, 4, 6, 6, 6, 6])
+    with np.errstate(all="ignore"):
+        want = (ref[pick] * scale[:, None] ** order[None, :]).astype(np.float32)
+    same = np.isfinite(want) & (np.abs(want) > 1.2e-38)
+    assert np.array_equal(np.isinf(got), np.isinf(want))
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    bad = np.argwhere(same & ~np.isclose(got, want, rtol=2.5e-7, atol=0))
+    assert bad.size == 0, (N, bad[:5], [(got[i, j], want[i, j], kinds[i], pick[i]) for i, j in bad[:5]])
+    assert np.array_equal(got[kinds == 0], ref[pick][kinds == 0].astype(np.float32), equal_nan=True)
+
+
 def test_ends_of_float32_through_the_range_pass():
     """range_extreme_n2048.npz (captured from the reference): the range fixture's frames at 1e-30, 1e-20,
     1e20 and 1e30 -- |x|^2 itself leaves float32.  The reference, evaluating in complex128, still returns
