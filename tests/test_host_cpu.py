@@ -993,8 +993,6 @@ def test_bench_self_launch_process_handling(tmp_path):
     non-zero exit becomes the job's and the ranks still running are killed, a time limit kills them all, and a
     clean run returns 0."""
     import time
-    sys.path.insert(0, str(REPO))
-    import bench
     script = tmp_path / "rank.py"
     script.write_text(textwrap.dedent("""
         import os, sys, time, pathlib
