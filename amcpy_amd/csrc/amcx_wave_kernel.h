@@ -49,8 +49,8 @@
 // tables is bank-conflict free and addressed as lane_base + immediate.
 //
 // One workgroup per CU.  N <= 1024: 768 threads = 12 waves = 3 per SIMD.  N = 2048: 1024 threads = 16 waves = 4 per
-// SIMD (128 VGPRs; one fp64 value of the per-batch finaliser is spilled -- a scratch store and a load per four frames,
-// none in the frame body: amcpy_amd/csrc/kernel_resources.json; the exchange buffer at its exact 8672 bytes and batches of four frames make
+// SIMD (128 VGPRs; two lane-dependent values, 12 bytes, are spilled in the prologue: one 32-bit reload per frame at the
+// end of the wave reduction, one 64-bit reload per batch of four: amcpy_amd/csrc/kernel_resources.json; the exchange buffer at its exact 8672 bytes and batches of four frames make
 // the LDS fit): 4.3 % fewer SIMD cycles per frame than with 12 waves, of which the power cap takes 2.5 % back
 // as clock -- +1.2 ... +1.9 % frames/s for the kernel alone, +0.5 % through the library's step (DESIGN.md section 4.1;
 // -DAMCX_EXP_WAVES12 builds the 12-wave form).
@@ -64,6 +64,23 @@
 #include <utility>
 
 #include "amcx_math.h"
+
+// WAVE PRIORITY.  A SIMD issues vector instructions by priority first, then by age (MI355X_MICROARCH.md, "Two waves per SIMD").
+// Four waves share one here, each somewhere else in its frame: in the statistics / envelope sweeps (dense fp32 arithmetic, every
+// issue slot used), in the wave reduction (dependent permlane / DPP chains), or in the FFT (three register passes between LDS
+// exchanges: it waits a lot).  With all of them at priority 0 the oldest wave wins every contested slot whatever it is doing.
+// Raising a wave to s_setprio 1 for everything EXCEPT its FFT -- bits 0-2 below -- lets the arithmetic-dense phases run at
+// full rate and the FFT fill the gaps its own waits leave: same instructions, same results, and, through the library on one
+// box in alternating runs (profiles/r4_wave_priority_ab.txt):
+//     N = 128 +4.7 %   256 +3.2 %   512 +1.5 %   1024 +4.3 %   2048 +4.4 ... +6.2 %   4096 +5.2 ... +5.9 %
+// The level does not matter (1, 2, 3: +6.0 / +5.9 / +5.7 % at N = 2048), the extent does: sweep only +-0; sweep + envelope
+// +1.1 %; sweep + envelope + reduction +6.0 % (this); + FFT pass 1 +4.3 %; the reduction alone +0.6 %; + the finaliser: no
+// change.  (The opposite choice -- priority for the FFT -- costs 2.9 %, a static priority for half of the waves 3.2 %.)
+// Which sections of a frame run at s_setprio 1: bit 0 statistics sweep, 1 envelope sweep, 2 wave reduction, 3 FFT pass 1,
+// 4 FFT passes 2-3, 5 the batch finaliser.
+#ifndef AMCX_PRIO_MASK
+#define AMCX_PRIO_MASK 7
+#endif
 
 namespace amcx {
 namespace wave {
@@ -106,7 +123,7 @@ struct Cfg {
   static constexpr int kTailChunk = kGroup > 2 ? kGroup : 2;
   // waves per workgroup = waves per CU: 2 per SIMD when the frame alone takes 128 VGPRs (N >= 4096), 3 per SIMD for
   // the short frames (16 waves at N = 1024, 114 VGPRs, measured no faster), 4 per SIMD at N = 2048: the kernel fits
-  // 128 VGPRs there without a spill, the fourth wave hides 4.3 % of the SIMD's cycles and the power cap gives 2.5 %
+  // 128 VGPRs there with three spilled dwords (kernel_resources.json), the fourth wave hides 4.3 % of the SIMD's cycles and the power cap gives 2.5 %
   // of them back as clock -- +1.2 ... +1.9 % frames/s for the kernel alone in alternating same-box rounds, +0.5 % through
   // the library's step (profiles/r3_waves16_ab.txt)
 #if defined(AMCX_EXP_WAVES12)
@@ -817,6 +834,7 @@ __device__ __forceinline__ float fft_peak(const float (&xr)[2 * R], const float 
       zr[n2] = v.x; zi[n2] = v.y;
     });
     if constexpr (gph == 0) asm volatile("; MARK fft2");
+    if constexpr (gph == 0) __builtin_amdgcn_s_setprio((AMCX_PRIO_MASK >> 4) & 1);
     __builtin_amdgcn_sched_barrier(0);
     // pass 2 over n2, twist (W_(NF/8)^k1)^n2; exchange 2; pass 3 over n3, twist (W_NF^(R k2 + k1))^n3
     const char* const tw2 = la.tw2;
@@ -1171,6 +1189,7 @@ __device__ __forceinline__ void wave_body(
       constexpr bool kAInRegs = C::kGroup > 1;   // |x| stays in registers: exchange 1 is shared by the group
 #endif
       asm volatile("; MARK load");
+      __builtin_amdgcn_s_setprio((AMCX_PRIO_MASK >> 0) & 1);
       AMCX_STAMP(7);
       // wave reduction of a frame's 27 per-lane sums into one stash row
       auto reduce_sums = [&](float (&r28)[28], float (&r7)[7]) __attribute__((always_inline)) {
@@ -1275,6 +1294,7 @@ __device__ __forceinline__ void wave_body(
         });
       }
       asm volatile("; MARK envelope");
+      __builtin_amdgcn_s_setprio((AMCX_PRIO_MASK >> 1) & 1);
       AMCX_STAMP(0);
       __builtin_amdgcn_sched_barrier(0);
       // envelope second sweep about the exact mean
@@ -1297,6 +1317,7 @@ __device__ __forceinline__ void wave_body(
       // registers are free while it runs
       // =====================================================================
       asm volatile("; MARK reduce");
+      __builtin_amdgcn_s_setprio((AMCX_PRIO_MASK >> 2) & 1);
       AMCX_STAMP(3);
       __builtin_amdgcn_sched_barrier(0);
       float* const row = stash + (g * C::kFlushes + (C::kFlushes - 1)) * kStashStride;   // the frame's last row
@@ -1322,6 +1343,7 @@ __device__ __forceinline__ void wave_body(
       asm volatile("; MARK fft1");
       AMCX_STAMP(1);
       __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio((AMCX_PRIO_MASK >> 3) & 1);
       float peak;
       if constexpr (C::kGroup > 1) {
         fft_front<R, SLOT * R>(xr, xi, la);     // the group's shared back half follows the last frame
@@ -1543,6 +1565,7 @@ __device__ __forceinline__ void wave_body(
 
     AMCX_STAMP(4);
     asm volatile("; MARK finalize");
+    __builtin_amdgcn_s_setprio((AMCX_PRIO_MASK >> 5) & 1);
     [[maybe_unused]] const unsigned long long left_over = finalise(std::false_type{}, n_here);
     if constexpr (kRedoHere) {
       asm volatile("; MARK redo");
