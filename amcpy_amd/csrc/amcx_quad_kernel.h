@@ -173,6 +173,17 @@ struct Recentred {
   }
 };
 
+// Wave priority by section (bit 0 phase A, 1 envelope + reduction, 2 radix-4 rounds, 3 pass 1 of the register FFT; its
+// passes 2-3 drop to 0 in fft_peak): a SIMD issues by priority first, see AMCX_PRIO_MASK in amcx_wave_kernel.h.  Here two
+// workgroups share a CU = two waves per SIMD, each paced by its quad's four barriers.  Same box, alternating, through
+// the library (profiles/r4_wave_priority_ab.txt, section 6): phase A alone at priority 1 +6.8 % (the product), A + B
+// +4.9 %, A + B + radix-4 rounds +6.6 %, everything but FFT passes 2-3 +4.9 %, radix-4 rounds alone +1.1 %, FFT pass 1
+// alone +0.1 %.  Same instructions, bit-identical results.
+#ifndef AMCX_QUAD_PRIO_MASK
+#define AMCX_QUAD_PRIO_MASK 1
+#endif
+#define AMCX_QUAD_PRIO(b) __builtin_amdgcn_s_setprio((AMCX_QUAD_PRIO_MASK >> (b)) & 1)
+
 __global__ __launch_bounds__(kThreads, 2) void amcx_features18_quad_kernel(
     const float2* __restrict__ iq, long long n_frames, long long row_stride,
     float* __restrict__ out, long long out_stride) {
@@ -326,6 +337,7 @@ __global__ __launch_bounds__(kThreads, 2) void amcx_features18_quad_kernel(
       float xr[2 * kRowsQ], xi[2 * kRowsQ];
       Stats S;
       // ---- phase A: this wave's quarter (requested a frame ago), statistics sweep, rows 0-7 published ----
+      AMCX_QUAD_PRIO(0);
       static_for<kRowsQ>([&](auto ii) {
         constexpr int i = decltype(ii)::value;
         xr[2 * i] = nxt[i].x; xi[2 * i] = nxt[i].y; xr[2 * i + 1] = nxt[i].z; xi[2 * i + 1] = nxt[i].w;
@@ -354,6 +366,7 @@ __global__ __launch_bounds__(kThreads, 2) void amcx_features18_quad_kernel(
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();                                      // (1) rows 0-7 of every quarter and the envelope partial sums are in LDS
       // ---- phase B: envelope about the exact mean, sums -> stash, radix-4 stage in two rounds ----
+      AMCX_QUAD_PRIO(1);
       {
         const float mu = ((mu_part[0] + mu_part[1]) + (mu_part[2] + mu_part[3])) * (1.0f / (float)kN);
         static_for<2 * kRowsQ>([&](auto ee) {
@@ -374,6 +387,7 @@ __global__ __launch_bounds__(kThreads, 2) void amcx_features18_quad_kernel(
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+      AMCX_QUAD_PRIO(2);
       radix4_round(xr, xi, Row0{});
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();                                      // (2) round 1 has been read
@@ -392,6 +406,7 @@ __global__ __launch_bounds__(kThreads, 2) void amcx_features18_quad_kernel(
       if (more && !finalise_now) load_quarter(nxt, f_next);
       __builtin_amdgcn_sched_barrier(0);
       // ---- phase C: 2048-point register FFT of y_q, its peak into the stash row ----
+      AMCX_QUAD_PRIO(3);
       {
         const float peak = fft_peak<R>(xr, xi, la);
         const float pk = wave_max_l63(peak);

@@ -48,8 +48,9 @@
 // Every ds_write_b64 / ds_read_b64 / ds_read_b128 of the exchanges and twiddle
 // tables is bank-conflict free and addressed as lane_base + immediate.
 //
-// One workgroup per CU.  N <= 1024: 768 threads = 12 waves = 3 per SIMD.  N = 2048: 1024 threads = 16 waves = 4 per
-// SIMD (128 VGPRs; two lane-dependent values, 12 bytes, are spilled in the prologue: one 32-bit reload per frame at the
+// One workgroup per CU.  N <= 512: 768 threads = 12 waves = 3 per SIMD.  N = 1024 and N = 2048: 1024 threads = 16 waves =
+// 4 per SIMD (N = 1024: 128 VGPRs, no spill, no second register set for the next frame -- the other waves cover the load;
+// N = 2048: 128 VGPRs; two lane-dependent values, 12 bytes, are spilled in the prologue: one 32-bit reload per frame at the
 // end of the wave reduction, one 64-bit reload per batch of four: amcpy_amd/csrc/kernel_resources.json; the exchange buffer at its exact 8672 bytes and batches of four frames make
 // the LDS fit): 4.3 % fewer SIMD cycles per frame than with 12 waves, of which the power cap takes 2.5 % back
 // as clock -- +1.2 ... +1.9 % frames/s for the kernel alone, +0.5 % through the library's step (DESIGN.md section 4.1;
@@ -113,8 +114,6 @@ struct Cfg {
   // moves the worst scaled error of the N = 4096 sweep from 5.8e-6 to 6.9e-6
   static constexpr int kFlushes = N == 4096 ? 2 : 1;
   static constexpr int kStashBytes = kFramesPerWave * kFlushes * kStashStride * 4;
-  // next frame of the chunk loaded into a second register set while this one is processed
-  static constexpr bool kPrefetch = N <= 1024;
   // short frames (R < 8 rows) fill only R of the 8 k1 slots of exchange 1, so kGroup = 8/R
   // consecutive frames share one run of FFT passes 2 and 3: frame j's k1 goes to slot j R + k1,
   // its bins come out in lanes [8 R j, 8 R (j+1))
@@ -122,15 +121,21 @@ struct Cfg {
   // frames per grab over the last stretch of a workgroup's slice (levels the waves' finish)
   static constexpr int kTailChunk = kGroup > 2 ? kGroup : 2;
   // waves per workgroup = waves per CU: 2 per SIMD when the frame alone takes 128 VGPRs (N >= 4096), 3 per SIMD for
-  // the short frames (16 waves at N = 1024, 114 VGPRs, measured no faster), 4 per SIMD at N = 2048: the kernel fits
-  // 128 VGPRs there with three spilled dwords (kernel_resources.json), the fourth wave hides 4.3 % of the SIMD's cycles and the power cap gives 2.5 %
-  // of them back as clock -- +1.2 ... +1.9 % frames/s for the kernel alone in alternating same-box rounds, +0.5 % through
-  // the library's step (profiles/r3_waves16_ab.txt)
+  // the short frames (their batches of 16 / 32 frames leave LDS for 12 waves; halving the batch doubles the fp64
+  // finaliser's share), 4 per SIMD at N = 2048 and N = 1024: the kernels fit 128 VGPRs there (2048: three spilled
+  // dwords, 1024: none -- kernel_resources.json).  N = 2048: the fourth wave hides 4.3 % of the SIMD's cycles, +0.5 %
+  // through the library's step in round 3 (profiles/r3_waves16_ab.txt), +2.5 % under wave priority
+  // (profiles/r4_wave_priority_ab.txt, section 7).  N = 1024 (round 4): 16 waves AND no second register set, +2.9 %
+  // same box through the library (section 8); 16 waves with the prefetch kept spill 37 registers, -2.2 %.
 #if defined(AMCX_EXP_WAVES12)
   static constexpr int kWavesPerWG = kSplit ? 8 : 12;
 #else
-  static constexpr int kWavesPerWG = kSplit ? 8 : (N == 2048 ? 16 : 12);
+  static constexpr int kWavesPerWG = kSplit ? 8 : (N == 2048 || N == 1024 ? 16 : 12);
 #endif
+  // next frame of the chunk loaded into a second register set while this one is processed: the short frames, whose
+  // load latency is a large share of the frame -- unless four waves share the SIMD and cover it for each other
+  // (at N = 1024 with 12 waves the second set buys nothing any more under wave priority: -0.1 %)
+  static constexpr bool kPrefetch = N <= 1024 && kWavesPerWG < 16;
   static constexpr int kThreads = 64 * kWavesPerWG;
   static constexpr int kTailFrames = kWavesPerWG * kFramesPerWave;
   static constexpr int kRows = N / 128;                // rows of 128 samples per frame
