@@ -77,10 +77,17 @@
 // The level does not matter (1, 2, 3: +6.0 / +5.9 / +5.7 % at N = 2048), the extent does: sweep only +-0; sweep + envelope
 // +1.1 %; sweep + envelope + reduction +6.0 % (this); + FFT pass 1 +4.3 %; the reduction alone +0.6 %; + the finaliser: no
 // change.  (The opposite choice -- priority for the FFT -- costs 2.9 %, a static priority for half of the waves 3.2 %.)
+// Different levels per section (AMCX_PRIO_LEVELS): reduction above envelope above sweep +0.2 ... +0.5 % (noise level), the
+// sweep above the others -2.7 %.
 // Which sections of a frame run at s_setprio 1: bit 0 statistics sweep, 1 envelope sweep, 2 wave reduction, 3 FFT pass 1,
 // 4 FFT passes 2-3, 5 the batch finaliser.
 #ifndef AMCX_PRIO_MASK
 #define AMCX_PRIO_MASK 7
+#endif
+#ifdef AMCX_PRIO_LEVELS   // experiment: a level 0-3 per section, one hex digit each, section 0 in the lowest
+#define AMCX_PRIO_OF(b) ((AMCX_PRIO_LEVELS >> (4 * (b))) & 3)
+#else
+#define AMCX_PRIO_OF(b) ((AMCX_PRIO_MASK >> (b)) & 1)
 #endif
 
 namespace amcx {
@@ -839,7 +846,7 @@ __device__ __forceinline__ float fft_peak(const float (&xr)[2 * R], const float 
       zr[n2] = v.x; zi[n2] = v.y;
     });
     if constexpr (gph == 0) asm volatile("; MARK fft2");
-    if constexpr (gph == 0) __builtin_amdgcn_s_setprio((AMCX_PRIO_MASK >> 4) & 1);
+    if constexpr (gph == 0) __builtin_amdgcn_s_setprio(AMCX_PRIO_OF(4));
     __builtin_amdgcn_sched_barrier(0);
     // pass 2 over n2, twist (W_(NF/8)^k1)^n2; exchange 2; pass 3 over n3, twist (W_NF^(R k2 + k1))^n3
     const char* const tw2 = la.tw2;
@@ -1194,7 +1201,7 @@ __device__ __forceinline__ void wave_body(
       constexpr bool kAInRegs = C::kGroup > 1;   // |x| stays in registers: exchange 1 is shared by the group
 #endif
       asm volatile("; MARK load");
-      __builtin_amdgcn_s_setprio((AMCX_PRIO_MASK >> 0) & 1);
+      __builtin_amdgcn_s_setprio(AMCX_PRIO_OF(0));
       AMCX_STAMP(7);
       // wave reduction of a frame's 27 per-lane sums into one stash row
       auto reduce_sums = [&](float (&r28)[28], float (&r7)[7]) __attribute__((always_inline)) {
@@ -1299,7 +1306,7 @@ __device__ __forceinline__ void wave_body(
         });
       }
       asm volatile("; MARK envelope");
-      __builtin_amdgcn_s_setprio((AMCX_PRIO_MASK >> 1) & 1);
+      __builtin_amdgcn_s_setprio(AMCX_PRIO_OF(1));
       AMCX_STAMP(0);
       __builtin_amdgcn_sched_barrier(0);
       // envelope second sweep about the exact mean
@@ -1322,7 +1329,7 @@ __device__ __forceinline__ void wave_body(
       // registers are free while it runs
       // =====================================================================
       asm volatile("; MARK reduce");
-      __builtin_amdgcn_s_setprio((AMCX_PRIO_MASK >> 2) & 1);
+      __builtin_amdgcn_s_setprio(AMCX_PRIO_OF(2));
       AMCX_STAMP(3);
       __builtin_amdgcn_sched_barrier(0);
       float* const row = stash + (g * C::kFlushes + (C::kFlushes - 1)) * kStashStride;   // the frame's last row
@@ -1348,7 +1355,7 @@ __device__ __forceinline__ void wave_body(
       asm volatile("; MARK fft1");
       AMCX_STAMP(1);
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio((AMCX_PRIO_MASK >> 3) & 1);
+      __builtin_amdgcn_s_setprio(AMCX_PRIO_OF(3));
       float peak;
       if constexpr (C::kGroup > 1) {
         fft_front<R, SLOT * R>(xr, xi, la);     // the group's shared back half follows the last frame
@@ -1570,7 +1577,7 @@ __device__ __forceinline__ void wave_body(
 
     AMCX_STAMP(4);
     asm volatile("; MARK finalize");
-    __builtin_amdgcn_s_setprio((AMCX_PRIO_MASK >> 5) & 1);
+    __builtin_amdgcn_s_setprio(AMCX_PRIO_OF(5));
     [[maybe_unused]] const unsigned long long left_over = finalise(std::false_type{}, n_here);
     if constexpr (kRedoHere) {
       asm volatile("; MARK redo");
