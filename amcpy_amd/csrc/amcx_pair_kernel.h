@@ -1,7 +1,9 @@
 // EXPERIMENT (-DAMCX_EXP_PAIR4096; not in the product library): N = 4096 (BASELINE configs[2]) with TWO wavefronts per
 // frame, each holding one half of it in registers.
 //
-// RESULT (round 4, same box, alternating runs through the library, tools/ab_lib.sh "-DAMCX_EXP_PAIR4096" 2 4096;
+// RESULT under wave priority (later in round 4, the product's sweeps at s_setprio 1): 85.8 M frames/s with AMCX_PAIR_PRIO_MASK = 3
+// against 83.5 M without and 92.5 M for the one-wave kernel -- 7.3 % SLOWER (profiles/r4_pair_vs_wave4096_ab.txt, second part).
+// RESULT before it (round 4, same box, alternating runs through the library, tools/ab_lib.sh "-DAMCX_EXP_PAIR4096" 2 4096;
 // profiles/r4_pair_vs_wave4096_ab.txt): 85.2-85.8 M frames/s against 86.7-87.2 M for the one-wave kernel -- 1.7 % SLOWER,
 // where the bar for adopting it was +3 %.  Parity is green (the N = 4096 golden, ragged, variant and full-size tests
 // pass through it).  Why it does not pay: what four waves per SIMD buy over two on this arithmetic is ~8 % (measured on
@@ -97,6 +99,14 @@ constexpr int kLdsBytes = kOffCounters + 8;
 static_assert(kLdsBytes <= 163840, "one workgroup per CU must fit in 160 KiB of LDS");
 static_assert(kRoundRows * 1024 <= kRegionBytes, "a wave's region holds a round's rows");
 constexpr int kSpinLimit = 1 << 22;
+
+// Wave priority as in amcx_wave_kernel.h (AMCX_PRIO_MASK): which sections of a frame run at s_setprio 1 -- bit 0 the statistics
+// sweep (phase A), bit 1 envelope + wave reduction + round 1 of the radix-2 stage (phase B), bit 2 round 2 of the radix-2
+// stage.  A wave drops to 0 while it waits at a meeting and for its FFT.
+#ifndef AMCX_PAIR_PRIO_MASK
+#define AMCX_PAIR_PRIO_MASK 3
+#endif
+#define AMCX_PAIR_PRIO(b) __builtin_amdgcn_s_setprio((AMCX_PAIR_PRIO_MASK >> (b)) & 1)
 
 // W_4096^(2 l + b) = (cos, -sin)(2 pi (2 l + b) / 4096) for lane l, b = 0, 1: the lane factors of the radix-2 stage, correctly
 // rounded (generated with numpy in float64).  1 KiB of constant global memory that every wave re-reads from the caches
@@ -260,7 +270,13 @@ __global__ __launch_bounds__(kThreads, kWavesPerWG / 4) void amcx_features18_pai
     }
     alive = false;
   };
-  auto meet = [&]() { if (alive) { arrive(); wait(); } };
+  auto meet = [&]() {
+    if (alive) {
+      arrive();
+      if (AMCX_PAIR_PRIO_MASK != 0) __builtin_amdgcn_s_setprio(0);
+      wait();
+    }
+  };
 
   // ---- work: the workgroup owns a contiguous slice of frames; its pairs take chunks of it ---------
   const long long per_wg = (n_frames + gridDim.x - 1) / gridDim.x;
@@ -316,6 +332,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerWG / 4) void amcx_features18_pai
           xr[2 * i] = v[i].x; xi[2 * i] = v[i].y; xr[2 * i + 1] = v[i].z; xi[2 * i + 1] = v[i].w;
         });
       }
+      AMCX_PAIR_PRIO(0);
       Stats S;
       static_for<kRowsH>([&](auto ii) {
         constexpr int i = decltype(ii)::value;
@@ -339,6 +356,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerWG / 4) void amcx_features18_pai
       __builtin_amdgcn_sched_barrier(0);
       meet();                                                // (1) rows 0-7 of both halves and both envelope sums are in LDS
       if (!alive) break;
+      AMCX_PAIR_PRIO(1);
       if (h == 0) {
         // the phase step that crosses the middle of the frame: half 1's first sample is row 0, lane 0, b = 0 of what the
         // partner has just published (a broadcast read); lane 63 holds this half's last sample, to which row<.., LAST>
@@ -384,6 +402,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerWG / 4) void amcx_features18_pai
       __builtin_amdgcn_sched_barrier(0);
       meet();                                                // (2) round 1 has been read
       if (!alive) break;
+      AMCX_PAIR_PRIO(2);
       {
         char* const mine = ex + lane_here() * 16;
         static_for<kRoundRows>([&](auto ii) {
@@ -395,10 +414,12 @@ __global__ __launch_bounds__(kThreads, kWavesPerWG / 4) void amcx_features18_pai
       }
       meet();                                                // (3) rows 8-15 of both halves are in LDS
       if (!alive) break;
+      AMCX_PAIR_PRIO(2);
       if (h == 0) radix2_stage<0, kRoundRows>(xr, xi, ex_other, lane_here(), lw); else radix2_stage<1, kRoundRows>(xr, xi, ex_other, lane_here(), lw);
       __builtin_amdgcn_sched_barrier(0);
       meet();                                                // (4) round 2 has been read: my region is my FFT scratch now
       if (!alive) break;
+      if (AMCX_PAIR_PRIO_MASK != 0) __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       // ---- phase C: 2048-point register FFT of my branch, its peak into my stash row ----
       {
