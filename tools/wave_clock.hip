@@ -134,6 +134,22 @@ void all(long long F) {
   if (want(5)) run<N>("random, 192 workgroups", d_iq, F, d_out, d_st, 192, T);
   if (want(6)) run<N>("random, 128 workgroups", d_iq, F, d_out, d_st, 128, T);
   if (want(7)) run<N>("random, 64 workgroups", d_iq, F, d_out, d_st, 64, T);
+  // the same random frames in allocations of other kinds (hipExtMallocWithFlags): does the memory type of the caller's
+  // buffer -- what L2 and the memory-side cache may keep of a stream nobody reads twice -- move the power-capped rate?
+  if (want(8) && g_only == 8) {
+    const struct { const char* name; unsigned flags; } kinds[] = {
+        {"random, uncached allocation", hipDeviceMallocUncached}, {"random, fine-grained allocation", hipDeviceMallocFinegrained}};
+    for (const auto& kind : kinds) {
+      float2* d_alt = nullptr;
+      CHECK(hipExtMallocWithFlags(reinterpret_cast<void**>(&d_alt), n_samp * 8, kind.flags));
+      CHECK(hipMemcpy(d_alt, d_iq, n_samp * 8, hipMemcpyDeviceToDevice));
+      run<N>("random, all CUs (hipMalloc)", d_iq, F, d_out, d_st, 256, T);
+      run<N>(kind.name, d_alt, F, d_out, d_st, 256, T);
+      run<N>("random, all CUs (hipMalloc)", d_iq, F, d_out, d_st, 256, T);
+      run<N>(kind.name, d_alt, F, d_out, d_st, 256, T);
+      CHECK(hipFree(d_alt));
+    }
+  }
   CHECK(hipFree(d_iq)); CHECK(hipFree(d_zero)); CHECK(hipFree(d_out)); CHECK(hipFree(d_st));
 }
 
