@@ -15,7 +15,9 @@
 #ifdef AMCX_EXP_PAIR4096      // experiment: two waves per frame at N = 4096 (measured 1.7 % slower: profiles/r4_pair_vs_wave4096_ab.txt)
 #include "amcx_pair_kernel.h"
 #endif
+#ifdef AMCX_EXP_PAIR4096      // the pair experiment still marks out-of-range frames for a second launch
 #include "amcx_fixup_kernel.h"
+#endif
 #include "amcx_post_kernels.h"
 #include "amcx_pack_kernel.h"
 #include "amcx_upload.h"
@@ -205,18 +207,15 @@ int amcx_features18_c64_ex(const void* iq_dev, int64_t n_frames, int32_t frame_s
     else
       e = amcx::launch_wave(iq, n_frames, frame_size, row_stride_elems, out_dev, out_row_stride, stream, cu_count());
     if (e != hipSuccess) return hip_fail(e, "wave kernel launch");
-    // every wave kernel (N = 128 ... 4096) has re-run the frames outside its fp32 sums' range itself -- one launch, rows
-    // final.  The quad kernel (N = 8192; and the pair experiment) marked such frames in band (f5 = -inf): the block
-    // kernel's fp64-sum routine redoes them.  (Frames with a phase step within an angle rounding of +-pi are finished
-    // inside every throughput kernel.)
-    if (amcx::wave_redoes_in_kernel(frame_size)
-#ifdef AMCX_EXP_PAIR4096
-        && frame_size != amcx::pair::kN
+    // every throughput kernel (N = 128 ... 4096 one wave per frame, N = 8192 the quad) has re-run the frames outside its
+    // fp32 sums' range itself -- one launch, rows final -- and finished frames with a phase step within an angle rounding
+    // of +-pi in its finaliser.
+#ifdef AMCX_EXP_PAIR4096      // the pair experiment marks such frames in band (f5 = -inf) for the block kernel's fp64-sum routine
+    if (frame_size == amcx::pair::kN) {
+      e = amcx::launch_range_fixup(iq, n_frames, frame_size, row_stride_elems, out_dev, out_row_stride, stream, cu_count());
+      if (e != hipSuccess) return hip_fail(e, "range fix-up launch");
+    }
 #endif
-        )
-      return AMCX_OK;
-    e = amcx::launch_range_fixup(iq, n_frames, frame_size, row_stride_elems, out_dev, out_row_stride, stream, cu_count());
-    if (e != hipSuccess) return hip_fail(e, "range fix-up launch");
     return AMCX_OK;
   }
   return launch_block(iq, n_frames, frame_size, row_stride_elems, out_dev, out_row_stride, stream);

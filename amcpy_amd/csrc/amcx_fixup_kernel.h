@@ -1,5 +1,7 @@
-// The launch behind the quad kernel (N = 8192), which does not re-run out-of-range frames itself (the wave kernels,
-// N = 128 ... 4096, do: amcx_wave_kernel.h).
+// EXPERIMENT SUPPORT ONLY (compiled with -DAMCX_EXP_PAIR4096): the launch behind the pair kernel, which does not re-run
+// out-of-range frames itself.  Every product kernel does -- the wave kernels behind each batch (amcx_wave_kernel.h), the
+// N = 8192 quad kernel in a pass at the end of its launch (amcx_quad_kernel.h) -- so the product library has no second
+// launch and does not contain this kernel.
 // The throughput kernel does its per-sample arithmetic and its sums in fp32; its finaliser marks, in
 // band, the frames it cannot finish -- feature 5 (a standard deviation: >= 0 or NaN) is stored
 //   -infinity : the frame is outside the range in which fp32 sixth-order sums are trustworthy (mean

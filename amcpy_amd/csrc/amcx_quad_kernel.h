@@ -51,7 +51,9 @@ constexpr int kStashFloats = kBatch * kWavesPerQuad * kStashRow;       // one bu
 constexpr int kOffFrames = kTabBytes;
 constexpr int kOffStash = kOffFrames + kFrameBytes;
 constexpr int kOffMu = kOffStash + 2 * kStashFloats * 4;
-constexpr int kLdsBytes = kOffMu + kWavesPerQuad * 4;
+constexpr int kOffMx = kOffMu + kWavesPerQuad * 4;          // [wave] largest |component| of its quarter (re-run of an out-of-range frame)
+constexpr int kOffFlag = kOffMx + kWavesPerQuad * 4;         // != 0: this workgroup has marked a frame for its re-run pass
+constexpr int kLdsBytes = kOffFlag + 4;
 static_assert(kWGsPerCU * kLdsBytes <= 163840, "two workgroups per CU");
 static_assert(kExchangeBytes <= kRegionBytes && kRoundRows * 1024 <= kRegionBytes, "a wave's region holds a round's rows and its FFT exchange buffer");
 
@@ -197,6 +199,9 @@ __global__ __launch_bounds__(kThreads, 2) void amcx_features18_quad_kernel(
   char* fb = smem + kOffFrames;                             // exchange area / FFT scratch, one region per wave
   float* stash_q = reinterpret_cast<float*>(smem + kOffStash);
   float* mu_part = reinterpret_cast<float*>(smem + kOffMu);
+  float* mx_part = reinterpret_cast<float*>(smem + kOffMx);
+  unsigned* const redo_flag = reinterpret_cast<unsigned*>(smem + kOffFlag);
+  if (tid == 0) *redo_flag = 0;
 
   // ---- tables of the 2048-point register FFT ----
   constexpr int R = C2::kFftRows;                           // 16
@@ -232,9 +237,12 @@ __global__ __launch_bounds__(kThreads, 2) void amcx_features18_quad_kernel(
   // the wave with quarter 0: the batch whose stash rows are complete once the next barrier has been passed
   long long pend_f0 = 0;
   int pend_n = 0, pend_buf = 0;
-  auto finalise = [&](long long f_first, int count, const float* stash) {
+  // range_tag true: ONE frame, re-run on a copy multiplied by 2^-ex (the re-run pass at the end of the kernel); its
+  // features follow from the scaled sums through the scaling laws (finalize_features<true>)
+  auto finalise = [&](auto range_tag, long long f_first, int count, const float* stash, int ex) {
+    constexpr bool RG = decltype(range_tag)::value;
     float feat[18];
-    bool tie = false;
+    bool tie = false, marked = false;
     float kw0 = 0.f;
     if (lane < count) {
       const float* rows = stash + lane * kWavesPerQuad * kStashRow;
@@ -266,17 +274,28 @@ __global__ __launch_bounds__(kThreads, 2) void amcx_features18_quad_kernel(
       F.swd1 = ws.s1; F.swd2 = ws.s2; F.swd3 = ws.s3; F.swd4 = ws.s4;
       F.gmax_raw = pk;
       F.pi_tie = flagged;
-      finalize_features(F, kN, feat);
-      if (is_outside_fp32_range(F, kN)) feat[4] = -__builtin_inff();       // redone by amcx_range_fixup_kernel
+      if constexpr (RG) {
+        finalize_features<true>(F, kN, feat, ex);
+      } else {
+        finalize_features(F, kN, feat);
+        // outside the fp32 sums' range: marked here (f5 = -inf: a standard deviation is >= 0 or NaN) in the workgroup's
+        // OWN row, found again and re-run by the whole quad in the pass at the end of this kernel -- the row is final
+        // when the launch is
+        if (is_outside_fp32_range(F, kN)) { feat[4] = -__builtin_inff(); marked = true; }
+      }
       tie = __builtin_signbitf(feat[4]) && feat[4] == feat[4] && feat[4] != -__builtin_inff();
     }
+    if constexpr (!RG) {
+      if (__builtin_amdgcn_ballot_w64(marked) != 0 && lane == 0) *redo_flag = 1;
+    }
     unsigned long long ties = __builtin_amdgcn_ballot_w64(tie);
+    const float sct = RG ? __builtin_bit_cast(float, (127 - ex) << 23) : 1.0f;   // the 2^-ex the frame was multiplied by
     while (ties != 0) {                                     // phase steps within an fp32 ulp of +-pi: exact f5 / f9
       const int idx = __builtin_ctzll(ties);
       ties &= ties - 1;
       const float kwt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, kw0), idx));
       float f5x, f9x;
-      wave_exact_frequency<kN>(iq + (f_first + idx) * row_stride, 1.0f, kwt, lane, f5x, f9x);
+      wave_exact_frequency<kN>(iq + (f_first + idx) * row_stride, sct, kwt, lane, f5x, f9x);
       if (lane == idx) { feat[4] = f5x; feat[8] = f9x; }
     }
     if (lane < count) {
@@ -321,6 +340,76 @@ __global__ __launch_bounds__(kThreads, 2) void amcx_features18_quad_kernel(
   using Row0 = std::integral_constant<int, 0>;
   using Row8 = std::integral_constant<int, kRoundRows>;
 
+  // ---- a frame, phases A and B: statistics sweep of this wave's quarter (xr / xi; nx = the first sample of the next
+  // quarter), envelope about the exact mean, sums -> stash row (g, q), radix-4 stage in two rounds: xr / xi leave as y_q.
+  // Four workgroup barriers, the same in all four waves.
+  auto phases_ab = [&](float (&xr)[2 * kRowsQ], float (&xi)[2 * kRowsQ], const float2 nx, float* stash, int g)
+      __attribute__((always_inline)) {
+    Stats S;
+    // ---- phase A: statistics sweep, rows 0-7 published ----
+    AMCX_QUAD_PRIO(0);
+    static_for<kRowsQ>([&](auto ii) {
+      constexpr int i = decltype(ii)::value;
+      float a0, a1;                                       // |x| is taken again in phase B: no room to park 8 KB per wave
+      S.template row<i == 0, i == kRowsQ - 1>(xr[2 * i], xi[2 * i], xr[2 * i + 1], xi[2 * i + 1], lane, a0, a1);
+    });
+    publish_rows(xr, xi, Row0{});
+    if (q < 3) {
+      const float an = __builtin_amdgcn_sqrtf(__builtin_fmaf(nx.x, nx.x, __builtin_fmaf(nx.y, nx.y, kTinyPower)));
+      const float w = wrapped_step(fast_angle(nx.x, nx.y, an), S.th_b1_prev);
+      if (lane == 63) {                                   // lane 63 holds the quarter's last sample (row<.., LAST> gave it a null step)
+        S.step(w);
+        S.wmax = __builtin_fmaxf(S.wmax, __builtin_fabsf(w));
+      }
+    }
+    {
+      const float sa_w = wave_sum_l63(S.sa);
+      if (lane == 63) mu_part[q] = sa_w;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                                      // (1) rows 0-7 of every quarter and the envelope partial sums are in LDS
+    // ---- phase B: envelope about the exact mean, sums -> stash, radix-4 stage in two rounds ----
+    AMCX_QUAD_PRIO(1);
+    {
+      const float mu = ((mu_part[0] + mu_part[1]) + (mu_part[2] + mu_part[3])) * (1.0f / (float)kN);
+      static_for<2 * kRowsQ>([&](auto ee) {
+        constexpr int e = decltype(ee)::value;
+        S.envelope(__builtin_amdgcn_sqrtf(__builtin_fmaf(xr[e], xr[e], __builtin_fmaf(xi[e], xi[e], kTinyPower))), mu);
+      });
+      float* const row = stash + (g * kWavesPerQuad + q) * kStashRow;
+      float r28[28] = {S.sA, S.sBh, S.sP, S.sAA, S.sX4, S.sAB, S.sAP, S.sBP, S.sAAA, S.sABB,
+                       S.sAAB, S.sBBB, S.sAAP, S.sX4P, S.sABP, S.sa, S.sad1, S.sad2, S.sad4,
+                       S.st1, S.st2, S.sab1, S.sab2, S.sw1, S.sw2, S.sw3, S.sw4, 0.f};
+      const unsigned long long tie = __builtin_amdgcn_ballot_w64(S.wmax > kPi - kTieBand);
+      reduce_store(r28, row, lane);
+      if (lane == 63) {
+        row[kNumSums + 1] = S.Kt;
+        row[kNumSums + 2] = S.Kw;
+        row[kNumSums + 3] = S.Ka;
+        row[kNumSums + 4] = tie != 0 ? 1.0f : 0.0f;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    AMCX_QUAD_PRIO(2);
+    radix4_round(xr, xi, Row0{});
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                                      // (2) round 1 has been read
+    publish_rows(xr, xi, Row8{});
+    __syncthreads();                                      // (3) rows 8-15 of every quarter are in LDS
+    radix4_round(xr, xi, Row8{});
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                                      // (4) round 2 has been read: a wave's region is its FFT scratch now
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // ---- phase C: 2048-point register FFT of y_q, its peak into the stash row ----
+  auto phase_c = [&](float (&xr)[2 * kRowsQ], float (&xi)[2 * kRowsQ], float* stash, int g) __attribute__((always_inline)) {
+    AMCX_QUAD_PRIO(3);
+    const float peak = fft_peak<R>(xr, xi, la);
+    const float pk = wave_max_l63(peak);
+    if (lane == 63) stash[(g * kWavesPerQuad + q) * kStashRow + kNumSums] = pk;
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
   // The next frame's quarter is requested before this frame's FFT and lands behind it.
   v4f nxt[kRowsQ];
   {
@@ -335,9 +424,7 @@ __global__ __launch_bounds__(kThreads, 2) void amcx_features18_quad_kernel(
     float* const stash = stash_q + (it & 1) * kStashFloats;
     for (int g = 0; g < n_here; ++g) {                      // n_here is the same for the quad's four waves: so are the barriers
       float xr[2 * kRowsQ], xi[2 * kRowsQ];
-      Stats S;
-      // ---- phase A: this wave's quarter (requested a frame ago), statistics sweep, rows 0-7 published ----
-      AMCX_QUAD_PRIO(0);
+      // this wave's quarter (requested a frame ago)
       static_for<kRowsQ>([&](auto ii) {
         constexpr int i = decltype(ii)::value;
         xr[2 * i] = nxt[i].x; xi[2 * i] = nxt[i].y; xr[2 * i + 1] = nxt[i].z; xi[2 * i + 1] = nxt[i].w;
@@ -345,58 +432,7 @@ __global__ __launch_bounds__(kThreads, 2) void amcx_features18_quad_kernel(
       // the first sample of the next quarter: the phase step that crosses the quarter boundary
       float2 nx = make_float2(1.f, 0.f);
       if (q < 3) nx = iq[(f0 + g) * row_stride + (q + 1) * kQuarter];
-      static_for<kRowsQ>([&](auto ii) {
-        constexpr int i = decltype(ii)::value;
-        float a0, a1;                                       // |x| is taken again in phase B: no room to park 8 KB per wave
-        S.template row<i == 0, i == kRowsQ - 1>(xr[2 * i], xi[2 * i], xr[2 * i + 1], xi[2 * i + 1], lane, a0, a1);
-      });
-      publish_rows(xr, xi, Row0{});
-      if (q < 3) {
-        const float an = __builtin_amdgcn_sqrtf(__builtin_fmaf(nx.x, nx.x, __builtin_fmaf(nx.y, nx.y, kTinyPower)));
-        const float w = wrapped_step(fast_angle(nx.x, nx.y, an), S.th_b1_prev);
-        if (lane == 63) {                                   // lane 63 holds the quarter's last sample (row<.., LAST> gave it a null step)
-          S.step(w);
-          S.wmax = __builtin_fmaxf(S.wmax, __builtin_fabsf(w));
-        }
-      }
-      {
-        const float sa_w = wave_sum_l63(S.sa);
-        if (lane == 63) mu_part[q] = sa_w;
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();                                      // (1) rows 0-7 of every quarter and the envelope partial sums are in LDS
-      // ---- phase B: envelope about the exact mean, sums -> stash, radix-4 stage in two rounds ----
-      AMCX_QUAD_PRIO(1);
-      {
-        const float mu = ((mu_part[0] + mu_part[1]) + (mu_part[2] + mu_part[3])) * (1.0f / (float)kN);
-        static_for<2 * kRowsQ>([&](auto ee) {
-          constexpr int e = decltype(ee)::value;
-          S.envelope(__builtin_amdgcn_sqrtf(__builtin_fmaf(xr[e], xr[e], __builtin_fmaf(xi[e], xi[e], kTinyPower))), mu);
-        });
-        float* const row = stash + (g * kWavesPerQuad + q) * kStashRow;
-        float r28[28] = {S.sA, S.sBh, S.sP, S.sAA, S.sX4, S.sAB, S.sAP, S.sBP, S.sAAA, S.sABB,
-                         S.sAAB, S.sBBB, S.sAAP, S.sX4P, S.sABP, S.sa, S.sad1, S.sad2, S.sad4,
-                         S.st1, S.st2, S.sab1, S.sab2, S.sw1, S.sw2, S.sw3, S.sw4, 0.f};
-        const unsigned long long tie = __builtin_amdgcn_ballot_w64(S.wmax > kPi - kTieBand);
-        reduce_store(r28, row, lane);
-        if (lane == 63) {
-          row[kNumSums + 1] = S.Kt;
-          row[kNumSums + 2] = S.Kw;
-          row[kNumSums + 3] = S.Ka;
-          row[kNumSums + 4] = tie != 0 ? 1.0f : 0.0f;
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      AMCX_QUAD_PRIO(2);
-      radix4_round(xr, xi, Row0{});
-      __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();                                      // (2) round 1 has been read
-      publish_rows(xr, xi, Row8{});
-      __syncthreads();                                      // (3) rows 8-15 of every quarter are in LDS
-      radix4_round(xr, xi, Row8{});
-      __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();                                      // (4) round 2 has been read: a wave's region is its FFT scratch now
-      __builtin_amdgcn_sched_barrier(0);
+      phases_ab(xr, xi, nx, stash, g);
       // The next frame's quarter is requested here, before the FFT, and lands behind it -- except when this wave has a
       // batch to finalise: the fp64 algebra wants ~200 registers, so it runs after the FFT, when y_q is dead, and the
       // request follows it (one exposed round trip per batch, on one wave; the CU's other workgroup covers it).
@@ -405,16 +441,9 @@ __global__ __launch_bounds__(kThreads, 2) void amcx_features18_quad_kernel(
       const bool more = g + 1 < n_here ? frame_at(it, g + 1, f_next) : frame_at(it + 1, 0, f_next);
       if (more && !finalise_now) load_quarter(nxt, f_next);
       __builtin_amdgcn_sched_barrier(0);
-      // ---- phase C: 2048-point register FFT of y_q, its peak into the stash row ----
-      AMCX_QUAD_PRIO(3);
-      {
-        const float peak = fft_peak<R>(xr, xi, la);
-        const float pk = wave_max_l63(peak);
-        if (lane == 63) stash[(g * kWavesPerQuad + q) * kStashRow + kNumSums] = pk;
-      }
-      __builtin_amdgcn_sched_barrier(0);
+      phase_c(xr, xi, stash, g);
       if (finalise_now) {                                   // the previous batch: every wave is past its last FFT (barrier 1 of this frame)
-        finalise(pend_f0, pend_n, stash_q + pend_buf * kStashFloats);
+        finalise(std::false_type{}, pend_f0, pend_n, stash_q + pend_buf * kStashFloats, 0);
         pend_n = 0;
         __builtin_amdgcn_sched_barrier(0);
         if (more) load_quarter(nxt, f_next);
@@ -423,7 +452,73 @@ __global__ __launch_bounds__(kThreads, 2) void amcx_features18_quad_kernel(
     if (q == 0) { pend_f0 = f0; pend_n = n_here; pend_buf = it & 1; }
   }
   __syncthreads();                                          // the last batch's FFT peaks are in the stash
-  if (q == 0 && pend_n > 0) finalise(pend_f0, pend_n, stash_q + pend_buf * kStashFloats);
+  if (q == 0) {
+    if (pend_n > 0) finalise(std::false_type{}, pend_f0, pend_n, stash_q + pend_buf * kStashFloats, 0);
+    __threadfence();                                        // this wave's rows (and marks) are visible to the quad's other waves
+  }
+  __syncthreads();
+
+  // ---- re-run pass: frames outside the fp32 sums' range (never on ordinary data: one LDS word says so) ----
+  // The finaliser marked them in the workgroup's own rows (f5 = -inf).  All four waves scan those rows -- the same
+  // memory, so the same list in every wave, and the barriers stay common -- and run each marked frame again, multiplied
+  // by 2^-ex first (ex the even-rounded exponent of the frame's largest component: every component below 4, no
+  // sixth-order product can overflow); the scaled finaliser undoes it through the features' scaling laws
+  // (finalize_features<true>), as the wave kernels do (amcx_wave_kernel.h, rerun_scaled).  A launch leaves every row
+  // final; rounds 2-3 left the marks to a second launch of the block kernel's fp64 routine (amcx_range_fixup_kernel).
+  if (__builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile unsigned*>(redo_flag)) != 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const long long fa = b0 * kBatch;
+    long long fz = b1 * kBatch;
+    if (fz > n_frames) fz = n_frames;
+    float* const stash = stash_q;
+    for (long long base = fa; base < fz; base += 64) {
+      unsigned bits = 0;
+      if (base + lane < fz)
+        bits = __hip_atomic_load(reinterpret_cast<const unsigned*>(out + (base + lane) * out_stride + 4), __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+      unsigned long long todo = __builtin_amdgcn_ballot_w64(bits == 0xff800000u);      // -inf
+      while (todo != 0) {
+        const int idx = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const long long f = base + idx;
+        float xr[2 * kRowsQ], xi[2 * kRowsQ];
+        {
+          v4f v[kRowsQ];
+          load_quarter(v, f);
+          static_for<kRowsQ>([&](auto ii) {
+            constexpr int i = decltype(ii)::value;
+            xr[2 * i] = v[i].x; xi[2 * i] = v[i].y; xr[2 * i + 1] = v[i].z; xi[2 * i + 1] = v[i].w;
+          });
+        }
+        float2 nx = make_float2(1.f, 0.f);
+        if (q < 3) nx = iq[f * row_stride + (q + 1) * kQuarter];
+        float m = 0.f;                                      // largest |component| of the FRAME: NaNs drop out of the maximum
+        static_for<2 * kRowsQ>([&](auto ee) {
+          constexpr int e = decltype(ee)::value;
+          m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(xr[e])), __builtin_fabsf(xi[e]));
+        });
+        m = wave_max_l63(m);
+        if (lane == 63) mx_part[q] = m;
+        __syncthreads();
+        m = __builtin_fmaxf(__builtin_fmaxf(mx_part[0], mx_part[1]), __builtin_fmaxf(mx_part[2], mx_part[3]));
+        int ex = 0;                                         // an infinite component keeps 0: the sums go NaN
+        if (m >= 0x1p-125f && m <= 3.4028235e38f) ex = (((__builtin_bit_cast(int, m) >> 23) & 0xff) - 127) & ~1;
+        ex = __builtin_amdgcn_readfirstlane(ex);
+        const float sc = __builtin_bit_cast(float, (127 - ex) << 23);       // 2^-ex, exact
+        static_for<2 * kRowsQ>([&](auto ee) {
+          constexpr int e = decltype(ee)::value;
+          xr[e] *= sc; xi[e] *= sc;
+        });
+        nx.x *= sc; nx.y *= sc;
+        phases_ab(xr, xi, nx, stash, 0);
+        phase_c(xr, xi, stash, 0);
+        __syncthreads();                                    // the four peaks are in the stash
+        if (q == 0) finalise(std::true_type{}, f, 1, stash, ex);
+        // (the next marked frame's stash rows are written behind ITS barrier (1), which the wave with quarter 0 joins
+        //  only after the finaliser above; mx_part is not read by it)
+      }
+    }
+  }
 }
 
 inline hipError_t launch_quad(const float2* iq, int64_t n_frames, int64_t row_stride, float* out,

@@ -1061,7 +1061,7 @@ __device__ __forceinline__ void wave_body(
     const float2* __restrict__ iq, long long n_frames, long long row_stride,
     float* __restrict__ out, long long out_stride AMCX_STAMP_ARG) {
   using C = Cfg<N>;
-  constexpr bool kRedoHere = true;                       // every wave-kernel size (the quad kernel, N = 8192, still marks in band)
+  constexpr bool kRedoHere = true;                       // every wave-kernel size (the quad kernel, N = 8192, has its own re-run pass)
   constexpr int R = C::kFftRows, ROWS = C::kHeldRows;
   constexpr int kWavesPerWG = C::kWavesPerWG, kThreads = C::kThreads, kTailFrames = C::kTailFrames;
   constexpr int kFramesPerWave = C::kFramesPerWave, kTailChunk = C::kTailChunk;
@@ -1632,10 +1632,6 @@ inline const char* wave_kernel_name(int frame_size) {
 }
 
 #ifndef AMCX_WAVE_STAMPS
-// sizes whose kernel re-runs out-of-range frames itself (wave_body): every wave-kernel size; the quad kernel (N = 8192)
-// marks them in band (f5 = -inf) for amcx_range_fixup_kernel
-inline bool wave_redoes_in_kernel(int frame_size) { return frame_size <= 4096; }
-
 template <int N>
 inline hipError_t launch_wave_n(const float2* iq, int64_t n_frames, int64_t row_stride, float* out,
                                 int64_t out_stride, hipStream_t stream, int cus) {

@@ -30,20 +30,16 @@
  *     for zeros).  The block kernel stages each frame times an exact power of two and
  *     un-scales in fp64.  The throughput kernel's fp32 sums hold inside 1e-5 <~ rms|x| <~ 1e5;
  *     a frame outside that (or any of whose sums overflows: a single 1e7 sample among unit
- *     ones) is re-run on a copy multiplied by an exact power of two -- at the power-of-two frame
- *     sizes 128 ... 4096 by the throughput kernel itself, right behind the batch it was found in (a
- *     data set that is out of range throughout, e.g. raw 24-bit ADC counts, runs at half the normal
- *     rate), at 8192 by the block kernel's routine in a second launch (~1/10 of the rate) -- so
+ *     ones) is re-run on a copy multiplied by an exact power of two by the throughput kernel itself
+ *     -- at the frame sizes 128 ... 4096 right behind the batch it was found in, at 8192 in a pass of
+ *     the quad at the end of the launch (a data set that is out of range throughout, e.g. raw 24-bit
+ *     ADC counts, runs at half the normal rate) -- so
  *     results match the reference, which evaluates in complex128 (features.py:46-58), including
  *     the inf / 0 / denormals its float32 store produces (feature_extraction.py:35,56).
- *   - AMCX_VARIANT_WAVE / AUTO at a power-of-two frame size 128 ... 4096 is ONE launch on the stream and
- *     stores every row once, final (ABI 3 as built in rounds 2-3 took two launches and marked out-of-range
- *     frames in band in between).  At 8192 it is still TWO: the throughput kernel marks the frames whose
- *     amplitude is outside its fp32 range in band -- feature 5 (a standard deviation, >= 0 or NaN) stored
- *     as -inf -- and amcx_range_fixup_kernel behind it redoes them; a consumer on ANOTHER stream that
- *     reads `out_dev` between those two launches sees the marks: order it after the whole call (event /
- *     stream sync), as usual.  (Frames with a phase step within an fp32 ulp of +-pi are finished exactly
- *     inside every throughput kernel.)
+ *   - AMCX_VARIANT_WAVE / AUTO at a power-of-two frame size 128 ... 8192 is ONE launch on the stream; when
+ *     it has completed every row is final (ABI 3 as built in rounds 2-3 took two launches and left out-of-range
+ *     frames marked in band in between, and so did N = 8192 until late in round 4).  Frames with a phase step
+ *     within an fp32 ulp of +-pi are finished exactly inside every throughput kernel.
  *   - PARITY CONTRACT with the reference (the executable form is tests/test_gpu_parity.py): features
  *     1-9 and 11 within 1e-5 relative of the reference's complex128 evaluation stored as float32;
  *     features 10, 12-18 (cumulants whose terms cancel) within 1e-5 of max(|value|, S), S the sum of

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Worst case for the range path: a whole data set scaled like raw 24-bit ADC counts (x 1e7), so
 every frame is outside the throughput kernel's fp32 range, is flagged (f5 = -inf) and goes through
-the wave kernel's own re-run (the same machine on a power-of-two pre-scaled copy, inside the launch; frame
-sizes without one: amcx_range_fixup_kernel, fp64 sums).  Prints the rate of that path, of the same
+the throughput kernel's own re-run (the same machine on a power-of-two pre-scaled copy, inside the launch: behind
+each batch in the wave kernels, in a pass at the end of the launch in the N = 8192 quad kernel).  Prints the rate of that path, of the same
 data pre-scaled by hand into range, and checks both against each other through the features'
 scaling laws."""
 import sys
@@ -15,7 +15,8 @@ import torch  # noqa: E402
 from amcpy_amd import synth  # noqa: E402
 from amcpy_amd.features import features18  # noqa: E402
 
-n_snr, n_frames, N = 26, 512, 2048
+n_snr, n_frames = 26, 512
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048        # python tests/manual/worst_case_range.py [frame size]
 arena = torch.empty((6, n_snr, n_frames, N), dtype=torch.complex64, device="cuda")
 for mi, mod in enumerate(synth.MODS6):
     synth.device_frames(mod, n_snr, n_frames, N, device="cuda", rank=0, mod_idx=mi, out=arena[mi])

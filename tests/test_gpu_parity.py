@@ -1016,7 +1016,7 @@ def test_iq_pair_dataset_through_the_engine():
     _assert_parity(want, orc.features18_batch(x), x, "RadioML-shaped (I, Q) pairs, N = 1024")
 
 
-@pytest.mark.parametrize("N", [128, 256, 512, 1024, 2048, 4096])
+@pytest.mark.parametrize("N", [128, 256, 512, 1024, 2048, 4096, 8192])
 def test_range_pass_mixed_batches_and_scaling_laws(N):
     """The wave kernel's re-run of out-of-range frames (inside the kernel, on a power-of-two pre-scaled copy):
     in a batch where some frames are in range and others are scaled by 2^30 or 2^-40 (out of range both
@@ -1047,7 +1047,7 @@ def test_range_pass_mixed_batches_and_scaling_laws(N):
     assert np.all(got[kinds == 0] == ref[pick][kinds == 0].astype(np.float32))
 
 
-@pytest.mark.parametrize("N", [512, 1024, 2048])
+@pytest.mark.parametrize("N", [512, 1024, 2048, 8192])
 def test_out_of_range_frames_scattered_over_a_full_grid(N):
     """The in-kernel re-run under a FULL grid: 40 000 frames (every workgroup's slice has a body, a tail and batches
     with none, one or several out-of-range frames), 1 % of them scaled by 2^28 or 2^-36 -- half of those noiseless
@@ -1064,7 +1064,7 @@ def test_out_of_range_frames_scattered_over_a_full_grid(N):
     ties[2, ::3] *= -1
     ties[3] *= (1 + 0j)
     base = np.concatenate([base, ties]).astype(np.complex64)                                                    # 28 originals
-    F = 40000
+    F = 40000 if N < 8192 else 12000          # N = 8192: 512 quads take batches of four; 786 MB of frames
     pick = rng.integers(0, 24, size=F)
     kinds = np.zeros(F, dtype=np.int64)
     out_of_range = rng.choice(F, size=F // 100, replace=False)
