@@ -80,7 +80,9 @@
 // Different levels per section (AMCX_PRIO_LEVELS): reduction above envelope above sweep +0.2 ... +0.5 % (noise level), the
 // sweep above the others -2.7 %.
 // Which sections of a frame run at s_setprio 1: bit 0 statistics sweep, 1 envelope sweep, 2 wave reduction, 3 FFT pass 1,
-// 4 FFT passes 2-3, 5 the batch finaliser.
+// 4 FFT passes 2-3, 5 the batch finaliser; N = 4096 only: 6 the radix-2 split stage in front of the two FFTs, 7 pass 1 of
+// the second FFT (passes 2-3 of either drop to bit 4's level in fft_peak) -- measured: -2.6 % with the split stage at priority 1,
+// -4.4 ... -4.6 % with a pass 1 as well (profiles/r4_wave_priority_ab.txt, section 10): 7 is the product at every size.
 #ifndef AMCX_PRIO_MASK
 #define AMCX_PRIO_MASK 7
 #endif
@@ -1374,6 +1376,7 @@ __device__ __forceinline__ void wave_body(
         auto fft4096 = [&](auto&& row_of) -> float {
           const float4 w4 = *reinterpret_cast<const float4*>(t4 + lane * 16);
           float sr[2 * R], si[2 * R], dr[2 * R], di[2 * R];
+          if constexpr (AMCX_PRIO_OF(6) != AMCX_PRIO_OF(3)) __builtin_amdgcn_s_setprio(AMCX_PRIO_OF(6));
           static_for<R>([&](auto ii) {
             constexpr int i = decltype(ii)::value;
             constexpr int lo = 2 * i;
@@ -1390,8 +1393,13 @@ __device__ __forceinline__ void wave_body(
             dr[lo + 1] = __builtin_fmaf(d1r, w4.z, -(d1i * w4.w));
             di[lo + 1] = __builtin_fmaf(d1r, w4.w, d1i * w4.z);
           });
+          if constexpr (AMCX_PRIO_OF(6) != AMCX_PRIO_OF(3)) {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(AMCX_PRIO_OF(3));
+          }
           float pk4 = fft_peak<R>(sr, si, la);
           __builtin_amdgcn_sched_barrier(0);
+          if constexpr (AMCX_PRIO_OF(7) != AMCX_PRIO_OF(4)) __builtin_amdgcn_s_setprio(AMCX_PRIO_OF(7));   // pass 1 of the second FFT
           return __builtin_fmaxf(pk4, fft_peak<R>(dr, di, la));
         };
         peak = fft4096([&](auto ic) {
