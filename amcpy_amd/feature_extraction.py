@@ -602,17 +602,29 @@ def extract_iq_pairs(dataset, frame_size: Optional[int] = None, *, first_frame: 
 
 
 def extract_radioml_hdf5(path, *, key: str = "X", frame_size: Optional[int] = None, first_frame: int = 0,
-                         max_frames: Optional[int] = None, device: Optional[int] = None) -> np.ndarray:
+                         max_frames: Optional[int] = None, device: Optional[int] = None, compute=None,
+                         chunk_frames: Optional[int] = None) -> np.ndarray:
     """``extract_iq_pairs`` on dataset ``key`` of a RadioML-style HDF5 file (``GOLD_XYZ_OSC.0001_1024.hdf5``:
-    ``X`` float32 (2 555 904, 1024, 2), reference old/dataset.py:43-56).  Needs ``h5py``, which the reference
-    lists for its legacy scripts; raises ImportError with that hint where it is not installed."""
+    ``X`` float32 (2 555 904, 1024, 2), reference old/dataset.py:43-56).  The file is opened with ``h5py``, which the
+    reference lists for its legacy scripts, where that is importable; otherwise with the HDF5 C library itself through
+    ``amcpy_amd.hdf5_min`` (ctypes; this image ships libhdf5 1.10.6 but no h5py for its interpreter).  Either way the
+    library decodes the chunks -- contiguous, chunked and deflate-compressed files read alike -- ``chunk_frames`` rows at a
+    time on a reader thread ahead of the upload.  Neither there: ImportError that says so."""
     try:
         import h5py
-    except ImportError as exc:                    # not a silent fallback: say what is missing
-        raise ImportError("extract_radioml_hdf5 needs h5py (pip install h5py); any sliceable (F, L, 2) float32 "
-                          "dataset can be passed to extract_iq_pairs instead") from exc
-    with h5py.File(str(path), "r") as fh:
-        return extract_iq_pairs(fh[key], frame_size, first_frame=first_frame, max_frames=max_frames, device=device)
+    except ImportError:
+        h5py = None
+    if h5py is not None:
+        with h5py.File(str(path), "r") as fh:
+            return extract_iq_pairs(fh[key], frame_size, first_frame=first_frame, max_frames=max_frames, device=device,
+                                    compute=compute, chunk_frames=chunk_frames)
+    from . import hdf5_min
+    if not hdf5_min.available():                  # not a silent fallback: say what is missing
+        raise ImportError("extract_radioml_hdf5 needs h5py (pip install h5py) or an HDF5 C library >= 1.10 (AMCX_LIBHDF5=/path/to/"
+                          "libhdf5.so); any sliceable (F, L, 2) float32 dataset can be passed to extract_iq_pairs instead")
+    with hdf5_min.File(path) as fh:
+        return extract_iq_pairs(fh[key], frame_size, first_frame=first_frame, max_frames=max_frames, device=device,
+                                compute=compute, chunk_frames=chunk_frames)
 
 
 # ----------------------------------------------------------------------------

@@ -1,0 +1,306 @@
+"""The few calls of the HDF5 C library this path needs, through ctypes: open a file read-only, open a
+dataset, ask for its shape and element type, read a range of rows.  For RadioML-style containers
+(``GOLD_XYZ_OSC.0001_1024.hdf5``: ``X`` float32 (2 555 904, 1024, 2); reference old/dataset.py:43-56,
+old/dataset_analysis.py:17-22) where ``h5py`` -- which the reference's legacy scripts import -- is not installed but the
+C library is (this image: /opt/conda/lib/libhdf5.so.103, HDF5 1.10.6).  libhdf5 does the decoding, so contiguous,
+chunked and deflate-compressed datasets all read the same way.
+
+    with hdf5_min.File(path) as fh:
+        x = fh["X"]                  # .shape, .dtype, x[a:b] -> numpy array of rows a .. b-1
+        feats = extract_iq_pairs(x)
+
+Not a general binding: simple (non-compound) integer and IEEE float element types, whole rows along axis 0.
+`create_dataset` exists for the tests, which need a genuine HDF5 file to read back.
+
+The library is found through AMCX_LIBHDF5 (a path), ctypes.util.find_library("hdf5"), then the usual install
+locations; `available()` says whether one loaded.  Builds of libhdf5 are usually NOT thread-safe: every call into it
+is made under one process-wide lock (ctypes drops the GIL around foreign calls, and `extract_iq_pairs` slices a
+dataset from reader threads)."""
+from __future__ import annotations
+
+import ctypes
+import ctypes.util
+import glob
+import os
+import threading
+from typing import Optional, Tuple
+
+import numpy as np
+
+_LOCK = threading.RLock()
+_LIB = None
+_LIB_PATH: Optional[str] = None
+_TRIED = False
+
+hid_t = ctypes.c_int64          # HDF5 >= 1.10
+hsize_t = ctypes.c_uint64
+herr_t = ctypes.c_int
+
+H5F_ACC_RDONLY, H5F_ACC_TRUNC = 0, 2
+H5P_DEFAULT, H5S_ALL = 0, 0
+H5S_SELECT_SET = 0
+H5T_INTEGER, H5T_FLOAT = 0, 1
+H5T_SGN_NONE = 0
+H5T_ORDER_LE, H5T_ORDER_BE = 0, 1
+
+
+def _candidates():
+    env = os.environ.get("AMCX_LIBHDF5")
+    if env:
+        yield env
+    found = ctypes.util.find_library("hdf5") or ctypes.util.find_library("hdf5_serial")
+    if found:
+        yield found
+    for pat in ("/usr/lib/x86_64-linux-gnu/libhdf5_serial.so*", "/usr/lib/x86_64-linux-gnu/hdf5/serial/libhdf5.so*",
+                "/usr/lib64/libhdf5.so*", "/usr/local/lib/libhdf5.so*", "/opt/conda/lib/libhdf5.so*"):
+        for p in sorted(glob.glob(pat)):
+            yield p
+
+
+def _load():
+    global _LIB, _LIB_PATH, _TRIED
+    with _LOCK:
+        if _TRIED:
+            return _LIB
+        _TRIED = True
+        for cand in _candidates():
+            try:
+                lib = ctypes.CDLL(cand)
+                major, minor, rel = ctypes.c_uint(), ctypes.c_uint(), ctypes.c_uint()
+                lib.H5get_libversion.restype = herr_t
+                if lib.H5get_libversion(ctypes.byref(major), ctypes.byref(minor), ctypes.byref(rel)) < 0:
+                    continue
+                if (major.value, minor.value) < (1, 10):        # hid_t was 32 bits before 1.10
+                    continue
+                _declare(lib)
+                if lib.H5open() < 0:
+                    continue
+                # the library prints an error stack to stderr by default; failures are raised here instead
+                lib.H5Eset_auto2(hid_t(0), None, None)
+                _LIB, _LIB_PATH = lib, cand
+                break
+            except (OSError, AttributeError):
+                continue
+        return _LIB
+
+
+def _declare(lib):
+    P = ctypes.POINTER
+    sigs = {
+        "H5open": (herr_t, []),
+        "H5Eset_auto2": (herr_t, [hid_t, ctypes.c_void_p, ctypes.c_void_p]),
+        "H5Fopen": (hid_t, [ctypes.c_char_p, ctypes.c_uint, hid_t]),
+        "H5Fcreate": (hid_t, [ctypes.c_char_p, ctypes.c_uint, hid_t, hid_t]),
+        "H5Fclose": (herr_t, [hid_t]),
+        "H5Lexists": (ctypes.c_int, [hid_t, ctypes.c_char_p, hid_t]),
+        "H5Dopen2": (hid_t, [hid_t, ctypes.c_char_p, hid_t]),
+        "H5Dcreate2": (hid_t, [hid_t, ctypes.c_char_p, hid_t, hid_t, hid_t, hid_t, hid_t]),
+        "H5Dclose": (herr_t, [hid_t]),
+        "H5Dget_space": (hid_t, [hid_t]),
+        "H5Dget_type": (hid_t, [hid_t]),
+        "H5Dread": (herr_t, [hid_t, hid_t, hid_t, hid_t, hid_t, ctypes.c_void_p]),
+        "H5Dwrite": (herr_t, [hid_t, hid_t, hid_t, hid_t, hid_t, ctypes.c_void_p]),
+        "H5Sclose": (herr_t, [hid_t]),
+        "H5Screate_simple": (hid_t, [ctypes.c_int, P(hsize_t), P(hsize_t)]),
+        "H5Sget_simple_extent_ndims": (ctypes.c_int, [hid_t]),
+        "H5Sget_simple_extent_dims": (ctypes.c_int, [hid_t, P(hsize_t), P(hsize_t)]),
+        "H5Sselect_hyperslab": (herr_t, [hid_t, ctypes.c_int, P(hsize_t), P(hsize_t), P(hsize_t), P(hsize_t)]),
+        "H5Tclose": (herr_t, [hid_t]),
+        "H5Tget_class": (ctypes.c_int, [hid_t]),
+        "H5Tget_size": (ctypes.c_size_t, [hid_t]),
+        "H5Tget_sign": (ctypes.c_int, [hid_t]),
+        "H5Tget_order": (ctypes.c_int, [hid_t]),
+        "H5Pcreate": (hid_t, [hid_t]),
+        "H5Pclose": (herr_t, [hid_t]),
+        "H5Pset_chunk": (herr_t, [hid_t, ctypes.c_int, P(hsize_t)]),
+        "H5Pset_deflate": (herr_t, [hid_t, ctypes.c_uint]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+
+
+def available() -> bool:
+    """True when an HDF5 C library (>= 1.10) could be loaded."""
+    return _load() is not None
+
+
+def library_path() -> Optional[str]:
+    _load()
+    return _LIB_PATH
+
+
+def _lib():
+    lib = _load()
+    if lib is None:
+        raise ImportError("no HDF5 C library (libhdf5 >= 1.10) found: set AMCX_LIBHDF5 to its path, or install h5py")
+    return lib
+
+
+def _native_type(lib, dtype: np.dtype) -> int:
+    """The library's predefined native type for a numpy dtype (the H5T_NATIVE_* macros are global variables)."""
+    names = {"f4": "H5T_NATIVE_FLOAT_g", "f8": "H5T_NATIVE_DOUBLE_g", "i1": "H5T_NATIVE_SCHAR_g", "u1": "H5T_NATIVE_UCHAR_g",
+             "i2": "H5T_NATIVE_SHORT_g", "u2": "H5T_NATIVE_USHORT_g", "i4": "H5T_NATIVE_INT_g", "u4": "H5T_NATIVE_UINT_g",
+             "i8": "H5T_NATIVE_LLONG_g", "u8": "H5T_NATIVE_ULLONG_g"}
+    key = np.dtype(dtype).newbyteorder("=").str[1:]
+    if key not in names:
+        raise TypeError(f"element type {dtype} is not handled by hdf5_min")
+    return hid_t.in_dll(lib, names[key]).value
+
+
+def _dims(seq) -> "ctypes.Array":
+    return (hsize_t * len(seq))(*[int(v) for v in seq])
+
+
+class Dataset:
+    """A dataset of a simple element type: ``shape``, ``dtype`` and row slices ``ds[a:b]`` (axis 0, step 1), each read
+    with one H5Dread of a hyperslab into a fresh C-ordered numpy array."""
+
+    def __init__(self, file: "File", name: str):
+        lib = _lib()
+        self._file, self.name = file, name
+        with _LOCK:
+            self._id = lib.H5Dopen2(file._id, name.encode(), H5P_DEFAULT)
+            if self._id < 0:
+                raise KeyError(f"{file.path}: no dataset {name!r}")
+            space = lib.H5Dget_space(self._id)
+            try:
+                rank = lib.H5Sget_simple_extent_ndims(space)
+                if rank < 1:
+                    raise ValueError(f"{name!r} is not a simple array (rank {rank})")
+                dims = (hsize_t * rank)()
+                lib.H5Sget_simple_extent_dims(space, dims, None)
+                self.shape: Tuple[int, ...] = tuple(int(d) for d in dims)
+            finally:
+                lib.H5Sclose(space)
+            tid = lib.H5Dget_type(self._id)
+            try:
+                cls, size = lib.H5Tget_class(tid), int(lib.H5Tget_size(tid))
+                if cls == H5T_FLOAT and size in (4, 8):
+                    self.dtype = np.dtype(f"f{size}")
+                elif cls == H5T_INTEGER and size in (1, 2, 4, 8):
+                    self.dtype = np.dtype(("u" if lib.H5Tget_sign(tid) == H5T_SGN_NONE else "i") + str(size))
+                else:
+                    raise TypeError(f"{name!r}: element class {cls} of {size} bytes is not handled by hdf5_min")
+            finally:
+                lib.H5Tclose(tid)
+
+    def __len__(self) -> int:
+        return self.shape[0]
+
+    @property
+    def ndim(self) -> int:
+        return len(self.shape)
+
+    def __getitem__(self, key) -> np.ndarray:
+        if key is Ellipsis:
+            key = slice(None)
+        if isinstance(key, (int, np.integer)):
+            return self[int(key):int(key) + 1][0] if -self.shape[0] <= key < self.shape[0] else self._index_error(key)
+        if not isinstance(key, slice):
+            raise TypeError("hdf5_min.Dataset reads row ranges: ds[a:b]")
+        lo, hi, step = key.indices(self.shape[0])
+        if step != 1:
+            raise ValueError("hdf5_min.Dataset reads contiguous row ranges (step 1)")
+        count = max(0, hi - lo)
+        out = np.empty((count,) + self.shape[1:], dtype=self.dtype)
+        if out.size == 0:
+            return out
+        lib = _lib()
+        with _LOCK:
+            if self._id < 0:
+                raise ValueError("dataset of a closed file")
+            fspace = lib.H5Dget_space(self._id)
+            mspace = lib.H5Screate_simple(len(out.shape), _dims(out.shape), None)
+            try:
+                start = _dims((lo,) + (0,) * (len(self.shape) - 1))
+                if lib.H5Sselect_hyperslab(fspace, H5S_SELECT_SET, start, None, _dims(out.shape), None) < 0:
+                    raise OSError(f"{self.name!r}: selecting rows {lo}:{hi} failed")
+                if lib.H5Dread(self._id, _native_type(lib, self.dtype), mspace, fspace, H5P_DEFAULT,
+                               out.ctypes.data_as(ctypes.c_void_p)) < 0:
+                    raise OSError(f"{self._file.path}: reading rows {lo}:{hi} of {self.name!r} failed "
+                                  "(file cut short, or a filter this libhdf5 lacks)")
+            finally:
+                lib.H5Sclose(mspace)
+                lib.H5Sclose(fspace)
+        return out
+
+    def _index_error(self, key):
+        raise IndexError(f"row {key} of a dataset of {self.shape[0]}")
+
+    def _close(self):
+        with _LOCK:
+            if self._id >= 0:
+                _lib().H5Dclose(self._id)
+                self._id = -1
+
+
+class File:
+    """An HDF5 file: read-only by default (``mode="w"`` truncates; the tests write the file they read)."""
+
+    def __init__(self, path, mode: str = "r"):
+        lib = _lib()
+        self.path = str(path)
+        self._sets = []
+        with _LOCK:
+            if mode == "r":
+                if not os.path.exists(self.path):
+                    raise FileNotFoundError(self.path)
+                self._id = lib.H5Fopen(self.path.encode(), H5F_ACC_RDONLY, H5P_DEFAULT)
+            elif mode == "w":
+                self._id = lib.H5Fcreate(self.path.encode(), H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT)
+            else:
+                raise ValueError("mode is 'r' or 'w'")
+            if self._id < 0:
+                raise OSError(f"{self.path}: not an HDF5 file this library can open")
+
+    def __contains__(self, name: str) -> bool:
+        with _LOCK:
+            return _lib().H5Lexists(self._id, name.encode(), H5P_DEFAULT) > 0
+
+    def __getitem__(self, name: str) -> Dataset:
+        if name not in self:
+            raise KeyError(f"{self.path}: no dataset {name!r}")
+        ds = Dataset(self, name)
+        self._sets.append(ds)
+        return ds
+
+    def create_dataset(self, name: str, data: np.ndarray, chunks: Optional[Tuple[int, ...]] = None,
+                       deflate: Optional[int] = None) -> None:
+        """Write ``data`` as dataset ``name`` -- contiguous, or chunked (and deflate-compressed) when ``chunks`` is given."""
+        lib = _lib()
+        data = np.ascontiguousarray(data)
+        with _LOCK:
+            space = lib.H5Screate_simple(data.ndim, _dims(data.shape), None)
+            dcpl = H5P_DEFAULT
+            if chunks is not None:
+                dcpl = lib.H5Pcreate(hid_t.in_dll(lib, "H5P_CLS_DATASET_CREATE_ID_g").value)
+                lib.H5Pset_chunk(dcpl, data.ndim, _dims(chunks))
+                if deflate is not None:
+                    lib.H5Pset_deflate(dcpl, int(deflate))
+            tid = _native_type(lib, data.dtype)
+            dset = lib.H5Dcreate2(self._id, name.encode(), tid, space, H5P_DEFAULT, dcpl, H5P_DEFAULT)
+            try:
+                if dset < 0 or lib.H5Dwrite(dset, tid, H5S_ALL, H5S_ALL, H5P_DEFAULT, data.ctypes.data_as(ctypes.c_void_p)) < 0:
+                    raise OSError(f"{self.path}: writing {name!r} failed")
+            finally:
+                if dset >= 0:
+                    lib.H5Dclose(dset)
+                if dcpl != H5P_DEFAULT:
+                    lib.H5Pclose(dcpl)
+                lib.H5Sclose(space)
+
+    def close(self):
+        with _LOCK:
+            for ds in self._sets:
+                ds._close()
+            self._sets = []
+            if self._id >= 0:
+                _lib().H5Fclose(self._id)
+                self._id = -1
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

@@ -21,6 +21,8 @@ from tests.conftest import load_npz
 
 pytestmark = pytest.mark.gpu
 
+REPO = Path(__file__).resolve().parents[1]
+
 TOL = 1e-5
 VARIANTS_POW2 = ["block", "wave"]
 
@@ -1014,6 +1016,36 @@ def test_iq_pair_dataset_through_the_engine():
     assert np.array_equal(extract_iq_pairs(pairs, first_frame=17, max_frames=100), want[17:117])
     assert np.array_equal(features18_iq_pairs(torch.from_numpy(pairs).cuda()).cpu().numpy(), want)
     _assert_parity(want, orc.features18_batch(x), x, "RadioML-shaped (I, Q) pairs, N = 1024")
+
+
+def test_radioml_hdf5_container_through_the_engine():
+    """A genuine HDF5 container in RadioML 2018.01A's layout, written by the real h5py (tests/golden/radioml_like.h5: X
+    float32 (24, 1024, 2) chunked + shuffled + gzip; reference old/dataset.py:43-56), through extract_radioml_hdf5 -- h5py
+    where it is importable, else libhdf5 itself through amcpy_amd.hdf5_min: bit for bit what the same (I, Q) pairs give as a
+    device tensor, at the full frame length and a shorter one, and within the parity bounds of the oracle."""
+    torch = _torch()
+    import json
+    from amcpy_amd import hdf5_min
+    from amcpy_amd.feature_extraction import extract_radioml_hdf5
+    from amcpy_amd.features import features18_iq_pairs
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        if not hdf5_min.available():
+            pytest.skip("neither h5py nor an HDF5 C library on this machine")
+    path = REPO / "tests" / "golden" / "radioml_like.h5"
+    meta = json.loads((REPO / "tests" / "golden" / "radioml_like.json").read_text())
+    with hdf5_min.File(path) as fh:
+        pairs = fh["X"][:]
+    import hashlib
+    assert hashlib.sha256(pairs.tobytes()).hexdigest() == meta["sha256"]["X"]
+    x = np.ascontiguousarray(pairs[..., 0] + 1j * pairs[..., 1]).astype(np.complex64)
+    got = extract_radioml_hdf5(path, chunk_frames=7)                      # several chunks, the last one ragged
+    assert got.shape == (24, 18) and got.dtype == np.float32
+    assert np.array_equal(got, features18_iq_pairs(torch.from_numpy(pairs).cuda()).cpu().numpy())
+    _assert_parity(got, orc.features18_batch(x), x, "RadioML-shaped HDF5 container, N = 1024")
+    half = extract_radioml_hdf5(path, frame_size=512, first_frame=5, max_frames=11)
+    assert np.array_equal(half, _run(np.ascontiguousarray(x[5:16, :512]), "auto"))
 
 
 @pytest.mark.parametrize("N", [128, 256, 512, 1024, 2048, 4096, 8192])

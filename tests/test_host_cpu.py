@@ -3,6 +3,7 @@ symbol include/amcx.h declares, the config mirror keeps the reference's
 attribute paths and defaults, frame sharding, and the world_size-2 gather over
 gloo.  No GPU compute is called here."""
 import ctypes
+import json
 import os
 import re
 import socket
@@ -447,8 +448,97 @@ def test_iq_pair_dataset_framing(tmp_path):
     try:
         import h5py  # noqa: F401
     except ImportError:
-        with pytest.raises(ImportError, match="h5py"):
+        from amcpy_amd import hdf5_min
+        # neither h5py nor an HDF5 C library: ImportError that names both; with the C library: the file is what is missing
+        with pytest.raises(FileNotFoundError if hdf5_min.available() else ImportError):
             extract_radioml_hdf5(tmp_path / "missing.hdf5")
+
+
+def _hdf5_or_skip():
+    from amcpy_amd import hdf5_min
+    if not hdf5_min.available():
+        pytest.skip("no HDF5 C library (>= 1.10) on this machine: set AMCX_LIBHDF5")
+    return hdf5_min
+
+
+def test_hdf5_min_reads_the_container_h5py_wrote():
+    """tests/golden/radioml_like.h5 was written by the REAL h5py (tests/golden/make_radioml_like_h5.py, run with the image's
+    conda interpreter) in the layout of RadioML 2018.01A -- X float32 (F, 1024, 2) chunked + shuffled + gzip, Y int64 one-hot
+    contiguous, Z int64 chunked; the reference reads such a file in old/dataset.py:43-56.  amcpy_amd.hdf5_min (ctypes over
+    libhdf5) returns exactly the bytes h5py was given (SHA-256 recorded by the writing script), whole and in row ranges, and
+    extract_radioml_hdf5 hands the engine the complex64 frames those pairs are."""
+    import hashlib
+    h5 = _hdf5_or_skip()
+    from amcpy_amd.feature_extraction import extract_radioml_hdf5
+    meta = json.loads((REPO / "tests" / "golden" / "radioml_like.json").read_text())
+    path = REPO / "tests" / "golden" / "radioml_like.h5"
+    with h5.File(path) as fh:
+        assert "X" in fh and "nope" not in fh
+        with pytest.raises(KeyError):
+            fh["nope"]
+        X = fh["X"]
+        assert X.shape == (24, 1024, 2) and X.dtype == np.float32 and len(X) == 24 and X.ndim == 3
+        assert fh["Y"].dtype == np.int64 and fh["Z"].shape == (24, 1)
+        whole = {k: fh[k][:] for k in "XYZ"}
+        for k, arr in whole.items():
+            assert hashlib.sha256(arr.tobytes()).hexdigest() == meta["sha256"][k], k
+            assert list(arr.shape) == meta["shape"][k]
+        assert np.array_equal(X[5:19], whole["X"][5:19]) and np.array_equal(X[7], whole["X"][7])
+        assert np.array_equal(X[-3:], whole["X"][-3:]) and X[24:].shape == (0, 1024, 2) and X[...].shape == (24, 1024, 2)
+        with pytest.raises(ValueError):
+            X[::2]
+        with pytest.raises(IndexError):
+            X[24]
+        assert (whole["Y"].sum(axis=1) == 1).all() and set(whole["Z"][:, 0]) == {2, 18}
+    with pytest.raises(ValueError):
+        X[0:1]                                   # the file is closed
+    want = whole["X"][..., 0] + 1j * whole["X"][..., 1]
+    seen = []
+
+    def compute(block):
+        seen.append(np.array(block))
+        return np.zeros((block.shape[0], 18), dtype=np.float32)
+
+    out = extract_radioml_hdf5(path, first_frame=3, max_frames=17, frame_size=512, compute=compute)
+    assert out.shape == (17, 18) and seen[0].dtype == np.complex64 and np.array_equal(seen[0], want[3:20, :512])
+    with pytest.raises(KeyError):
+        extract_radioml_hdf5(path, key="W", compute=compute)
+
+
+def test_hdf5_min_round_trip_and_concurrent_readers(tmp_path):
+    """Files hdf5_min writes itself -- contiguous, chunked, chunked + deflate -- read back bit for bit, also from several
+    threads at once (libhdf5 builds are usually not thread-safe: every call is made under one lock; extract_iq_pairs slices
+    a dataset from reader threads); something that is not HDF5 is refused."""
+    import threading
+    h5 = _hdf5_or_skip()
+    rng = np.random.default_rng(11)
+    data = rng.standard_normal((130, 64, 2)).astype(np.float32)
+    labels = rng.integers(-20, 31, size=(130, 1)).astype(np.int64)
+    for kw in ({}, {"chunks": (16, 64, 2)}, {"chunks": (7, 64, 2), "deflate": 4}):
+        path = tmp_path / "t.h5"
+        with h5.File(path, "w") as fh:
+            fh.create_dataset("X", data, **kw)
+            fh.create_dataset("Z", labels)
+        with h5.File(path) as fh:
+            ds = fh["X"]
+            assert np.array_equal(ds[:], data) and np.array_equal(fh["Z"][:], labels)
+            ok = {}
+
+            def read(a, ds=ds, ok=ok):
+                ok[a] = np.array_equal(ds[a:a + 40], data[a:a + 40])
+
+            threads = [threading.Thread(target=read, args=(a,)) for a in range(0, 120, 5)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            assert len(ok) == 24 and all(ok.values())
+    bad = tmp_path / "bad.h5"
+    bad.write_bytes(b"not an hdf5 file " * 64)
+    with pytest.raises(OSError):
+        h5.File(bad)
+    with pytest.raises(FileNotFoundError):
+        h5.File(tmp_path / "absent.h5")
 
 
 # ----------------------------------------------------------------------------
