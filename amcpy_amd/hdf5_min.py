@@ -196,7 +196,10 @@ class Dataset:
         if key is Ellipsis:
             key = slice(None)
         if isinstance(key, (int, np.integer)):
-            return self[int(key):int(key) + 1][0] if -self.shape[0] <= key < self.shape[0] else self._index_error(key)
+            k = int(key) + (self.shape[0] if key < 0 else 0)
+            if not 0 <= k < self.shape[0]:
+                raise IndexError(f"row {int(key)} of a dataset of {self.shape[0]}")
+            return self[k:k + 1][0]
         if not isinstance(key, slice):
             raise TypeError("hdf5_min.Dataset reads row ranges: ds[a:b]")
         lo, hi, step = key.indices(self.shape[0])
@@ -224,9 +227,6 @@ class Dataset:
                 lib.H5Sclose(mspace)
                 lib.H5Sclose(fspace)
         return out
-
-    def _index_error(self, key):
-        raise IndexError(f"row {key} of a dataset of {self.shape[0]}")
 
     def _close(self):
         with _LOCK:

@@ -489,6 +489,7 @@ def test_hdf5_min_reads_the_container_h5py_wrote():
             X[::2]
         with pytest.raises(IndexError):
             X[24]
+        assert np.array_equal(X[-1], whole["X"][23]) and np.array_equal(X[-24], whole["X"][0])
         assert (whole["Y"].sum(axis=1) == 1).all() and set(whole["Z"][:, 0]) == {2, 18}
     with pytest.raises(ValueError):
         X[0:1]                                   # the file is closed
