@@ -163,27 +163,35 @@ class Dataset:
             self._id = lib.H5Dopen2(file._id, name.encode(), H5P_DEFAULT)
             if self._id < 0:
                 raise KeyError(f"{file.path}: no dataset {name!r}")
-            space = lib.H5Dget_space(self._id)
             try:
-                rank = lib.H5Sget_simple_extent_ndims(space)
-                if rank < 1:
-                    raise ValueError(f"{name!r} is not a simple array (rank {rank})")
-                dims = (hsize_t * rank)()
-                lib.H5Sget_simple_extent_dims(space, dims, None)
-                self.shape: Tuple[int, ...] = tuple(int(d) for d in dims)
-            finally:
-                lib.H5Sclose(space)
-            tid = lib.H5Dget_type(self._id)
-            try:
-                cls, size = lib.H5Tget_class(tid), int(lib.H5Tget_size(tid))
-                if cls == H5T_FLOAT and size in (4, 8):
-                    self.dtype = np.dtype(f"f{size}")
-                elif cls == H5T_INTEGER and size in (1, 2, 4, 8):
-                    self.dtype = np.dtype(("u" if lib.H5Tget_sign(tid) == H5T_SGN_NONE else "i") + str(size))
-                else:
-                    raise TypeError(f"{name!r}: element class {cls} of {size} bytes is not handled by hdf5_min")
-            finally:
-                lib.H5Tclose(tid)
+                self._describe(lib, name)
+            except Exception:
+                lib.H5Dclose(self._id)            # a dataset this binding does not handle: no handle is left behind
+                self._id = -1
+                raise
+
+    def _describe(self, lib, name: str) -> None:
+        space = lib.H5Dget_space(self._id)
+        try:
+            rank = lib.H5Sget_simple_extent_ndims(space)
+            if rank < 1:
+                raise ValueError(f"{name!r} is not a simple array (rank {rank})")
+            dims = (hsize_t * rank)()
+            lib.H5Sget_simple_extent_dims(space, dims, None)
+            self.shape: Tuple[int, ...] = tuple(int(d) for d in dims)
+        finally:
+            lib.H5Sclose(space)
+        tid = lib.H5Dget_type(self._id)
+        try:
+            cls, size = lib.H5Tget_class(tid), int(lib.H5Tget_size(tid))
+            if cls == H5T_FLOAT and size in (4, 8):
+                self.dtype = np.dtype(f"f{size}")
+            elif cls == H5T_INTEGER and size in (1, 2, 4, 8):
+                self.dtype = np.dtype(("u" if lib.H5Tget_sign(tid) == H5T_SGN_NONE else "i") + str(size))
+            else:
+                raise TypeError(f"{name!r}: element class {cls} of {size} bytes is not handled by hdf5_min")
+        finally:
+            lib.H5Tclose(tid)
 
     def __len__(self) -> int:
         return self.shape[0]
