@@ -590,6 +590,15 @@ def extract_iq_pairs(dataset, frame_size: Optional[int] = None, *, first_frame: 
     if compute is not None:                       # injected engine (tests): plain (F, N) arrays
         block = np.ascontiguousarray(_pairs_as_complex(np.asarray(dataset[lo:hi]))[:, :N])
         return np.asarray(compute(block), dtype=np.float32)
+    from . import hdf5_min
+    if (isinstance(dataset, hdf5_min.Dataset) and N == L and dataset.file_offset is not None and dataset.little_endian):
+        # a contiguous dataset is a raw interleaved complex64 stream at a known place in the file: the staging threads
+        # read it themselves, slot by slot (as extract_raw_stream does), and libhdf5 is not on the data path at all
+        stream = FileComplex(dataset.file_path, np.complex64, (1, hi - lo, L), dataset.file_offset + lo * L * 8, interleaved=True)
+        try:
+            return np.asarray(HipEngine(N, device)(FrameRows(stream, 1, hi - lo)), dtype=np.float32)
+        finally:
+            stream.release()
     engine = HipEngine(N, device)
     if isinstance(dataset, np.ndarray):
         return engine(_pairs_as_complex(dataset[lo:hi]))
@@ -605,26 +614,25 @@ def extract_radioml_hdf5(path, *, key: str = "X", frame_size: Optional[int] = No
                          max_frames: Optional[int] = None, device: Optional[int] = None, compute=None,
                          chunk_frames: Optional[int] = None) -> np.ndarray:
     """``extract_iq_pairs`` on dataset ``key`` of a RadioML-style HDF5 file (``GOLD_XYZ_OSC.0001_1024.hdf5``:
-    ``X`` float32 (2 555 904, 1024, 2), reference old/dataset.py:43-56).  The file is opened with ``h5py``, which the
-    reference lists for its legacy scripts, where that is importable; otherwise with the HDF5 C library itself through
-    ``amcpy_amd.hdf5_min`` (ctypes; this image ships libhdf5 1.10.6 but no h5py for its interpreter).  Either way the
-    library decodes the chunks -- contiguous, chunked and deflate-compressed files read alike -- ``chunk_frames`` rows at a
-    time on a reader thread ahead of the upload.  Neither there: ImportError that says so."""
+    ``X`` float32 (2 555 904, 1024, 2), reference old/dataset.py:43-56).  The file is opened with the HDF5 C library
+    through ``amcpy_amd.hdf5_min`` (ctypes) where one is found, otherwise with ``h5py``, which the reference lists for
+    its legacy scripts (this image ships libhdf5 1.10.6 but no h5py for its interpreter).  A CONTIGUOUS ``X`` at its full
+    frame length is then a raw complex64 stream at a known file offset and the engine's staging threads read it
+    themselves; a chunked or compressed one is decoded by the library ``chunk_frames`` rows at a time on a reader thread
+    ahead of the upload.  Neither library there: ImportError that says so."""
+    from . import hdf5_min
+    kw = dict(first_frame=first_frame, max_frames=max_frames, device=device, compute=compute, chunk_frames=chunk_frames)
+    if hdf5_min.available():                      # the C library itself: a contiguous X then bypasses it altogether
+        with hdf5_min.File(path) as fh:
+            return extract_iq_pairs(fh[key], frame_size, **kw)
     try:
         import h5py
-    except ImportError:
-        h5py = None
-    if h5py is not None:
-        with h5py.File(str(path), "r") as fh:
-            return extract_iq_pairs(fh[key], frame_size, first_frame=first_frame, max_frames=max_frames, device=device,
-                                    compute=compute, chunk_frames=chunk_frames)
-    from . import hdf5_min
-    if not hdf5_min.available():                  # not a silent fallback: say what is missing
-        raise ImportError("extract_radioml_hdf5 needs h5py (pip install h5py) or an HDF5 C library >= 1.10 (AMCX_LIBHDF5=/path/to/"
-                          "libhdf5.so); any sliceable (F, L, 2) float32 dataset can be passed to extract_iq_pairs instead")
-    with hdf5_min.File(path) as fh:
-        return extract_iq_pairs(fh[key], frame_size, first_frame=first_frame, max_frames=max_frames, device=device,
-                                compute=compute, chunk_frames=chunk_frames)
+    except ImportError as exc:                    # not a silent fallback: say what is missing
+        raise ImportError("extract_radioml_hdf5 needs an HDF5 C library >= 1.10 (AMCX_LIBHDF5=/path/to/libhdf5.so) or h5py "
+                          "(pip install h5py); any sliceable (F, L, 2) float32 dataset can be passed to extract_iq_pairs "
+                          "instead") from exc
+    with h5py.File(str(path), "r") as fh:
+        return extract_iq_pairs(fh[key], frame_size, **kw)
 
 
 # ----------------------------------------------------------------------------

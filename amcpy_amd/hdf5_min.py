@@ -98,6 +98,7 @@ def _declare(lib):
         "H5Dclose": (herr_t, [hid_t]),
         "H5Dget_space": (hid_t, [hid_t]),
         "H5Dget_type": (hid_t, [hid_t]),
+        "H5Dget_offset": (ctypes.c_uint64, [hid_t]),
         "H5Dread": (herr_t, [hid_t, hid_t, hid_t, hid_t, hid_t, ctypes.c_void_p]),
         "H5Dwrite": (herr_t, [hid_t, hid_t, hid_t, hid_t, hid_t, ctypes.c_void_p]),
         "H5Sclose": (herr_t, [hid_t]),
@@ -190,8 +191,14 @@ class Dataset:
                 self.dtype = np.dtype(("u" if lib.H5Tget_sign(tid) == H5T_SGN_NONE else "i") + str(size))
             else:
                 raise TypeError(f"{name!r}: element class {cls} of {size} bytes is not handled by hdf5_min")
+            self.little_endian = lib.H5Tget_order(tid) == H5T_ORDER_LE
         finally:
             lib.H5Tclose(tid)
+        # a CONTIGUOUS dataset's bytes lie in one run of the file (no chunks, no filters): where, or None.  The engine's
+        # staging threads can then pread them straight into their pinned slots, past libhdf5 (extract_iq_pairs).
+        off = int(lib.H5Dget_offset(self._id))
+        self.file_offset: Optional[int] = None if off == 0xFFFFFFFFFFFFFFFF else off
+        self.file_path = self._file.path
 
     def __len__(self) -> int:
         return self.shape[0]

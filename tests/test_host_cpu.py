@@ -523,6 +523,12 @@ def test_hdf5_min_round_trip_and_concurrent_readers(tmp_path):
         with h5.File(path) as fh:
             ds = fh["X"]
             assert np.array_equal(ds[:], data) and np.array_equal(fh["Z"][:], labels)
+            # a contiguous dataset says where its bytes lie in the file (the engine's staging threads pread them
+            # there, past the library); a chunked one has no such place
+            assert ds.little_endian and (ds.file_offset is None) == ("chunks" in kw)
+            if ds.file_offset is not None:
+                raw = np.fromfile(path, dtype=np.float32, count=data.size, offset=ds.file_offset).reshape(data.shape)
+                assert np.array_equal(raw, data)
             ok = {}
 
             def read(a, ds=ds, ok=ok):
