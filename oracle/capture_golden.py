@@ -8,6 +8,7 @@ there read these fixtures.
 
     python oracle/capture_golden.py                      # regenerate every fixture
     python oracle/capture_golden.py frames 128 512 8192  # only these frames_n{N}.npz
+    python oracle/capture_golden.py edges 1024 4096 8192 # only these edges_n{N}.npz
 
 Fixtures:
   kat_n10.json            the reference's own known-answer vector and table
@@ -17,7 +18,7 @@ Fixtures:
                           input, float32-stored as feature_extraction.py:35,56
                           does) + its unrounded float64; golden32 (reference on
                           the complex64 input as is); the 11 moments
-  edges_n{N}.npz          degenerate frames and what the reference returns
+  edges_n{N}.npz          N in {1000, 1024, 2048, 4096, 8192}: degenerate frames and what the reference returns
   range_n2048.npz         ordinary frames at scales 1e-12 ... 1e12 (and mixed-scale ones): the
                           reference's float32-stored outputs incl. their inf / 0 pattern
   range_extreme_n2048.npz the same frames at 1e-30, 1e-20, 1e20, 1e30 (the ends of float32)
@@ -312,6 +313,12 @@ def main():
             p = OUT / f"frames_n{N}.npz"
             print(f"{p.name:28s} {p.stat().st_size:9d} B")
         return
+    if len(sys.argv) > 2 and sys.argv[1] == "edges":
+        for N in map(int, sys.argv[2:]):
+            capture_edges(rfeat, N)
+            p = OUT / f"edges_n{N}.npz"
+            print(f"{p.name:28s} {p.stat().st_size:9d} B")
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "range":
         capture_range(rfeat, 2048)
         capture_roundtrip_f64(rfe, rcfg)
@@ -321,7 +328,7 @@ def main():
     capture_kat(rfeat)
     for N in (128, 512, 1024, 2048, 4096, 8192):
         capture_frames(rfeat, N)
-    for N in (1000, 2048):
+    for N in (1000, 1024, 2048, 4096, 8192):
         capture_edges(rfeat, N)
     capture_range(rfeat, 2048)
     capture_roundtrip(rfe, rcfg)

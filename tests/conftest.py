@@ -43,6 +43,6 @@ def golden_frames(request):
     return request.param, load_npz(f"frames_n{request.param}.npz")
 
 
-@pytest.fixture(scope="session", params=[1000, 2048])
+@pytest.fixture(scope="session", params=[1000, 1024, 2048, 4096, 8192])
 def golden_edges(request):
     return request.param, load_npz(f"edges_n{request.param}.npz")
