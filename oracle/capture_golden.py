@@ -19,9 +19,9 @@ Fixtures:
                           does) + its unrounded float64; golden32 (reference on
                           the complex64 input as is); the 11 moments
   edges_n{N}.npz          N in {1000, 1024, 2048, 4096, 8192}: degenerate frames and what the reference returns
-  range_n2048.npz         ordinary frames at scales 1e-12 ... 1e12 (and mixed-scale ones): the
-                          reference's float32-stored outputs incl. their inf / 0 pattern
-  range_extreme_n2048.npz the same frames at 1e-30, 1e-20, 1e20, 1e30 (the ends of float32)
+  range_n{N}.npz          N in {2048, 4096, 8192}: ordinary frames at scales 1e-12 ... 1e12 (and mixed-scale
+                          ones): the reference's float32-stored outputs incl. their inf / 0 pattern
+  range_extreme_n{N}.npz  the same frames at 1e-30, 1e-20, 1e20, 1e30 (the ends of float32)
   extract_roundtrip.npz   a tiny `run_extraction(cfg)` run by the reference:
                           input container + the six output files' contents
   extract_roundtrip_f64.npz  the same on a container of genuine doubles (not float32 casts)
@@ -319,6 +319,12 @@ def main():
             p = OUT / f"edges_n{N}.npz"
             print(f"{p.name:28s} {p.stat().st_size:9d} B")
         return
+    if len(sys.argv) > 2 and sys.argv[1] == "range":            # range 4096 8192: only these sizes' range fixtures
+        for N in map(int, sys.argv[2:]):
+            capture_range(rfeat, N)
+            for name in (f"range_n{N}.npz", f"range_extreme_n{N}.npz"):
+                print(f"{name:28s} {(OUT / name).stat().st_size:9d} B")
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "range":
         capture_range(rfeat, 2048)
         capture_roundtrip_f64(rfe, rcfg)
@@ -330,7 +336,8 @@ def main():
         capture_frames(rfeat, N)
     for N in (1000, 1024, 2048, 4096, 8192):
         capture_edges(rfeat, N)
-    capture_range(rfeat, 2048)
+    for N in (2048, 4096, 8192):
+        capture_range(rfeat, N)
     capture_roundtrip(rfe, rcfg)
     capture_roundtrip_f64(rfe, rcfg)
     capture_config_defaults(rcfg)

@@ -727,15 +727,16 @@ def test_launch_is_graph_capturable():
     assert torch.equal(out, want)
 
 
-def test_dynamic_range_matches_the_float32_stored_reference():
+@pytest.mark.parametrize("N", [2048, 4096, 8192])
+def test_dynamic_range_matches_the_float32_stored_reference(N):
     """Frames of ordinary shape at scales 1e-12 ... 1e12, one whose halves differ by ten orders
-    of magnitude and one with a single 5e7 sample (tests/golden/range_n2048.npz, captured from
-    the reference).  The reference evaluates in complex128 and stores float32
+    of magnitude and one with a single 5e7 sample (tests/golden/range_n{N}.npz, captured from
+    the reference; N = 4096 and 8192 since round 4: the one-wave kernel's and the quad kernel's own re-runs).  The reference evaluates in complex128 and stores float32
     (features.py:46-58, feature_extraction.py:35,56): its sixth-order cumulants are inf above
     |x| ~ 2.6e6 and 0 below ~ 3e-8 while everything else stays finite.  Both variants must
     reproduce that pattern exactly and every finite value within the usual tolerance -- the wave
     kernel by flagging what its fp32 sums cannot hold for the fp64-sum fix-up."""
-    g = load_npz("range_n2048.npz")
+    g = load_npz(f"range_n{N}.npz")
     x, names = g["iq"], [str(n) for n in g["names"]]
     gold32, gold64 = g["golden64"], g["golden64_f64"]
     S = orc.conditioning_scales(x.astype(np.complex128))
@@ -1145,14 +1146,15 @@ def test_out_of_range_frames_scattered_over_a_full_grid(N):
     assert np.array_equal(got[kinds == 0], ref[pick][kinds == 0].astype(np.float32), equal_nan=True)
 
 
-def test_ends_of_float32_through_the_range_pass():
-    """range_extreme_n2048.npz (captured from the reference): the range fixture's frames at 1e-30, 1e-20,
+@pytest.mark.parametrize("N", [2048, 4096, 8192])
+def test_ends_of_float32_through_the_range_pass(N):
+    """range_extreme_n{N}.npz (captured from the reference): the range fixture's frames at 1e-30, 1e-20,
     1e20 and 1e30 -- |x|^2 itself leaves float32.  The reference, evaluating in complex128, still returns
     finite scale-free features, a finite mean magnitude, and inf / 0 / float32 denormals for the rest.
     The wave kernel flags such frames (also the ones whose power underflows to that of an all-zero
     frame: their angles give them away) and its range pass, working on the frame times an exact power
     of two, reproduces all of it."""
-    g = load_npz("range_extreme_n2048.npz")
+    g = load_npz(f"range_extreme_n{N}.npz")
     x, names, gold32 = g["iq"], [str(n) for n in g["names"]], g["golden64"]
     S = orc.conditioning_scales(x.astype(np.complex128))
     for variant in VARIANTS_POW2:            # the block kernel stages every frame times a power of two as well
@@ -1164,7 +1166,7 @@ def test_ends_of_float32_through_the_range_pass():
     _check_ends_of_float32(_run(x1000, "auto"), gold1000, orc.conditioning_scales(x1000.astype(np.complex128)), names, "N=1000")
     # an all-zero frame is still a zero frame (not flagged, not scaled): NaN pattern of the reference
     for variant in VARIANTS_POW2:
-        z = _run(np.zeros((1, 2048), np.complex64), variant)[0]
+        z = _run(np.zeros((1, N), np.complex64), variant)[0]
         assert np.isnan(z[[3, 7, 8]]).all() and np.all(z[[0, 1, 2, 4, 5, 6] + list(range(9, 18))] == 0)
 
 

@@ -131,11 +131,12 @@ def test_extract_roundtrip_fixture_is_reference_rows():
         assert str(g[f"label_{mod}"]) == mod
 
 
-def test_oracle_at_extreme_scales_matches_reference():
-    """range_n2048.npz (captured from the reference): frames at scales 1e-12 ... 1e12, a mixed-scale
+@pytest.mark.parametrize("N", [2048, 4096, 8192])
+def test_oracle_at_extreme_scales_matches_reference(N):
+    """range_n{N}.npz (captured from the reference): frames at scales 1e-12 ... 1e12, a mixed-scale
     frame and a single 5e7 spike.  Both oracle evaluators on the complex128 cast reproduce the
     reference's float64 values (and therefore its float32-stored inf / 0 pattern)."""
-    g = load_npz("range_n2048.npz")
+    g = load_npz(f"range_n{N}.npz")
     x, gold = g["iq"].astype(np.complex128), g["golden64_f64"]
     fused = orc.features18_batch(x)
     assert np.allclose(fused, gold, rtol=5e-9, atol=0, equal_nan=True)
@@ -161,8 +162,9 @@ def test_oracle_on_genuine_doubles_matches_reference_run():
         assert np.allclose(got, want, rtol=2e-6, atol=0, equal_nan=True), m
 
 
-def test_oracle_at_the_ends_of_float32_matches_reference():
-    g = load_npz("range_extreme_n2048.npz")
+@pytest.mark.parametrize("N", [2048, 4096, 8192])
+def test_oracle_at_the_ends_of_float32_matches_reference(N):
+    g = load_npz(f"range_extreme_n{N}.npz")
     x, gold = g["iq"].astype(np.complex128), g["golden64_f64"]
     assert np.allclose(orc.features18_batch(x), gold, rtol=5e-9, atol=0, equal_nan=True)
     got = np.array(orc.calculate_features(range(1, 19), x[0]))
