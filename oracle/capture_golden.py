@@ -13,8 +13,9 @@ there read these fixtures.
 Fixtures:
   kat_n10.json            the reference's own known-answer vector and table
                           (features.py:240-255, 286-305) restated as data
-  frames_n{N}.npz         N in {128, 512, 1024, 2048, 4096}: 6 mods x 3 SNR x 2 frames
-                          (N = 8192: 6 mods x 1 SNR x 2) complex64 inputs; golden64 (reference on complex128
+  frames_n{N}.npz         N in {128, 256, 512, 1000, 1024, 2048, 4096}: 6 mods x 3 SNR x 2 frames
+                          (N = 5000, 8192: 6 mods x 1 SNR x 2) complex64 inputs (1000 and 5000: the block kernel's
+                          two Bluestein forms); golden64 (reference on complex128
                           input, float32-stored as feature_extraction.py:35,56
                           does) + its unrounded float64; golden32 (reference on
                           the complex64 input as is); the 11 moments
@@ -99,7 +100,7 @@ def capture_kat(rfeat):
 
 def capture_frames(rfeat, N):
     from amcpy_amd import synth
-    snrs = (-10.0, 4.0, 20.0) if N <= 4096 else (4.0,)        # N = 8192: 12 frames keep the fixture under 1 MB
+    snrs = (-10.0, 4.0, 20.0) if N <= 4096 else (4.0,)        # N = 5000, 8192: 12 frames keep the fixture under 1 MB
     frames, tags = [], []
     for mi, mod in enumerate(synth.MODS6):
         for si, snr in enumerate(snrs):
@@ -332,7 +333,7 @@ def main():
             print(f"{name:28s} {(OUT / name).stat().st_size:9d} B")
         return
     capture_kat(rfeat)
-    for N in (128, 512, 1024, 2048, 4096, 8192):
+    for N in (128, 256, 512, 1000, 1024, 2048, 4096, 5000, 8192):
         capture_frames(rfeat, N)
     for N in (1000, 1024, 2048, 4096, 8192):
         capture_edges(rfeat, N)

@@ -38,7 +38,7 @@ def load_npz(name):
     return np.load(GOLDEN / name, allow_pickle=False)
 
 
-@pytest.fixture(scope="session", params=[128, 512, 1024, 2048, 4096, 8192])
+@pytest.fixture(scope="session", params=[128, 256, 512, 1000, 1024, 2048, 4096, 5000, 8192])
 def golden_frames(request):
     return request.param, load_npz(f"frames_n{request.param}.npz")
 
