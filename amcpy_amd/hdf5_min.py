@@ -42,6 +42,8 @@ H5S_SELECT_SET = 0
 H5T_INTEGER, H5T_FLOAT = 0, 1
 H5T_SGN_NONE = 0
 H5T_ORDER_LE, H5T_ORDER_BE = 0, 1
+H5D_CHUNKED = 2
+H5Z_FILTER_DEFLATE, H5Z_FILTER_SHUFFLE = 1, 2
 
 
 def _candidates():
@@ -99,6 +101,12 @@ def _declare(lib):
         "H5Dget_space": (hid_t, [hid_t]),
         "H5Dget_type": (hid_t, [hid_t]),
         "H5Dget_offset": (ctypes.c_uint64, [hid_t]),
+        "H5Dget_create_plist": (hid_t, [hid_t]),
+        "H5Pget_layout": (ctypes.c_int, [hid_t]),
+        "H5Pget_chunk": (ctypes.c_int, [hid_t, ctypes.c_int, P(hsize_t)]),
+        "H5Pget_nfilters": (ctypes.c_int, [hid_t]),
+        "H5Pget_filter2": (ctypes.c_int, [hid_t, ctypes.c_uint, P(ctypes.c_uint), P(ctypes.c_size_t), P(ctypes.c_uint),
+                                           ctypes.c_size_t, ctypes.c_char_p, P(ctypes.c_uint)]),
         "H5Dread": (herr_t, [hid_t, hid_t, hid_t, hid_t, hid_t, ctypes.c_void_p]),
         "H5Dwrite": (herr_t, [hid_t, hid_t, hid_t, hid_t, hid_t, ctypes.c_void_p]),
         "H5Sclose": (herr_t, [hid_t]),
@@ -119,6 +127,18 @@ def _declare(lib):
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
+    # raw chunk access (1.10.3+): optional -- without it chunked datasets are read through H5Dread only
+    optional = {
+        "H5Dget_chunk_storage_size": (herr_t, [hid_t, P(hsize_t), P(hsize_t)]),
+        "H5Dread_chunk": (herr_t, [hid_t, hid_t, P(hsize_t), P(ctypes.c_uint32), ctypes.c_void_p]),
+    }
+    lib._amcx_raw_chunks = True
+    for name, (res, args) in optional.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            lib._amcx_raw_chunks = False
+        else:
+            fn.restype, fn.argtypes = res, args
 
 
 def available() -> bool:
@@ -199,6 +219,90 @@ class Dataset:
         off = int(lib.H5Dget_offset(self._id))
         self.file_offset: Optional[int] = None if off == 0xFFFFFFFFFFFFFFFF else off
         self.file_path = self._file.path
+        # chunk shape and filter pipeline (ids in the order they were applied on write)
+        self.chunks: Optional[Tuple[int, ...]] = None
+        self.filters: Tuple[int, ...] = ()
+        dcpl = lib.H5Dget_create_plist(self._id)
+        if dcpl >= 0:
+            try:
+                if lib.H5Pget_layout(dcpl) == H5D_CHUNKED:
+                    cd = (hsize_t * len(self.shape))()
+                    if lib.H5Pget_chunk(dcpl, len(self.shape), cd) >= 0:
+                        self.chunks = tuple(int(v) for v in cd)
+                    ids = []
+                    for i in range(max(0, lib.H5Pget_nfilters(dcpl))):
+                        flags, cfg = ctypes.c_uint(), ctypes.c_uint()
+                        n_cd = ctypes.c_size_t(0)
+                        ids.append(int(lib.H5Pget_filter2(dcpl, i, ctypes.byref(flags), ctypes.byref(n_cd), None, 0, None,
+                                                          ctypes.byref(cfg))))
+                    self.filters = tuple(ids)
+            finally:
+                lib.H5Pclose(dcpl)
+
+    @property
+    def _parallel_chunks(self) -> bool:
+        """Chunks of whole rows whose filters are at most shuffle + deflate, native little-endian elements: the raw chunks
+        can be fetched from the library (cheap, under the lock) and inflated on several threads outside it."""
+        lib = _lib()
+        return (getattr(lib, "_amcx_raw_chunks", False) and self.chunks is not None and self.little_endian
+                and self.chunks[1:] == self.shape[1:] and len(self.filters) > 0
+                and self.filters in ((H5Z_FILTER_DEFLATE,), (H5Z_FILTER_SHUFFLE, H5Z_FILTER_DEFLATE)))
+
+    def _read_chunks(self, lo: int, hi: int, out: np.ndarray) -> None:
+        """Rows lo .. hi-1 into ``out`` chunk by chunk: H5Dread_chunk hands over a chunk as it is stored, zlib inflates it and
+        the byte shuffle is undone here, on a few threads (zlib and numpy release the GIL) -- libhdf5's own H5Dread inflates
+        on the calling thread, under this module's lock."""
+        import zlib
+        from concurrent.futures import ThreadPoolExecutor
+        lib = _lib()
+        rows, item = self.chunks[0], self.dtype.itemsize
+        per_row = int(np.prod(self.shape[1:], dtype=np.int64)) if len(self.shape) > 1 else 1
+        chunk_bytes = rows * per_row * item
+        flat = out.reshape(hi - lo, per_row)
+
+        def one(k: int) -> None:
+            coord = _dims((k * rows,) + (0,) * (len(self.shape) - 1))
+            with _LOCK:
+                if self._id < 0:
+                    raise ValueError("dataset of a closed file")
+                stored = hsize_t(0)
+                if lib.H5Dget_chunk_storage_size(self._id, coord, ctypes.byref(stored)) < 0:
+                    raise OSError(f"{self.name!r}: chunk {k} has no storage size")
+                raw = None
+                if stored.value > 0:
+                    raw = ctypes.create_string_buffer(int(stored.value))
+                    mask = ctypes.c_uint32(0)
+                    if lib.H5Dread_chunk(self._id, H5P_DEFAULT, coord, ctypes.byref(mask), raw) < 0:
+                        raise OSError(f"{self._file.path}: reading chunk {k} of {self.name!r} failed")
+                    mask = mask.value
+            a, b = max(lo, k * rows), min(hi, (k + 1) * rows)
+            if raw is None:                                   # never written: the fill value (0 by default)
+                flat[a - lo:b - lo] = 0
+                return
+            data = raw.raw
+            for pos in range(len(self.filters) - 1, -1, -1):  # undo the pipeline back to front; bit `pos` set: skipped
+                if mask & (1 << pos):
+                    continue
+                if self.filters[pos] == H5Z_FILTER_DEFLATE:
+                    # (the output size is known: without it zlib grows its buffer step by step, re-taking the GIL each
+                    #  time, and eight threads are no faster than one)
+                    data = zlib.decompress(data, bufsize=chunk_bytes)
+                else:                                         # shuffle: byte j of every element was stored together
+                    n = len(data) // item
+                    data = np.frombuffer(data, dtype=np.uint8, count=n * item).reshape(item, n).T.tobytes()
+            if len(data) != chunk_bytes:
+                raise OSError(f"{self.name!r}: chunk {k} decodes to {len(data)} bytes, expected {chunk_bytes}")
+            block = np.frombuffer(data, dtype=self.dtype).reshape(rows, per_row)
+            flat[a - lo:b - lo] = block[a - k * rows:b - k * rows]
+
+        ks = range(lo // rows, (hi - 1) // rows + 1)
+        workers = min(len(ks), max(1, min(8, (os.cpu_count() or 2))))
+        if workers <= 1:
+            for k in ks:
+                one(k)
+        else:
+            with ThreadPoolExecutor(max_workers=workers, thread_name_prefix="amcx-h5") as ex:
+                list(ex.map(one, ks))
 
     def __len__(self) -> int:
         return self.shape[0]
@@ -223,6 +327,9 @@ class Dataset:
         count = max(0, hi - lo)
         out = np.empty((count,) + self.shape[1:], dtype=self.dtype)
         if out.size == 0:
+            return out
+        if self._parallel_chunks:
+            self._read_chunks(lo, hi, out)
             return out
         lib = _lib()
         with _LOCK:

@@ -478,6 +478,9 @@ def test_hdf5_min_reads_the_container_h5py_wrote():
             fh["nope"]
         X = fh["X"]
         assert X.shape == (24, 1024, 2) and X.dtype == np.float32 and len(X) == 24 and X.ndim == 3
+        # chunked + shuffled + gzip: read as raw chunks, inflated and unshuffled on several threads outside the library
+        assert X.chunks == (8, 1024, 2) and X.filters == (h5.H5Z_FILTER_SHUFFLE, h5.H5Z_FILTER_DEFLATE) and X._parallel_chunks
+        assert X.file_offset is None and fh["Y"].chunks is None and not fh["Z"]._parallel_chunks
         assert fh["Y"].dtype == np.int64 and fh["Z"].shape == (24, 1)
         whole = {k: fh[k][:] for k in "XYZ"}
         for k, arr in whole.items():
