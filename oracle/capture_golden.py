@@ -26,6 +26,8 @@ Fixtures:
   extract_roundtrip.npz   a tiny `run_extraction(cfg)` run by the reference:
                           input container + the six output files' contents
   extract_roundtrip_f64.npz  the same on a container of genuine doubles (not float32 casts)
+  configs0_reference_run.npz BASELINE configs[0] (6 x 2 x 500 x 2048) through the reference's run_extraction: its outputs
+                          and the SHA-256 of the seeded inputs (python oracle/capture_golden.py configs0)
   config_defaults.json    field names and defaults of the reference's config layer
 """
 
@@ -187,6 +189,43 @@ def capture_roundtrip(rfe, rcfg):
              n_frames=n_frames, mods=np.array(mods), **rec)
 
 
+def capture_configs0(rfe, rcfg):
+    """BASELINE configs[0] -- the reference's own CPU-runnable case -- by the reference's own batch driver: 6 modulations x
+    2 SNR x 500 frames x 2048 samples (synth.host_frames, the seeds of SURVEY.md section 8d) as a container of MATLAB
+    doubles, `run_extraction(cfg)` with its default eight threads per modulation, the six {mod}_features.mat it writes.
+    The 98 MB input is NOT stored: the test regenerates it from the seeds and checks the SHA-256 recorded here; the
+    fixture holds the reference's 6 x (2, 500, 18) float32 outputs (432 KB)."""
+    import hashlib
+    import time
+    import scipy.io
+    from amcpy_amd import synth
+    n_snr, n_frames, fs = 2, 500, 2048
+    mods = synth.MODS6
+    blocks = synth.host_frames(mods, n_snr, n_frames, fs)
+    with tempfile.TemporaryDirectory() as td:
+        paths = rcfg.Paths(root=Path(td))
+        sig = rcfg.SignalConfig(snr_values={0: "0", 1: "10"}, num_frames=n_frames, frame_size=fs)
+        cfg = rcfg.Config(paths=paths, signals=sig)
+        paths.ensure_dirs()
+        scipy.io.savemat(str(paths.mat_data / paths.mat_filename),
+                         {sig.mat_info[m]: blocks[m].astype(np.complex128) for m in mods})
+        t0 = time.time()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            rfe.run_extraction(cfg)
+        seconds = time.time() - t0
+        rec = {}
+        for m in mods:
+            d = scipy.io.loadmat(str(paths.calculated_features / f"{m}_features.mat"))
+            arr = d[sig.mat_info[m]]
+            assert arr.dtype == np.float32 and arr.shape == (n_snr, n_frames, 18) and np.isfinite(arr).all()
+            rec[f"out_{m}"] = arr
+            rec[f"sha256_in_{m}"] = np.array(hashlib.sha256(np.ascontiguousarray(blocks[m]).tobytes()).hexdigest())
+    np.savez(OUT / "configs0_reference_run.npz", n_snr=n_snr, n_frames=n_frames, frame_size=fs, mods=np.array(mods),
+             reference_seconds=seconds, reference_threads=sig.num_threads, **rec)
+    print(f"reference run_extraction on configs[0]: {seconds:.1f} s here ({6 * n_snr * n_frames / seconds:.0f} frames/s)")
+
+
 def range_frames(N):
     """Frames of ordinary shape at extraordinary scales (and one whose halves differ by ten
     orders of magnitude): the reference evaluates in complex128 and stores float32
@@ -314,6 +353,11 @@ def main():
             p = OUT / f"frames_n{N}.npz"
             print(f"{p.name:28s} {p.stat().st_size:9d} B")
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "configs0":
+        capture_configs0(rfe, rcfg)
+        p = OUT / "configs0_reference_run.npz"
+        print(f"{p.name:28s} {p.stat().st_size:9d} B")
+        return
     if len(sys.argv) > 2 and sys.argv[1] == "edges":
         for N in map(int, sys.argv[2:]):
             capture_edges(rfeat, N)
@@ -341,6 +385,7 @@ def main():
         capture_range(rfeat, N)
     capture_roundtrip(rfe, rcfg)
     capture_roundtrip_f64(rfe, rcfg)
+    capture_configs0(rfe, rcfg)
     capture_config_defaults(rcfg)
     for p in sorted(OUT.iterdir()):
         print(f"{p.name:28s} {p.stat().st_size:9d} B")

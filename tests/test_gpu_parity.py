@@ -801,6 +801,42 @@ def test_run_extraction_on_a_container_of_genuine_doubles(tmp_path):
 CLI_UNFLOORED_EXCEPTIONS = {"WGN": [106]}
 
 
+def test_run_extraction_against_the_references_own_run_of_configs0(tmp_path):
+    """BASELINE configs[0] end to end against the REFERENCE ITSELF: tests/golden/configs0_reference_run.npz holds what the
+    reference's run_extraction (feature_extraction.py:85-99) wrote for 6 modulations x 2 SNR x 500 frames x 2048 samples
+    of MATLAB doubles (oracle/capture_golden.py configs0; 16.7 s there).  The same container -- regenerated from its
+    seeds, SHA-256 checked -- through this package's run_extraction: same files, same keys, every one of the 6 000 rows
+    within the parity bounds of the reference's stored float32."""
+    import hashlib
+    import scipy.io
+    from amcpy_amd import synth
+    from amcpy_amd.config import Config, Paths, SignalConfig
+    from amcpy_amd.feature_extraction import run_extraction
+    g = load_npz("configs0_reference_run.npz")
+    n_snr, n_frames, fs = int(g["n_snr"]), int(g["n_frames"]), int(g["frame_size"])
+    blocks = synth.host_frames(synth.MODS6, n_snr, n_frames, fs)
+    for m in synth.MODS6:
+        assert hashlib.sha256(np.ascontiguousarray(blocks[m]).tobytes()).hexdigest() == str(g[f"sha256_in_{m}"]), m
+    cfg = Config(paths=Paths(root=tmp_path),
+                 signals=SignalConfig(snr_values={0: "0", 1: "10"}, num_frames=n_frames, frame_size=fs))
+    cfg.paths.ensure_dirs()
+    scipy.io.savemat(str(cfg.paths.mat_data / cfg.paths.mat_filename),
+                     {cfg.signals.mat_info[m]: blocks[m].astype(np.complex128) for m in synth.MODS6})
+    run_extraction(cfg, verbose=False)
+    worst = 0
+    for m in synth.MODS6:
+        d = scipy.io.loadmat(str(cfg.paths.calculated_features / f"{m}_features.mat"))
+        assert sorted(k for k in d if not k.startswith("__")) == sorted(["Modulation", cfg.signals.mat_info[m]])
+        arr = d[cfg.signals.mat_info[m]]
+        want = g[f"out_{m}"]
+        assert arr.dtype == np.float32 and arr.shape == want.shape == (n_snr, n_frames, 18)
+        x = blocks[m].reshape(-1, fs)
+        over = _assert_parity(arr.reshape(-1, 18), want.reshape(-1, 18).astype(np.float64), x,
+                              f"run_extraction vs the reference's run, {m}", large_sample=True)
+        worst = max(worst, int(np.count_nonzero(over)))
+    assert worst <= 1, worst            # at most the one frame per modulation the configs[0] CLI test pins as an exception
+
+
 def test_extract_cli_on_the_configs0_shape(tmp_path):
     """`python -m amcpy_amd extract` as a subprocess on BASELINE configs[0]: 6 modulations x 2 SNR
     x 500 frames x 2048 samples in mat-data/all_modulations.mat -> six {mod}_features.mat, checked

@@ -169,3 +169,21 @@ def test_oracle_at_the_ends_of_float32_matches_reference(N):
     assert np.allclose(orc.features18_batch(x), gold, rtol=5e-9, atol=0, equal_nan=True)
     got = np.array(orc.calculate_features(range(1, 19), x[0]))
     assert np.array_equal(got, gold[0], equal_nan=True)
+
+
+def test_oracle_matches_the_references_run_of_baseline_configs0():
+    """configs0_reference_run.npz: BASELINE configs[0] (6 modulations x 2 SNR x 500 frames x 2048 samples, a container of
+    MATLAB doubles) through the REFERENCE's own run_extraction (feature_extraction.py:85-99; 16.7 s on this container's
+    eight cores).  The inputs are regenerated from their seeds (SHA-256 checked); the oracle reproduces all 6 000 rows
+    the reference stored."""
+    import hashlib
+    from amcpy_amd import synth
+    g = load_npz("configs0_reference_run.npz")
+    n_snr, n_frames, fs = int(g["n_snr"]), int(g["n_frames"]), int(g["frame_size"])
+    blocks = synth.host_frames(synth.MODS6, n_snr, n_frames, fs)
+    for m in synth.MODS6:
+        x = np.ascontiguousarray(blocks[m])
+        assert hashlib.sha256(x.tobytes()).hexdigest() == str(g[f"sha256_in_{m}"]), f"{m}: the seeded input changed"
+        got = orc.features18_batch(x.reshape(-1, fs).astype(np.complex128)).astype(np.float32)
+        want = g[f"out_{m}"].reshape(-1, 18)
+        assert np.allclose(got, want, rtol=2e-6, atol=0), m
