@@ -28,6 +28,7 @@ Fixtures:
   extract_roundtrip_f64.npz  the same on a container of genuine doubles (not float32 casts)
   configs0_reference_run.npz BASELINE configs[0] (6 x 2 x 500 x 2048) through the reference's run_extraction: its outputs
                           and the SHA-256 of the seeded inputs (python oracle/capture_golden.py configs0)
+  configs2_reference_run.npz the same at BASELINE configs[2]'s frame size: 6 x 2 x 50 x 4096
   config_defaults.json    field names and defaults of the reference's config layer
 """
 
@@ -189,7 +190,7 @@ def capture_roundtrip(rfe, rcfg):
              n_frames=n_frames, mods=np.array(mods), **rec)
 
 
-def capture_configs0(rfe, rcfg):
+def capture_configs0(rfe, rcfg, n_frames=500, fs=2048, name="configs0_reference_run.npz"):
     """BASELINE configs[0] -- the reference's own CPU-runnable case -- by the reference's own batch driver: 6 modulations x
     2 SNR x 500 frames x 2048 samples (synth.host_frames, the seeds of SURVEY.md section 8d) as a container of MATLAB
     doubles, `run_extraction(cfg)` with its default eight threads per modulation, the six {mod}_features.mat it writes.
@@ -199,7 +200,7 @@ def capture_configs0(rfe, rcfg):
     import time
     import scipy.io
     from amcpy_amd import synth
-    n_snr, n_frames, fs = 2, 500, 2048
+    n_snr = 2
     mods = synth.MODS6
     blocks = synth.host_frames(mods, n_snr, n_frames, fs)
     with tempfile.TemporaryDirectory() as td:
@@ -221,9 +222,9 @@ def capture_configs0(rfe, rcfg):
             assert arr.dtype == np.float32 and arr.shape == (n_snr, n_frames, 18) and np.isfinite(arr).all()
             rec[f"out_{m}"] = arr
             rec[f"sha256_in_{m}"] = np.array(hashlib.sha256(np.ascontiguousarray(blocks[m]).tobytes()).hexdigest())
-    np.savez(OUT / "configs0_reference_run.npz", n_snr=n_snr, n_frames=n_frames, frame_size=fs, mods=np.array(mods),
+    np.savez(OUT / name, n_snr=n_snr, n_frames=n_frames, frame_size=fs, mods=np.array(mods),
              reference_seconds=seconds, reference_threads=sig.num_threads, **rec)
-    print(f"reference run_extraction on configs[0]: {seconds:.1f} s here ({6 * n_snr * n_frames / seconds:.0f} frames/s)")
+    print(f"reference run_extraction, 6 x {n_snr} x {n_frames} x {fs}: {seconds:.1f} s here ({6 * n_snr * n_frames / seconds:.0f} frames/s)")
 
 
 def range_frames(N):
@@ -355,8 +356,9 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "configs0":
         capture_configs0(rfe, rcfg)
-        p = OUT / "configs0_reference_run.npz"
-        print(f"{p.name:28s} {p.stat().st_size:9d} B")
+        capture_configs0(rfe, rcfg, n_frames=50, fs=4096, name="configs2_reference_run.npz")
+        for name in ("configs0_reference_run.npz", "configs2_reference_run.npz"):
+            print(f"{name:28s} {(OUT / name).stat().st_size:9d} B")
         return
     if len(sys.argv) > 2 and sys.argv[1] == "edges":
         for N in map(int, sys.argv[2:]):
@@ -386,6 +388,7 @@ def main():
     capture_roundtrip(rfe, rcfg)
     capture_roundtrip_f64(rfe, rcfg)
     capture_configs0(rfe, rcfg)
+    capture_configs0(rfe, rcfg, n_frames=50, fs=4096, name="configs2_reference_run.npz")
     capture_config_defaults(rcfg)
     for p in sorted(OUT.iterdir()):
         print(f"{p.name:28s} {p.stat().st_size:9d} B")

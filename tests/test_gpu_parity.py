@@ -801,18 +801,20 @@ def test_run_extraction_on_a_container_of_genuine_doubles(tmp_path):
 CLI_UNFLOORED_EXCEPTIONS = {"WGN": [106]}
 
 
-def test_run_extraction_against_the_references_own_run_of_configs0(tmp_path):
+@pytest.mark.parametrize("fixture", ["configs0_reference_run.npz", "configs2_reference_run.npz"])
+def test_run_extraction_against_the_references_own_run_of_configs0(tmp_path, fixture):
     """BASELINE configs[0] end to end against the REFERENCE ITSELF: tests/golden/configs0_reference_run.npz holds what the
     reference's run_extraction (feature_extraction.py:85-99) wrote for 6 modulations x 2 SNR x 500 frames x 2048 samples
     of MATLAB doubles (oracle/capture_golden.py configs0; 16.7 s there).  The same container -- regenerated from its
     seeds, SHA-256 checked -- through this package's run_extraction: same files, same keys, every one of the 6 000 rows
-    within the parity bounds of the reference's stored float32."""
+    within the parity bounds of the reference's stored float32.  configs2_reference_run.npz: the same at BASELINE
+    configs[2]'s frame size, 6 x 2 x 50 x 4096."""
     import hashlib
     import scipy.io
     from amcpy_amd import synth
     from amcpy_amd.config import Config, Paths, SignalConfig
     from amcpy_amd.feature_extraction import run_extraction
-    g = load_npz("configs0_reference_run.npz")
+    g = load_npz(fixture)
     n_snr, n_frames, fs = int(g["n_snr"]), int(g["n_frames"]), int(g["frame_size"])
     blocks = synth.host_frames(synth.MODS6, n_snr, n_frames, fs)
     for m in synth.MODS6:

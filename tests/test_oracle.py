@@ -171,14 +171,15 @@ def test_oracle_at_the_ends_of_float32_matches_reference(N):
     assert np.array_equal(got, gold[0], equal_nan=True)
 
 
-def test_oracle_matches_the_references_run_of_baseline_configs0():
+@pytest.mark.parametrize("fixture", ["configs0_reference_run.npz", "configs2_reference_run.npz"])
+def test_oracle_matches_the_references_run_of_baseline_configs0(fixture):
     """configs0_reference_run.npz: BASELINE configs[0] (6 modulations x 2 SNR x 500 frames x 2048 samples, a container of
     MATLAB doubles) through the REFERENCE's own run_extraction (feature_extraction.py:85-99; 16.7 s on this container's
     eight cores).  The inputs are regenerated from their seeds (SHA-256 checked); the oracle reproduces all 6 000 rows
-    the reference stored."""
+    the reference stored.  configs2_reference_run.npz: the same at BASELINE configs[2]'s frame size (6 x 2 x 50 x 4096)."""
     import hashlib
     from amcpy_amd import synth
-    g = load_npz("configs0_reference_run.npz")
+    g = load_npz(fixture)
     n_snr, n_frames, fs = int(g["n_snr"]), int(g["n_frames"]), int(g["frame_size"])
     blocks = synth.host_frames(synth.MODS6, n_snr, n_frames, fs)
     for m in synth.MODS6:
