@@ -29,6 +29,7 @@ Fixtures:
   configs0_reference_run.npz BASELINE configs[0] (6 x 2 x 500 x 2048) through the reference's run_extraction: its outputs
                           and the SHA-256 of the seeded inputs (python oracle/capture_golden.py configs0)
   configs2_reference_run.npz the same at BASELINE configs[2]'s frame size: 6 x 2 x 50 x 4096
+  configs4_reference_run.npz ... and at configs[4]'s (RadioML-2018 scale): 6 x 2 x 100 x 1024
   config_defaults.json    field names and defaults of the reference's config layer
 """
 
@@ -357,7 +358,8 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "configs0":
         capture_configs0(rfe, rcfg)
         capture_configs0(rfe, rcfg, n_frames=50, fs=4096, name="configs2_reference_run.npz")
-        for name in ("configs0_reference_run.npz", "configs2_reference_run.npz"):
+        capture_configs0(rfe, rcfg, n_frames=100, fs=1024, name="configs4_reference_run.npz")
+        for name in ("configs0_reference_run.npz", "configs2_reference_run.npz", "configs4_reference_run.npz"):
             print(f"{name:28s} {(OUT / name).stat().st_size:9d} B")
         return
     if len(sys.argv) > 2 and sys.argv[1] == "edges":
@@ -389,6 +391,7 @@ def main():
     capture_roundtrip_f64(rfe, rcfg)
     capture_configs0(rfe, rcfg)
     capture_configs0(rfe, rcfg, n_frames=50, fs=4096, name="configs2_reference_run.npz")
+    capture_configs0(rfe, rcfg, n_frames=100, fs=1024, name="configs4_reference_run.npz")
     capture_config_defaults(rcfg)
     for p in sorted(OUT.iterdir()):
         print(f"{p.name:28s} {p.stat().st_size:9d} B")

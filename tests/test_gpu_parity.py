@@ -801,7 +801,7 @@ def test_run_extraction_on_a_container_of_genuine_doubles(tmp_path):
 CLI_UNFLOORED_EXCEPTIONS = {"WGN": [106]}
 
 
-@pytest.mark.parametrize("fixture", ["configs0_reference_run.npz", "configs2_reference_run.npz"])
+@pytest.mark.parametrize("fixture", ["configs0_reference_run.npz", "configs2_reference_run.npz", "configs4_reference_run.npz"])
 def test_run_extraction_against_the_references_own_run_of_configs0(tmp_path, fixture):
     """BASELINE configs[0] end to end against the REFERENCE ITSELF: tests/golden/configs0_reference_run.npz holds what the
     reference's run_extraction (feature_extraction.py:85-99) wrote for 6 modulations x 2 SNR x 500 frames x 2048 samples

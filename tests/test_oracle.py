@@ -171,7 +171,7 @@ def test_oracle_at_the_ends_of_float32_matches_reference(N):
     assert np.array_equal(got, gold[0], equal_nan=True)
 
 
-@pytest.mark.parametrize("fixture", ["configs0_reference_run.npz", "configs2_reference_run.npz"])
+@pytest.mark.parametrize("fixture", ["configs0_reference_run.npz", "configs2_reference_run.npz", "configs4_reference_run.npz"])
 def test_oracle_matches_the_references_run_of_baseline_configs0(fixture):
     """configs0_reference_run.npz: BASELINE configs[0] (6 modulations x 2 SNR x 500 frames x 2048 samples, a container of
     MATLAB doubles) through the REFERENCE's own run_extraction (feature_extraction.py:85-99; 16.7 s on this container's
