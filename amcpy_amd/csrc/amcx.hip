@@ -12,12 +12,6 @@
 #include "amcx_block_kernel.h"
 #include "amcx_wave_kernel.h"
 #include "amcx_quad_kernel.h"
-#ifdef AMCX_EXP_PAIR4096      // experiment: two waves per frame at N = 4096 (measured 1.7 % slower: profiles/r4_pair_vs_wave4096_ab.txt)
-#include "amcx_pair_kernel.h"
-#endif
-#ifdef AMCX_EXP_PAIR4096      // the pair experiment still marks out-of-range frames for a second launch
-#include "amcx_fixup_kernel.h"
-#endif
 #include "amcx_post_kernels.h"
 #include "amcx_pack_kernel.h"
 #include "amcx_upload.h"
@@ -200,22 +194,12 @@ int amcx_features18_c64_ex(const void* iq_dev, int64_t n_frames, int32_t frame_s
     hipError_t e;
     if (frame_size == amcx::quad::kN)
       e = amcx::quad::launch_quad(iq, n_frames, row_stride_elems, out_dev, out_row_stride, stream, cu_count());
-#ifdef AMCX_EXP_PAIR4096
-    else if (frame_size == amcx::pair::kN)
-      e = amcx::pair::launch_pair(iq, n_frames, row_stride_elems, out_dev, out_row_stride, stream, cu_count());
-#endif
     else
       e = amcx::launch_wave(iq, n_frames, frame_size, row_stride_elems, out_dev, out_row_stride, stream, cu_count());
     if (e != hipSuccess) return hip_fail(e, "wave kernel launch");
     // every throughput kernel (N = 128 ... 4096 one wave per frame, N = 8192 the quad) has re-run the frames outside its
     // fp32 sums' range itself -- one launch, rows final -- and finished frames with a phase step within an angle rounding
     // of +-pi in its finaliser.
-#ifdef AMCX_EXP_PAIR4096      // the pair experiment marks such frames in band (f5 = -inf) for the block kernel's fp64-sum routine
-    if (frame_size == amcx::pair::kN) {
-      e = amcx::launch_range_fixup(iq, n_frames, frame_size, row_stride_elems, out_dev, out_row_stride, stream, cu_count());
-      if (e != hipSuccess) return hip_fail(e, "range fix-up launch");
-    }
-#endif
     return AMCX_OK;
   }
   return launch_block(iq, n_frames, frame_size, row_stride_elems, out_dev, out_row_stride, stream);

@@ -37,11 +37,7 @@ constexpr float kTinyPower = 1.0e-37f;
 
 __device__ __forceinline__ float fast_angle(float re, float im, float a) {
   const float den = a + __builtin_fabsf(re);
-#ifdef AMCX_ABL_NORCP   // diagnostic upper bound (tools/wave_clock.hip): the quotient's v_rcp_f32 removed, results wrong on purpose
-  const float u = im * 0.37f + den * 1e-3f;
-#else
   const float u = im * __builtin_amdgcn_rcpf(den);
-#endif
   const float s = u * u;
   // 2*atan(u)/u, 8-term minimax on [0,1] (tools/fit_atan.py coefficients x 2)
   float q = -8.109134424e-03f;

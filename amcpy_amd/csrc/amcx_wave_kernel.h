@@ -1,6 +1,7 @@
 // AMCX_VARIANT_WAVE: one wavefront (64 lanes) per frame, frame held in registers.
 // Instantiated for the power-of-two frame sizes 128 ... 4096; N = 8192 runs four waves per frame on this header's
-// machinery (amcx_quad_kernel.h), and so does the two-wave experiment at N = 4096 (amcx_pair_kernel.h).
+// machinery (amcx_quad_kernel.h).  Experiments and ablations that were built against this header and not adopted
+// live in tools/experiments/ (patches against a named commit); nothing of them is compiled here.
 //
 // Why not "one 256-thread workgroup per frame": this path is bound by the board's power cap
 // and by VALU issue, not by HBM (~105 fp32 VALU instructions per sample; DESIGN.md section
@@ -41,7 +42,7 @@
 // read came over the fabric -- FETCH_SIZE 2.0x the algorithmic bytes and 23 % of
 // wave-cycles waiting on it, profiles/r1d_n4096_summary.json.)
 // (Round 4 built the alternative -- two waves per frame at the N = 2048 kernel's 128 registers and 4 waves per SIMD,
-// the halves crossing through LDS: amcx_pair_kernel.h, -DAMCX_EXP_PAIR4096 -- and measured it 1.7 % SLOWER on the same
+// the halves crossing through LDS: tools/experiments/amcx_pair_kernel.h -- and measured it 1.7 % SLOWER on the same
 // box, profiles/r4_pair_vs_wave4096_ab.txt.  Rounds 1-3 also carried a one-wave N = 8192: two splits, the frame
 // streamed three times, 3.44x the algorithmic traffic, 75 spilled registers; the quad kernel replaced it in round 3
 // and the code was removed in round 4.)
@@ -54,7 +55,7 @@
 // end of the wave reduction, one 64-bit reload per batch of four: amcpy_amd/csrc/kernel_resources.json; the exchange buffer at its exact 8672 bytes and batches of four frames make
 // the LDS fit): 4.3 % fewer SIMD cycles per frame than with 12 waves, of which the power cap takes 2.5 % back
 // as clock -- +1.2 ... +1.9 % frames/s for the kernel alone, +0.5 % through the library's step (DESIGN.md section 4.1;
-// -DAMCX_EXP_WAVES12 builds the 12-wave form).
+// tools/experiments/r5_lab_branches.patch holds the 12-wave form).
 // (Two 6-wave workgroups did NOT co-reside at the 160 VGPRs of round 1a: their waves
 // landed 2,2,1,1 on the SIMDs, profiles/r1a.)  LDS per workgroup at N = 2048:
 // factor tables 1920 + 14336 B, 16 x 8672 B exchange, 16 x 528 B stash = 159.6 KB.
@@ -77,7 +78,7 @@
 // The level does not matter (1, 2, 3: +6.0 / +5.9 / +5.7 % at N = 2048), the extent does: sweep only +-0; sweep + envelope
 // +1.1 %; sweep + envelope + reduction +6.0 % (this); + FFT pass 1 +4.3 %; the reduction alone +0.6 %; + the finaliser: no
 // change.  (The opposite choice -- priority for the FFT -- costs 2.9 %, a static priority for half of the waves 3.2 %.)
-// Different levels per section (AMCX_PRIO_LEVELS): reduction above envelope above sweep +0.2 ... +0.5 % (noise level), the
+// Different levels per section (a variant kept in tools/experiments/r5_lab_branches.patch): reduction above envelope above sweep +0.2 ... +0.5 % (noise level), the
 // sweep above the others -2.7 %.
 // Which sections of a frame run at s_setprio 1: bit 0 statistics sweep, 1 envelope sweep, 2 wave reduction, 3 FFT pass 1,
 // 4 FFT passes 2-3, 5 the batch finaliser; N = 4096 only: 6 the radix-2 split stage in front of the two FFTs, 7 pass 1 of
@@ -86,11 +87,7 @@
 #ifndef AMCX_PRIO_MASK
 #define AMCX_PRIO_MASK 7
 #endif
-#ifdef AMCX_PRIO_LEVELS   // experiment: a level 0-3 per section, one hex digit each, section 0 in the lowest
-#define AMCX_PRIO_OF(b) ((AMCX_PRIO_LEVELS >> (4 * (b))) & 3)
-#else
 #define AMCX_PRIO_OF(b) ((AMCX_PRIO_MASK >> (b)) & 1)
-#endif
 
 namespace amcx {
 namespace wave {
@@ -113,11 +110,7 @@ struct Cfg {
   // frames per wave per batch, finalised together one frame per lane: the fp64 algebra costs
   // the same per batch whatever N is, so short frames come in larger batches
   // (N = 2048 runs 16 waves per CU, below: batches of four are what its LDS then holds)
-#ifdef AMCX_EXP_WAVES12   // the 12-wave configuration of rounds 1-3 at N = 2048, for A/B runs (tools/wave_clock.hip)
-  static constexpr int kFramesPerWave = N >= 1024 ? 8 : (N == 512 ? 16 : 32);
-#else
   static constexpr int kFramesPerWave = N == 2048 ? 4 : N >= 1024 ? 8 : (N == 512 ? 16 : 32);
-#endif
   // how many times per frame the per-lane fp32 sums are reduced into the stash and started
   // afresh (the finaliser adds the rows in fp64): a lane that runs 64 samples into one accumulator
   // moves the worst scaled error of the N = 4096 sweep from 5.8e-6 to 6.9e-6
@@ -136,11 +129,7 @@ struct Cfg {
   // through the library's step in round 3 (profiles/r3_waves16_ab.txt), +2.5 % under wave priority
   // (profiles/r4_wave_priority_ab.txt, section 7).  N = 1024 (round 4): 16 waves AND no second register set, +2.9 %
   // same box through the library (section 8); 16 waves with the prefetch kept spill 37 registers, -2.2 %.
-#if defined(AMCX_EXP_WAVES12)
-  static constexpr int kWavesPerWG = kSplit ? 8 : 12;
-#else
   static constexpr int kWavesPerWG = kSplit ? 8 : (N == 2048 || N == 1024 ? 16 : 12);
-#endif
   // next frame of the chunk loaded into a second register set while this one is processed: the short frames, whose
   // load latency is a large share of the frame -- unless four waves share the SIMD and cover it for each other
   // (at N = 1024 with 12 waves the second set buys nothing any more under wave priority: -0.1 %)
@@ -269,107 +258,6 @@ __device__ __forceinline__ void dif_stage(float (&re)[R], float (&im)[R]) {
 }
 
 
-// ---- EXPERIMENT (-DAMCX_EXP_PK_FFT, _PK_PASS1_ONLY, _PK_TAIL_ONLY; the product build uses none of it) -----------
-// The same butterflies on (re, im) register PAIRS with packed fp32 instructions.  v_pk_add / v_pk_mul /
-// v_pk_fma_f32 work on an aligned VGPR pair per operand and choose, per operand and per result half, which
-// half of the pair feeds it (op_sel / op_sel_hi) and whether it is negated (neg_lo / neg_hi): a complex value
-// kept as one pair needs no shuffles, a + b and a - b are one instruction, multiplication by -i or by a twiddle
-// folds into the operand selectors, and the 6-FMA butterfly of twisted_dit is three v_pk_fma_f32.  Every half is
-// rounded exactly as in the scalar form (same operations, same order): the builds give bit-identical features.
-// In isolation the packed 16-point pass takes 24 % fewer SIMD cycles (tools/ubench_fft.hip: 328 against 433 at
-// three waves per SIMD) and a packed FMA stream does 17 % more flops under the power cap than a scalar one
-// (profiles/r1_valu_issue_rates.txt).  IN the kernel it loses: 503 VALU instructions fewer per frame, the clock
-// 3 % higher (less energy per frame, as predicted) -- and 470 SIMD cycles per frame MORE (10 590 against 10 120;
-// pass 1 alone +528, passes 2-3 alone +937), i.e. -2.5 % frames/s, however the butterflies are ordered
-// (profiles/r3_pk_fft_ab.txt).  The kernel is not issue-bound (66 % of the VALU slots): a wave in its FFT shares
-// the SIMD with two waves in their statistics sweeps, and there a packed instruction costs the wave ~12 cycles
-// where the microbenchmark's three packed waves pay 8.8.  Kept for the record and for other silicon.
-// The compiler folds whole-pair swaps and negations into the modifiers by itself; the forms that negate
-// ONE half are spelled as inline assembly.
-typedef float v2 __attribute__((ext_vector_type(2)));
-#if defined(AMCX_EXP_PK_FFT)
-constexpr bool kPkPass1 = true, kPkTail = true;
-#elif defined(AMCX_EXP_PK_PASS1_ONLY)
-constexpr bool kPkPass1 = true, kPkTail = false;
-#elif defined(AMCX_EXP_PK_TAIL_ONLY)
-constexpr bool kPkPass1 = false, kPkTail = true;
-#else
-constexpr bool kPkPass1 = false, kPkTail = false;       // the product: scalar butterflies (see above)
-#endif
-
-__device__ __forceinline__ v2 pk_fma(v2 a, v2 b, v2 c) { return __builtin_elementwise_fma(a, b, c); }
-
-// y + t.y * (-b.y, b.x): the second half of y = a + t b
-__device__ __forceinline__ v2 pk_fma_rot(v2 b, v2 t, v2 y) {
-  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "+v"(y) : "v"(b), "v"(t));
-  return y;
-}
-// (a, b) <- (a + t b, a - t b): bfly6 in three packed FMAs
-__device__ __forceinline__ void bfly6_pk(v2& a, v2& b, const v2 t) {
-  const v2 y = pk_fma_rot(b, t, pk_fma(b, t.xx, a));
-  b = pk_fma(a, (v2){2.0f, 2.0f}, -y);
-  a = y;
-}
-// (a - b) * (-i) = (a.y - b.y, b.x - a.x)
-__device__ __forceinline__ v2 pk_sub_mul_mi(v2 a, v2 b) {
-  v2 r;
-  asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-// (z.x + z.y, z.y - z.x) = z * (1 - i)
-__device__ __forceinline__ v2 pk_mul_1mi(v2 z) {
-  v2 r;
-  asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(z));
-  return r;
-}
-// (z.y - z.x, -z.x - z.y) = z * (-1 - i)
-__device__ __forceinline__ v2 pk_mul_m1mi(v2 z) {
-  v2 r;
-  asm("v_pk_add_f32 %0, %1, %1 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[1,1]" : "=v"(r) : "v"(z));
-  return r;
-}
-// (z.y * k.y, -(z.x * k.y)): the inner products of z * (k.x - i k.y), k = (cos, sin) in an SGPR pair
-__device__ __forceinline__ v2 pk_cross(v2 z, v2 k) {
-  v2 r;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[1,0]" : "=v"(r) : "v"(z), "s"(k));
-  return r;
-}
-// (a - b) * W_32^J, every half rounded as dr = ar - br ... mul_w32<J>(dr, di) rounds it
-template <int J>
-__device__ __forceinline__ v2 pk_sub_mul_w32(v2 a, v2 b) {
-  constexpr float h = 0.70710678118654752f;
-  if constexpr (J == 0) {
-    return a - b;
-  } else if constexpr (J == 8) {
-    return pk_sub_mul_mi(a, b);
-  } else if constexpr (J == 4) {
-    return pk_mul_1mi(a - b) * (v2){h, h};
-  } else if constexpr (J == 12) {
-    return pk_mul_m1mi(a - b) * (v2){h, h};
-  } else {
-    const v2 d = a - b, k = {kC32[J], kS32[J]};
-    return pk_fma(d, k.xx, pk_cross(d, k));
-  }
-}
-template <int LEN, int OFF, int R>
-__device__ __forceinline__ void dif_stage_pk(v2 (&x)[R]) {
-  constexpr int H = LEN / 2;
-  static_for<H>([&](auto jj) {
-    constexpr int j = decltype(jj)::value;
-    const v2 a = x[OFF + j], b = x[OFF + j + H];
-    x[OFF + j] = a + b;
-    x[OFF + j + H] = pk_sub_mul_w32<j * (32 / LEN)>(a, b);
-  });
-}
-template <int LEN, int OFF, int R>
-__device__ __forceinline__ void dif_pk(v2 (&x)[R]) {
-  if constexpr (LEN >= 2) {
-    dif_stage_pk<LEN, OFF, R>(x);
-    dif_pk<LEN / 2, OFF, R>(x);
-    dif_pk<LEN / 2, OFF + LEN / 2, R>(x);
-  }
-}
-
 // ---- DPP helpers -------------------------------------------------------------
 template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf, bool BOUND = true>
 __device__ __forceinline__ float dpp(float v) {
@@ -485,11 +373,7 @@ struct Stats {
       sAAP = __builtin_fmaf(AA, P, sAAP);
       sX4P = __builtin_fmaf(X4, P, sX4P);
       sABP = __builtin_fmaf(AP, Bh, sABP);
-#ifdef AMCX_ABL_NOSQRT   // diagnostic upper bound (tools/wave_clock.hip): the envelope's v_sqrt_f32 removed, results wrong on purpose
-      av[b] = __builtin_fmaf(P, 0.61f, 0.2f);
-#else
       av[b] = __builtin_amdgcn_sqrtf(P);
-#endif
       sa += av[b];
       th[b] = fast_angle(re, im, av[b]);
     });
@@ -595,86 +479,6 @@ __device__ __forceinline__ void twisted_dit(float (&re)[LEN], float (&im)[LEN], 
   });
 }
 
-// A stage's LEN/2 butterflies are issued as three sweeps -- first FMA of all, second FMA of all, third of all --
-// with the scheduler fenced in between: a packed FMA's result is needed LEN/2 instructions later, not two (left to
-// itself the scheduler puts the three FMAs of a butterfly two apart, and the packed passes ran at 5.4 cycles
-// per instruction per SIMD instead of the 3.1 the instruction issues at).  The factors of the next stage are read
-// from LDS before the third sweep of this one.
-template <int LEN, class TW>
-__device__ __forceinline__ void twisted_dit_pk(v2 (&x)[LEN], TW&& tw) {
-  constexpr int LOG = LEN == 16 ? 4 : 3;
-  constexpr int NB = LEN / 2;
-  static_assert(LEN == 16 || LEN == 8, "pass lengths");
-  v2 t[NB], tn[NB];
-  t[0] = tw(std::integral_constant<int, 0>{});
-  static_for<LOG>([&](auto ss) {
-    constexpr int sidx = decltype(ss)::value;
-    constexpr int half = 1 << sidx;             // factors in this stage
-    constexpr int d = LEN / (2 * half);         // distance between the two inputs; butterfly (k, m): factor k
-    v2 y[NB];
-    static_for<NB>([&](auto bb) {
-      constexpr int k = decltype(bb)::value / d, m = decltype(bb)::value % d;
-      constexpr int p = m + 2 * d * bitrev(k, sidx);
-      y[decltype(bb)::value] = pk_fma(x[p + d], t[k].xx, x[p]);
-    });
-    __builtin_amdgcn_sched_barrier(0);
-    static_for<NB>([&](auto bb) {
-      constexpr int k = decltype(bb)::value / d, m = decltype(bb)::value % d;
-      constexpr int p = m + 2 * d * bitrev(k, sidx);
-      y[decltype(bb)::value] = pk_fma_rot(x[p + d], t[k], y[decltype(bb)::value]);
-    });
-    if constexpr (sidx + 1 < LOG)
-      static_for<2 * half>([&](auto kk) {
-        tn[decltype(kk)::value] = tw(std::integral_constant<int, 2 * half - 1 + decltype(kk)::value>{});
-      });
-    __builtin_amdgcn_sched_barrier(0);
-    static_for<NB>([&](auto bb) {
-      constexpr int k = decltype(bb)::value / d, m = decltype(bb)::value % d;
-      constexpr int p = m + 2 * d * bitrev(k, sidx);
-      x[p + d] = pk_fma(x[p], (v2){2.0f, 2.0f}, -y[decltype(bb)::value]);
-      x[p] = y[decltype(bb)::value];
-    });
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (sidx + 1 < LOG)
-      static_for<2 * half>([&](auto kk) { t[decltype(kk)::value] = tn[decltype(kk)::value]; });
-  });
-}
-
-// passes 2 and 3 behind exchange 1 (shared by fft_peak and fft_back): reads the lane's 16 pass-2 inputs, returns
-// the lane's max |X|^2; TW2 / TW3 give factor i of pass 2 / of pass 3's half j
-template <class TW2, class TW3>
-__device__ __forceinline__ float fft_tail_pk(const LaneAddr& la, float peak, TW2&& tw2, TW3&& tw3, bool mark) {
-  v2 z[16];
-  static_for<16>([&](auto nn) {
-    constexpr int n2 = decltype(nn)::value;
-    z[n2] = *reinterpret_cast<const v2*>(la.ex1_r + n2 * 32);
-  });
-  if (mark) asm volatile("; MARK fft2");
-  __builtin_amdgcn_sched_barrier(0);
-  twisted_dit_pk<16>(z, tw2);
-  lds_wave_fence();
-  static_for<16>([&](auto kk2) {
-    constexpr int k2 = decltype(kk2)::value;
-    *reinterpret_cast<v2*>(la.ex2_w + (k2 * kEx2StrideK2) * 8) = z[bitrev(k2, 4)];
-  });
-  lds_wave_fence();
-  static_for<2>([&](auto jj) {
-    constexpr int j = decltype(jj)::value;
-    v2 u[8];
-    static_for<8>([&](auto nn) {
-      constexpr int n3 = decltype(nn)::value;
-      u[n3] = *reinterpret_cast<const v2*>(la.ex2_r + (j * 8 * kEx2StrideK2 + n3) * 8);
-    });
-    twisted_dit_pk<8>(u, [&](auto ii) { return tw3(jj, ii); });
-    static_for<4>([&](auto pp) {
-      constexpr int p = 2 * decltype(pp)::value;
-      peak = __builtin_fmaxf(__builtin_fmaxf(peak, __builtin_fmaf(u[p].x, u[p].x, u[p].y * u[p].y)),
-                             __builtin_fmaf(u[p + 1].x, u[p + 1].x, u[p + 1].y * u[p + 1].y));   // v_max3
-    });
-  });
-  return peak;
-}
-
 // Register FFT of 128*R points held as xr/xi[2*i+b] (see header); returns this
 // lane's max |X|^2 over the 2R bins it ends up with.
 template <int R>
@@ -689,159 +493,28 @@ __device__ __forceinline__ float fft_peak(const float (&xr)[2 * R], const float 
   // pass 2, exchange 2 and pass 3 -- 32 registers fewer in flight than with both phases' pass-2
   // inputs read before either is processed.
   float v0r[R], v0i[R], v1r[R], v1i[R];
-  v2 v0[R], v1[R];
-  if constexpr (kPkPass1) {
-    static_for<R>([&](auto ii) {
-      constexpr int i = decltype(ii)::value;
-      v0[i] = (v2){xr[2 * i], xi[2 * i]}; v1[i] = (v2){xr[2 * i + 1], xi[2 * i + 1]};
-    });
-    if constexpr (PH == 2) {
-      dif_stage_pk<R, 0>(v0);
-      dif_stage_pk<R, 0>(v1);
-    }
-  } else {
-    static_for<R>([&](auto ii) {
-      constexpr int i = decltype(ii)::value;
-      v0r[i] = xr[2 * i]; v0i[i] = xi[2 * i]; v1r[i] = xr[2 * i + 1]; v1i[i] = xi[2 * i + 1];
-    });
-    if constexpr (PH == 2) {
-      dif_stage<R, 0>(v0r, v0i);
-      dif_stage<R, 0>(v1r, v1i);
-    }
+  static_for<R>([&](auto ii) {
+    constexpr int i = decltype(ii)::value;
+    v0r[i] = xr[2 * i]; v0i[i] = xi[2 * i]; v1r[i] = xr[2 * i + 1]; v1i[i] = xi[2 * i + 1];
+  });
+  if constexpr (PH == 2) {
+    dif_stage<R, 0>(v0r, v0i);
+    dif_stage<R, 0>(v1r, v1i);
   }
   float peak = 0.f;
-#if defined(AMCX_ABL_FFT_TAIL) || defined(AMCX_ABL_FFT_TAIL_MFMA)
-  // DIAGNOSTIC builds (tools/wave_clock.hip; results wrong on purpose) for the round-4 question "can passes 2-3 be
-  // replaced by something cheaper that nominates candidate bins?" (tools/coarse_spectrum_model.py):
-  //   AMCX_ABL_FFT_TAIL       pass 1 as it is, passes 2-3 and both exchanges REMOVED (|.|^2 and the maximum kept): the
-  //                           upper bound of any scheme that keeps pass 1 exact;
-  //   AMCX_ABL_FFT_TAIL_MFMA  ... and in their place the instruction mix of the one variant whose candidate count
-  //                           survives a proven error bound: inter-pass twiddles in fp32 (2 x 32 complex products per
-  //                           lane), 2 x 32 conversions to packed fp16, both exchanges through LDS at half width, the
-  //                           matrix operands read back, 8 v_mfma_f32_32x32x16_f16 (pass 2) + 16 v_mfma_f32_16x16x16_f16
-  //                           (pass 3) on those operands, |.|^2 and maximum, a candidate scan and two exact
-  //                           candidate evaluations from the pass-1 output (2 complex multiply-adds + a wave sum each).
   static_for<PH>([&](auto gg) {
     constexpr int gph = decltype(gg)::value;
     dif<8, 8 * gph>(v0r, v0i);
     dif<8, 8 * gph>(v1r, v1i);
-  });
-#if defined(AMCX_ABL_FFT_TAIL_MFMA)
-  {
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    typedef float f16v __attribute__((ext_vector_type(16)));
-    const char* const tw = la.tw3;                       // any per-lane table: 16 x ds_read_b128 of "twiddles" per glue stage
-    h2 zs[32];
-    // glue 1: T1 (fp32 complex products) + conversion
-    static_for<16>([&](auto ii) {
-      constexpr int i = decltype(ii)::value;
-      const float4 t = *reinterpret_cast<const float4*>(tw + (i % 14) * kTw3Row);
-      const float ar = __builtin_fmaf(v0r[i], t.x, -(v0i[i] * t.y)), ai = __builtin_fmaf(v0r[i], t.y, v0i[i] * t.x);
-      const float br = __builtin_fmaf(v1r[i], t.z, -(v1i[i] * t.w)), bi = __builtin_fmaf(v1r[i], t.w, v1i[i] * t.z);
-      zs[2 * i] = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(ar, ai));
-      zs[2 * i + 1] = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(br, bi));
-    });
-    lds_wave_fence();
-    static_for<16>([&](auto ii) {                        // exchange 1 at half width: 16 x ds_write_b64
-      constexpr int i = decltype(ii)::value;
-      *reinterpret_cast<float2*>(la.ex1_w + i * 512) = make_float2(__builtin_bit_cast(float, zs[2 * i]), __builtin_bit_cast(float, zs[2 * i + 1]));
-    });
-    lds_wave_fence();
-    // pass 2: [32 x 32] DFT-16 matrix (two K halves, resident) times 4 column blocks: 8 MFMAs, operands 8 x ds_read_b128
-    const h8 a_lo = *reinterpret_cast<const h8*>(tw), a_hi = *reinterpret_cast<const h8*>(tw + kTw3Row);
-    h2 us[32];
-    static_for<4>([&](auto cc) {
-      constexpr int c = decltype(cc)::value;
-      const h8 b0 = *reinterpret_cast<const h8*>(la.ex1_w + c * 2048), b1 = *reinterpret_cast<const h8*>(la.ex1_w + c * 2048 + 1024);
-      f16v d = {};
-      d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b0, d, 0, 0, 0);
-      d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b1, d, 0, 0, 0);
-      // glue 2: T2 on the block's 8 complex results + conversion
-      const float4 t0 = *reinterpret_cast<const float4*>(tw + (2 * c) * kTw3Row), t1 = *reinterpret_cast<const float4*>(tw + (2 * c + 1) * kTw3Row);
-      static_for<8>([&](auto jj) {
-        constexpr int j = decltype(jj)::value;
-        const float tr = (j & 1) ? t0.x : t1.z, ti = (j & 2) ? t0.y : t1.w;
-        const float ur = __builtin_fmaf(d[j], tr, -(d[j + 8] * ti)), ui = __builtin_fmaf(d[j], ti, d[j + 8] * tr);
-        us[8 * c + j] = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(ur, ui));
-      });
-    });
-    lds_wave_fence();
-    static_for<16>([&](auto ii) {                        // exchange 2 at half width
-      constexpr int i = decltype(ii)::value;
-      *reinterpret_cast<float2*>(la.ex2_w + i * 512) = make_float2(__builtin_bit_cast(float, us[2 * i]), __builtin_bit_cast(float, us[2 * i + 1]));
-    });
-    lds_wave_fence();
-    // pass 3: [16 x 16] DFT-8 matrix times 16 column blocks: 16 MFMAs, operands 16 x ds_read_b64; |.|^2 and maximum
-    const h4 a8 = *reinterpret_cast<const h4*>(tw + 2 * kTw3Row);
-    float mag[32];
-    static_for<16>([&](auto cc) {
-      constexpr int c = decltype(cc)::value;
-      const h4 b = *reinterpret_cast<const h4*>(la.ex2_w + c * 512);
-      f4 d = {};
-      d = __builtin_amdgcn_mfma_f32_16x16x16f16(a8, b, d, 0, 0, 0);
-      mag[2 * c] = __builtin_fmaf(d[0], d[0], d[1] * d[1]);
-      mag[2 * c + 1] = __builtin_fmaf(d[2], d[2], d[3] * d[3]);
-      peak = __builtin_fmaxf(__builtin_fmaxf(peak, mag[2 * c]), mag[2 * c + 1]);
-    });
-    // candidate scan: the wave maximum, a threshold, 32 comparisons; then two exact candidates from the pass-1 output
-    const float thr = bcast_l63(wave_max_l63(peak)) * 0.96f;
-    unsigned long long any = 0;
-    static_for<32>([&](auto ee) { any |= __builtin_amdgcn_ballot_w64(mag[decltype(ee)::value] >= thr); });
-    static_for<2>([&](auto cc) {
-      constexpr int c = decltype(cc)::value;
-      const float4 t = *reinterpret_cast<const float4*>(tw + (((int)(any >> (8 * c)) & 7) + c) * kTw3Row);
-      float sr = __builtin_fmaf(v0r[c], t.x, -(v0i[c] * t.y)), si = __builtin_fmaf(v0r[c], t.y, v0i[c] * t.x);
-      sr = __builtin_fmaf(v1r[c], t.z, __builtin_fmaf(-v1i[c], t.w, sr));
-      si = __builtin_fmaf(v1r[c], t.w, __builtin_fmaf(v1i[c], t.z, si));
-      sr = wave_sum_l63(sr); si = wave_sum_l63(si);
-      peak = __builtin_fmaxf(peak, __builtin_fmaf(sr, sr, si * si));
-    });
-  }
-#else
-  static_for<R>([&](auto ii) {
-    constexpr int i = decltype(ii)::value;
-    peak = __builtin_fmaxf(__builtin_fmaxf(peak, __builtin_fmaf(v0r[i], v0r[i], v0i[i] * v0i[i])),
-                           __builtin_fmaf(v1r[i], v1r[i], v1i[i] * v1i[i]));
-  });
-#endif
-  lds_wave_fence();
-  return peak;
-#endif
-  static_for<PH>([&](auto gg) {
-    constexpr int gph = decltype(gg)::value;
-    if constexpr (kPkPass1) {
-      dif_pk<8, 8 * gph>(v0);
-      dif_pk<8, 8 * gph>(v1);
-    } else {
-      dif<8, 8 * gph>(v0r, v0i);
-      dif<8, 8 * gph>(v1r, v1i);
-    }
     float zr[16], zi[16];
     lds_wave_fence();
     static_for<8>([&](auto kk_) {
       constexpr int kk = decltype(kk_)::value;
       constexpr int p = 8 * gph + bitrev(kk, 3);        // R = 16: k1 = 2 kk + gph; R = 8: k1 = kk
-      if constexpr (kPkPass1) {
-        *reinterpret_cast<v2*>(la.ex1_w + (kk * kEx1StrideKK) * 8) = v0[p];
-        *reinterpret_cast<v2*>(la.ex1_w + (kk * kEx1StrideKK + kEx1StrideB) * 8) = v1[p];
-      } else {
-        *reinterpret_cast<float2*>(la.ex1_w + (kk * kEx1StrideKK) * 8) = make_float2(v0r[p], v0i[p]);
-        *reinterpret_cast<float2*>(la.ex1_w + (kk * kEx1StrideKK + kEx1StrideB) * 8) = make_float2(v1r[p], v1i[p]);
-      }
+      *reinterpret_cast<float2*>(la.ex1_w + (kk * kEx1StrideKK) * 8) = make_float2(v0r[p], v0i[p]);
+      *reinterpret_cast<float2*>(la.ex1_w + (kk * kEx1StrideKK + kEx1StrideB) * 8) = make_float2(v1r[p], v1i[p]);
     });
     lds_wave_fence();
-    if constexpr (kPkTail) {
-      const char* const tw2p = la.tw2;
-      const char* const tw3p = la.tw3;
-      peak = fft_tail_pk(la, peak,
-          [&](auto ii) { return *reinterpret_cast<const v2*>(tw2p + gph * 8 * kTw2Stride + decltype(ii)::value * 8); },
-          [&](auto jj, auto ii) {
-            return *reinterpret_cast<const v2*>(tw3p + ((gph * 2 + decltype(jj)::value) * 7 + decltype(ii)::value) * kTw3Row);
-          }, gph == 0);
-    } else {
     static_for<16>([&](auto nn) {
       constexpr int n2 = decltype(nn)::value;
       const float2 v = *reinterpret_cast<const float2*>(la.ex1_r + n2 * 32);
@@ -880,7 +553,6 @@ __device__ __forceinline__ float fft_peak(const float (&xr)[2 * R], const float 
                                __builtin_fmaf(ur[p + 1], ur[p + 1], ui[p + 1] * ui[p + 1]));   // v_max3
       });
     });
-    }
     if constexpr (gph + 1 < PH) __builtin_amdgcn_sched_barrier(0);   // the other half starts only now
   });
   lds_wave_fence();
@@ -965,7 +637,7 @@ __device__ __forceinline__ float fft_back(const LaneAddr& la) {
 //      stage s (L = 2^(s+1), d = 16 / L):  (W_(NF/8)^k1)^d W_L^k  =  W_NF^(8 k1 d + k NF / L)
 //   t3 [phase][j][7][lane]: pass 3 (8 points over n3; lane = (kk, k2 low), combination c = 2 g + j: k2 = (lane & 7) + 8 j):
 //      (W_NF^(R k2 + k1))^d W_L^k = W_NF^((R k2 + k1) d + k NF / L), L = 2^(s+1), d = 8 / L
-// Shared by the wave kernels, the pair kernel (N = 4096) and the quad kernel (N = 8192).
+// Shared by the wave kernels and the quad kernel (N = 8192).
 // ---------------------------------------------------------------------------
 template <int NF>
 __device__ __forceinline__ void build_fft_tables(char* t2, char* t3, int tid, int n_threads) {
@@ -1063,7 +735,6 @@ __device__ __forceinline__ void wave_body(
     const float2* __restrict__ iq, long long n_frames, long long row_stride,
     float* __restrict__ out, long long out_stride AMCX_STAMP_ARG) {
   using C = Cfg<N>;
-  constexpr bool kRedoHere = true;                       // every wave-kernel size (the quad kernel, N = 8192, has its own re-run pass)
   constexpr int R = C::kFftRows, ROWS = C::kHeldRows;
   constexpr int kWavesPerWG = C::kWavesPerWG, kThreads = C::kThreads, kTailFrames = C::kTailFrames;
   constexpr int kFramesPerWave = C::kFramesPerWave, kTailChunk = C::kTailChunk;
@@ -1132,19 +803,7 @@ __device__ __forceinline__ void wave_body(
       if (lane == 0) got = __hip_atomic_fetch_add(&counters[0], (unsigned)kFramesPerWave, __ATOMIC_RELAXED,
                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
       got = __builtin_amdgcn_readfirstlane(got);
-#ifdef AMCX_EXP_INTERLEAVE   // experiment (tools/wave_clock.hip): chunks dealt round-robin over the workgroups, so that
-      {                       // all waves of the chip read inside one moving window of HBM instead of 256 distant slices
-        const long long chunk = (long long)(got / kFramesPerWave) * gridDim.x + blockIdx.x;
-        f0 = chunk * kFramesPerWave;
-        if (f0 >= n_frames) break;
-        const long long left = n_frames - f0;
-        n_here = left < kFramesPerWave ? (int)left : kFramesPerWave;
-      }
-      if (true) {
-      } else if (false) {
-#else
       if ((long long)got < body_len) {
-#endif
         f0 = slice0 + got;
         const long long left = body_len - got;
         n_here = left < kFramesPerWave ? (int)left : kFramesPerWave;
@@ -1164,32 +823,11 @@ __device__ __forceinline__ void wave_body(
     // byte is read once -> non-temporal
     auto load_frame = [&](float (&xr)[2 * ROWS], float (&xi)[2 * ROWS], long long f) {
       const float2* src = iq + f * row_stride + 2 * lane;
-#ifdef AMCX_EXP_LOAD_POLICY   // experiment (tools/wave_clock.hip): another cache policy on the frame loads, e.g. "sc0 sc1"
-      if constexpr (ROWS == 16) {
-        typedef float v4f __attribute__((ext_vector_type(4)));
-        v4f v[ROWS];
-#pragma unroll
-        for (int i = 0; i < ROWS; ++i)
-          asm volatile("global_load_dwordx4 %0, %1, off " AMCX_EXP_LOAD_POLICY : "=v"(v[i]) : "v"(src + 128 * i));
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
-                       "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
-#pragma unroll
-        for (int i = 0; i < ROWS; ++i) {
-          xr[2 * i] = v[i].x; xi[2 * i] = v[i].y; xr[2 * i + 1] = v[i].z; xi[2 * i + 1] = v[i].w;
-        }
-        return;
-      }
-#endif
       static_for<ROWS>([&](auto ii) {
         constexpr int i = decltype(ii)::value;
         typedef float v4f __attribute__((ext_vector_type(4)));
         const v4f* p = reinterpret_cast<const v4f*>(src + 128 * i);
-#ifdef AMCX_EXP_PLAIN_LOADS   // experiment (tools/wave_clock.hip): default cache policy instead of nt
-        const v4f v = *p;
-#else
         const v4f v = __builtin_nontemporal_load(p);
-#endif
         xr[2 * i] = v.x; xi[2 * i] = v.y; xr[2 * i + 1] = v.z; xi[2 * i + 1] = v.w;
       });
     };
@@ -1197,11 +835,7 @@ __device__ __forceinline__ void wave_body(
     // (SLOT: for grouped short frames, which eighth of exchange 1 this frame's FFT front fills)
     auto frame = [&](const float (&xr)[2 * ROWS], const float (&xi)[2 * ROWS], int g, auto slot_tag) {
       constexpr int SLOT = decltype(slot_tag)::value;
-#ifdef AMCX_EXP_A_IN_REGS   // experiment: N = 2048 keeps |x| in 32 VGPRs instead of parking it in LDS
-      constexpr bool kAInRegs = C::kGroup > 1 || N == 2048;
-#else
       constexpr bool kAInRegs = C::kGroup > 1;   // |x| stays in registers: exchange 1 is shared by the group
-#endif
       asm volatile("; MARK load");
       __builtin_amdgcn_s_setprio(AMCX_PRIO_OF(0));
       AMCX_STAMP(7);
@@ -1256,11 +890,11 @@ __device__ __forceinline__ void wave_body(
         });
       };
       auto store_sums = [&](const float (&r7)[7], float* row) __attribute__((always_inline)) {
-        // (with TWO copies of this frame code in the kernel -- kRedoHere -- the compiler hoists the lane-derived offset
+        // (with TWO copies of this frame code in the kernel -- the batch loop's and rerun_scaled's -- the compiler hoists the lane-derived offset
         //  out of both, spills it in the prologue and reloads it here once per frame behind a wait: the lane index
         //  goes through an empty asm instead, so that the offset is formed where it is used)
         int ln = lane;
-        if constexpr (kRedoHere) asm volatile("" : "+v"(ln));
+        asm volatile("" : "+v"(ln));
         if ((ln & 15) == 0) {                      // one lane per row: rows hold 4j + {0, 2, 1, 3}
           const int rsel = ln >> 4;
           float* dst = row + (((rsel & 1) << 1) | (rsel >> 1));
@@ -1281,11 +915,7 @@ __device__ __forceinline__ void wave_body(
         static_for<ROWS>([&](auto ii) {
           constexpr int i = decltype(ii)::value;
           float a0, a1;
-#ifdef AMCX_ABL_NOSTATS   // diagnostic ablation (tools/wave_clock.hip): results are wrong on purpose
-          a0 = xr[2 * i]; a1 = xi[2 * i + 1];
-#else
           S.template row<i == 0, i == ROWS - 1>(xr[2 * i], xi[2 * i], xr[2 * i + 1], xi[2 * i + 1], lane, a0, a1);
-#endif
           if constexpr (kAInRegs) {
             av[2 * i] = a0;
             av[2 * i + 1] = a1;
@@ -1363,11 +993,7 @@ __device__ __forceinline__ void wave_body(
         fft_front<R, SLOT * R>(xr, xi, la);     // the group's shared back half follows the last frame
         return;
       } else if constexpr (!C::kSplit) {
-#ifdef AMCX_ABL_NOFFT     // diagnostic ablation (tools/wave_clock.hip)
-        peak = xr[0] + xi[2 * ROWS - 1];
-#else
         peak = fft_peak<R>(xr, xi, la);
-#endif
       } else {
         // 4096 points in registers: radix-2 DIF split, s = y[n] + y[n+2048],
         // d = (y[n] - y[n+2048]) * W_4096^n,  n = 128 i + 2 l + b,  W_4096^n = W_32^i * W_4096^(2l+b)
@@ -1414,7 +1040,7 @@ __device__ __forceinline__ void wave_body(
 
     // ---- batch finalisation: lane g turns the sums in stash row g into 18 features ----
     // range_tag true: the rows are those of frames re-run on a pre-scaled copy (rerun_scaled below).
-    // Returns the lanes whose frame is outside the fp32 sums' range and has NOT been stored (kRedoHere only).
+    // Returns the lanes whose frame is outside the fp32 sums' range and has NOT been stored.
     auto finalise = [&](auto range_tag, int count) -> unsigned long long {
       constexpr bool RG = decltype(range_tag)::value;
       bool redo = false;
@@ -1452,10 +1078,7 @@ __device__ __forceinline__ void wave_body(
           f = f0 + (code & 63);
         } else {
           finalize_features(F, N, feat);
-          if (is_outside_fp32_range(F, N)) {
-            if constexpr (kRedoHere) redo = true;                // re-run below, in this kernel; the row is not stored
-            else feat[4] = -__builtin_inff();                    // all 18 redone by amcx_range_fixup_kernel
-          }
+          if (is_outside_fp32_range(F, N)) redo = true;         // re-run below, in this kernel; the row is not stored
           f = f0 + lane;
         }
         // flagged by the sweep (f5 came back negated) and neither NaN nor on its way to a re-run
@@ -1463,9 +1086,6 @@ __device__ __forceinline__ void wave_body(
       }
       // frames with a phase step within an fp32 rounding of +-pi: f5 and f9 again, the wave on one frame at a time
       unsigned long long ties = __builtin_amdgcn_ballot_w64(tie);
-#ifdef AMCX_ABL_NOTIEFIX   // diagnostic (tools/wave_clock.hip): flagged frames keep their fp32 f5 / f9 (negated): what does the fix cost?
-      ties = 0;
-#endif
       while (ties != 0) {
         const int idx = __builtin_ctzll(ties);
         ties &= ties - 1;
@@ -1586,11 +1206,9 @@ __device__ __forceinline__ void wave_body(
     AMCX_STAMP(4);
     asm volatile("; MARK finalize");
     __builtin_amdgcn_s_setprio(AMCX_PRIO_OF(5));
-    [[maybe_unused]] const unsigned long long left_over = finalise(std::false_type{}, n_here);
-    if constexpr (kRedoHere) {
-      asm volatile("; MARK redo");
-      if (left_over != 0) rerun_scaled(left_over);            // frames outside the fp32 sums' range: never on ordinary data
-    }
+    const unsigned long long left_over = finalise(std::false_type{}, n_here);
+    asm volatile("; MARK redo");
+    if (left_over != 0) rerun_scaled(left_over);              // frames outside the fp32 sums' range: never on ordinary data
     AMCX_STAMP(5);
   }
 #ifdef AMCX_WAVE_STAMPS
@@ -1629,11 +1247,7 @@ inline const char* wave_kernel_name(int frame_size) {
     case 512: return "amcx_features18_wave_kernel<512>";
     case 1024: return "amcx_features18_wave_kernel<1024>";
     case 2048: return "amcx_features18_wave_kernel<2048>";
-#ifdef AMCX_EXP_PAIR4096
-    case 4096: return "amcx_features18_pair_kernel";
-#else
     case 4096: return "amcx_features18_wave_kernel<4096>";
-#endif
     case 8192: return "amcx_features18_quad_kernel";
     default: return "";
   }

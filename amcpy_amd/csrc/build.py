@@ -25,7 +25,11 @@ HEADERS = sorted(HERE.glob("*.h")) + [HERE.parents[1] / "include" / "amcx.h"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          "-ffp-contract=off", "-fno-math-errno", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function",
-         "-Wl,-rpath,/opt/rocm/lib", "-Wl,-soname,libamcx.so"]
+         "-Wl,-rpath,/opt/rocm/lib", "-Wl,-soname,libamcx.so",
+         # a fixed compilation-unit id: hipcc otherwise derives it from the paths on its command line (the temporary output name
+         # carries the pid), it ends up in the names of the internal-linkage kernels, and two builds of one tree differ in bytes.
+         # With it the library is reproducible byte for byte, which tools/codeobj_gate.py relies on.
+         "-cuid=amcx"]
 
 
 def stale() -> bool:

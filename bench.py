@@ -327,26 +327,6 @@ def h2d_path(dev, frame_size: int = FRAME_SIZE, big: bool = True):
     return rec
 
 
-def _valu_note_r1(frames_per_s: float):
-    """Secondary bound from the committed PMC summary: the kernel is VALU/power-bound
-    (DESIGN.md section 4.3), so report the issue rate next to the HBM fraction."""
-    for p in sorted((REPO / "profiles").glob("*final_summary.json"), reverse=True):
-        try:
-            d = json.loads(p.read_text())
-            for name, c in d["counters_mean_per_dispatch"].items():
-                if "wave_kernel<2048>" in name and "SQ_INSTS_VALU" in c:
-                    per_frame = c["SQ_INSTS_VALU"] / (6 * 26 * 4096)
-                    return {"bound": "valu-issue/power", "valu_instr_per_frame": per_frame,
-                            "achieved_Gwaveinstr_per_s": per_frame * frames_per_s / 1e9,
-                            "plain_fma_stream_Gwaveinstr_per_s": 890.0,
-                            "board_power": "1370 W of the 1400 W cap, sclk 2.0 of 2.4 GHz while this kernel "
-                                           "loops (profiles/r1e_power_watch.txt)",
-                            "source": f"profiles/{p.name}; profiles/r1_valu_issue_rates.txt (3 waves/SIMD)"}
-        except Exception:
-            continue
-    return None
-
-
 def _valu_note(frames_per_s: float):
     """Secondary bounds of the N = 2048 kernel from this round's committed budget
     (profiles/r2_wave_budget.json: in-kernel clock, issue slots, ablations -- DESIGN.md 4.3)."""
@@ -356,7 +336,7 @@ def _valu_note(frames_per_s: float):
         if b is not None:
             break
     if b is None:
-        return _valu_note_r1(frames_per_s)
+        return None
     per_frame = b.get("valu_instr_per_frame")
     out = {"bound": b.get("bound", "board power, then VALU issue"), "valu_instr_per_frame": per_frame,
            "source": f"profiles/{name} (committed; replayed, not measured in this run)"}
