@@ -4,7 +4,7 @@
     python amcpy_amd/csrc/build.py [--force] [--save-temps] [--output OTHER.so]
 
 The product library is always built from the sources alone.  An experiment build (AMCX_EXTRA_FLAGS, e.g.
--DAMCX_EXP_WAVES12 for a same-box A/B) goes to ANOTHER file -- `--output amcpy_amd/lib/libamcx_exp.so`, selected at
+-DAMCX_PRIO_MASK=3, or one of the laboratory's switches inside tools/experiments/lab) goes to ANOTHER file -- `--output amcpy_amd/lib/libamcx_exp.so`, selected at
 run time with AMCX_LIB=... -- and never replaces libamcx.so: extra flags without --output are refused.
 
 hipcc cross-compiles without a GPU.  The library links only the HIP runtime

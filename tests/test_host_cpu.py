@@ -1367,6 +1367,51 @@ def test_kernel_resources_match_the_committed_table():
     assert got["amcx_features18_wave_kernel<2048>"]["scratch"] <= 16          # one fp64 value in the per-batch finaliser
 
 
+def test_product_sources_carry_no_laboratory():
+    """Product and laboratory are separate: nothing under amcpy_amd/csrc or include/ mentions an experiment / ablation
+    switch (AMCX_EXP_* / AMCX_ABL_*), the experiment kernels live in tools/experiments/, and the patch that puts the
+    branches back (tools/experiments/r5_lab_branches.patch, tools/experiments/make_lab.sh) names the commit it is
+    against.  AMCX_WAVE_STAMPS (tools/wave_clock.hip, wave_stamps.hip) and AMCX_PRIO_MASK are the two kept knobs."""
+    import re
+    hits = []
+    for p in sorted((REPO / "amcpy_amd" / "csrc").iterdir()) + sorted((REPO / "include").iterdir()):
+        if p.suffix in (".h", ".hip", ".py"):
+            for i, line in enumerate(p.read_text().splitlines(), 1):
+                if re.search(r"AMCX_(EXP|ABL)_[A-Z0-9_]+|if \(true\)|if \(false\)", line) and p.name != "build.py":
+                    hits.append(f"{p.name}:{i}: {line.strip()[:100]}")
+    assert not hits, hits
+    assert not (REPO / "amcpy_amd" / "csrc" / "amcx_pair_kernel.h").exists()
+    assert not (REPO / "amcpy_amd" / "csrc" / "amcx_fixup_kernel.h").exists()
+    exp = REPO / "tools" / "experiments"
+    assert (exp / "amcx_pair_kernel.h").exists() and (exp / "amcx_fixup_kernel.h").exists()
+    patch = (exp / "r5_lab_branches.patch").read_text()
+    for flag in ("AMCX_EXP_WAVES12", "AMCX_EXP_PK_FFT", "AMCX_ABL_NOFFT", "AMCX_ABL_FFT_TAIL_MFMA", "AMCX_EXP_PAIR4096"):
+        assert flag in patch, flag
+    base = re.search(r"^LAB_BASE=(\w+)", (exp / "make_lab.sh").read_text(), re.M).group(1)
+    r = subprocess.run(["git", "-C", str(REPO), "cat-file", "-e", f"{base}^{{commit}}"], capture_output=True)
+    if (REPO / ".git").exists():                       # (the GPU box's snapshot has no history)
+        assert r.returncode == 0, f"make_lab.sh's base commit {base} is not in this history"
+
+
+def test_built_library_is_the_committed_gpu_program():
+    """amcpy_amd/csrc/codeobj.json holds the SHA-256 of the gfx950 code object (and of its .text) that the committed
+    sources build to; the build is reproducible (fixed -cuid, build.py), so the library in the tree -- the one that
+    travels to the GPU box -- is held to it.  After a deliberate kernel change: python tools/codeobj_gate.py --update.
+    (Round 5's removal of the experiment branches was held to the same gate: byte-identical before and after,
+    profiles/r5_codeobj_gate.txt.)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("codeobj_gate", REPO / "tools" / "codeobj_gate.py")
+    gate = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gate)
+    from amcpy_amd.csrc import build as b
+    lib = b.build(force=False, verbose=False)
+    got = gate.digests(lib)
+    want = __import__("json").loads((REPO / "amcpy_amd" / "csrc" / "codeobj.json").read_text())
+    assert got["text_sha256"] == want["text_sha256"], \
+        "the built kernels differ from amcpy_amd/csrc/codeobj.json (python tools/codeobj_gate.py --update after a deliberate change)"
+    assert got["code_object_sha256"] == want["code_object_sha256"]
+
+
 def test_run_extraction_resume_skips_complete_files(tmp_path):
     """``run_extraction(cfg, resume=True)`` / ``extract --resume``: the per-modulation output file is the path's
     resume unit.  A file that is complete for THIS configuration is skipped; a missing one, one
