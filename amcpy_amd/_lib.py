@@ -12,7 +12,7 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("AMCX_LIB", _HERE / "lib" / "libamcx.so"))
 
-ABI_VERSION = 3          # the version this binding was written against; any library >= it will do (include/amcx.h)
+ABI_VERSION = 4          # the version this binding was written against; any library >= it will do (include/amcx.h)
 NUM_FEATURES = 18
 VARIANT_AUTO, VARIANT_BLOCK, VARIANT_WAVE = 0, 1, 2
 VARIANTS = {"auto": VARIANT_AUTO, "block": VARIANT_BLOCK, "wave": VARIANT_WAVE}
@@ -26,6 +26,12 @@ class UploadStats(C.Structure):
                 ("chunks", C.c_int32), ("threads", C.c_int32), ("plane_major", C.c_int32), ("from_file", C.c_int32),
                 ("seconds", C.c_double), ("seconds_staging", C.c_double), ("seconds_waiting", C.c_double),
                 ("seconds_prepare", C.c_double), ("seconds_tail", C.c_double)]
+
+
+class Placement(C.Structure):
+    """amcx_placement (include/amcx.h)."""
+    _fields_ = [("device", C.c_int32), ("numa_node", C.c_int32), ("n_cpus", C.c_int32), ("n_cpus_allowed", C.c_int32),
+                ("first_cpu", C.c_int32), ("last_cpu", C.c_int32), ("pci_bus_id", C.c_char * 32)]
 
 
 # every symbol include/amcx.h declares: (restype, argtypes)
@@ -56,6 +62,11 @@ SIGNATURES = {
     "amcx_pack_planes_c64": (C.c_int, [_vp, _i32, _i32, _i64, _i64, _i64, _i32, _vp, _i64, _i32, _vp]),
     "amcx_kernel_name": (C.c_int, [_i32, _i32, C.c_char_p, _i32]),
     "amcx_probe_read_bw": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "amcx_probe_fma_rate": (C.c_int, [C.c_double, _vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "amcx_device_pci_bus_id": (C.c_int, [_i32, C.c_char_p, _i32]),
+    "amcx_numa_place": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(_i32), C.POINTER(_i32), _i32, C.POINTER(_i32)]),
+    "amcx_ctx_bind_cpus": (C.c_int, [_vp, C.POINTER(_i32), _i32]),
+    "amcx_ctx_placement": (C.c_int, [_vp, C.POINTER(Placement)]),
     "amcx_group_stats_f32": (C.c_int, [_vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp]),
     "amcx_select_scale_f32": (C.c_int, [_vp, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _i64, _vp]),
     "amcx_group_stats_workspace_bytes": (_i64, [_i64, _i64, _i32]),
@@ -146,6 +157,30 @@ def kernel_name(frame_size: int, variant: int = VARIANT_AUTO) -> str:
     return buf.value.decode()
 
 
+def numa_place(pci_bus_id: str, sysfs_root: str = "") -> tuple:
+    """(node, [cpus]) local to the PCI device ``dddd:bb:dd.f`` according to ``<sysfs_root>/bus/pci/devices`` (default
+    /sys): amcx_numa_place.  (-1, []) when the platform does not say.  Host-only: needs no GPU."""
+    lib = load()
+    node, n = C.c_int32(-1), C.c_int32(0)
+    check(lib.amcx_numa_place(sysfs_root.encode(), pci_bus_id.encode(), C.byref(node), None, 0, C.byref(n)))
+    cpus = (C.c_int32 * max(1, n.value))()
+    check(lib.amcx_numa_place(sysfs_root.encode(), pci_bus_id.encode(), C.byref(node), cpus, n.value, C.byref(n)))
+    return node.value, [int(c) for c in cpus[:n.value]]
+
+
+def device_pci_bus_id(device: int) -> str:
+    buf = C.create_string_buffer(32)
+    check(load().amcx_device_pci_bus_id(int(device), buf, len(buf)))
+    return buf.value.decode()
+
+
+def probe_fma_rate(seconds: float = 1.0, stream: int = 0) -> dict:
+    """amcx_probe_fma_rate on the current device: {"wave_instr_per_s", "clock_GHz"} (synchronises the stream)."""
+    rate, clock = C.c_double(0.0), C.c_double(0.0)
+    check(load().amcx_probe_fma_rate(float(seconds), stream or None, C.byref(rate), C.byref(clock)))
+    return {"wave_instr_per_s": rate.value, "clock_GHz": clock.value}
+
+
 class HostContext:
     """Reusable host-buffer context (amcx_ctx_*): a stream and growing device scratch kept
     across calls.  One per thread and device; freed with the object."""
@@ -182,6 +217,18 @@ class HostContext:
             self._h, int(fd), int(re_offset), -1 if im_offset is None else int(im_offset), int(kind), int(n_snr),
             int(n_frames), int(frame_size), int(strides[0]), int(strides[1]), int(strides[2]), out.ctypes.data,
             out.shape[1], int(variant)))
+
+    def bind_cpus(self, cpus) -> None:
+        """amcx_ctx_bind_cpus: the staging threads (and the caller during a large upload) on these CPUs; [] unbinds."""
+        cpus = [int(c) for c in cpus]
+        arr = (C.c_int32 * max(1, len(cpus)))(*cpus)
+        check(load().amcx_ctx_bind_cpus(self._h, arr, len(cpus)))
+
+    def placement(self) -> dict:
+        pl = Placement()
+        check(load().amcx_ctx_placement(self._h, C.byref(pl)))
+        return {"device": pl.device, "numa_node": pl.numa_node, "n_cpus": pl.n_cpus, "n_cpus_allowed": pl.n_cpus_allowed,
+                "first_cpu": pl.first_cpu, "last_cpu": pl.last_cpu, "pci_bus_id": pl.pci_bus_id.decode()}
 
     def upload_stats(self) -> dict:
         st = UploadStats()

@@ -114,6 +114,34 @@ int launch_block(const float2* iq, int64_t n_frames, int32_t N, int64_t row_stri
   return AMCX_OK;
 }
 
+// The instruction-issue ceiling under the board's power cap: 16 wavefronts per CU (4 per SIMD, the N = 2048 kernel's
+// occupancy), each running `iters` trips of 32 independent v_fma_f32 (8 chains x 4) on registers -- no memory traffic.
+// Lane 0 of every wave leaves its shader-clock cycles and its 100 MHz real-time ticks, from which the clock follows.
+__global__ __launch_bounds__(1024) void amcx_probe_fma_kernel(int iters, float* sink, unsigned long long* ticks) {
+  float a0 = (float)threadIdx.x, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f,
+        a6 = a0 + 6.f, a7 = a0 + 7.f;
+  const float b0 = 1.0001f, b1 = 0.9999f;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      asm volatile(
+          "v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+          "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b0), "v"(b1));
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  const float s = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+  if (s == 12345.678f) sink[0] = s;                       // keeps the chains alive; never true in practice
+  if ((threadIdx.x & 63) == 0) {
+    const long long w = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    ticks[2 * w] = t1 - t0;
+    ticks[2 * w + 1] = r1 - r0;
+  }
+}
+
 __global__ __launch_bounds__(256) void amcx_probe_read_kernel(const float4* __restrict__ src,
                                                              long long n_vec, float* partial) {
   typedef float v4f __attribute__((ext_vector_type(4)));
@@ -234,6 +262,11 @@ struct amcx_ctx {
   hipEvent_t slab_free[2] = {nullptr, nullptr};
   float* out_pin = nullptr; size_t out_pin_cap = 0;   // the result lands in pinned memory first
   amcx_upload_stats stats = {};
+  // host placement (amcx_upload.h, NumaPlace): the CPUs local to this device; staging threads, the calling thread for the
+  // duration of a threaded upload, and with it the pinned slots it allocates, stay on them.  Empty: nothing is bound.
+  char pci_bus_id[32] = {0};
+  int numa_node = -1;
+  std::vector<int> bind_cpus;
   // small row-major calls (a loop of per-frame calculate_features calls): the copy in, the launches and the copy
   // out as ONE instantiated graph per (frames, frame size, variant, element type, buffers), relaunched
   struct SmallGraph {
@@ -288,6 +321,7 @@ double wall_now() {
 int strided_prepare(amcx_ctx* c, size_t slot, size_t dslot, size_t frames_bytes, size_t out_bytes, bool threaded) {
   if (c->threads == 0) {
     unsigned hw = std::thread::hardware_concurrency();
+    if (!c->bind_cpus.empty()) hw = (unsigned)amcx::allowed_subset(c->bind_cpus).size();   // this device's share of the host
     c->threads = (int)(hw == 0 ? 4 : hw > 8 ? 8 : hw);
   }
   if (threaded) c->pool.resize(c->threads);      // the staging threads start with the first call that has work for them
@@ -359,6 +393,10 @@ int ctx_run_strided(amcx_ctx* c, amcx::Source src, int64_t S, int64_t K,
   // rows of complex128 rounded on the device: each device slot is followed by room for its rounded rows
   const size_t dslot = (rows && as_c128) ? slot + slot / 2 : slot;
   const bool threaded = total_staged >= (size_t(1) << 20);        // below 1 MiB a condition-variable wake costs more than the copy
+  // an upload worth its staging threads runs on the device's own socket, this thread included: it stages, and the pinned
+  // slots strided_prepare may allocate are placed where it runs (a per-frame call is not worth two affinity system calls)
+  static const std::vector<int> kNoCpus;
+  amcx::AffinityGuard on_local_cpus(threaded ? c->bind_cpus : kNoCpus);
   int rc = strided_prepare(c, slot, dslot, rows ? 0 : (size_t)F * N * 8, sizeof(float) * AMCX_NUM_FEATURES * (size_t)F,
                            threaded);
   if (rc != AMCX_OK) return rc;
@@ -590,7 +628,73 @@ int amcx_ctx_create(int32_t device, amcx_ctx** ctx_out) {
   c->device = device;
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreateWithFlags"); }
+  // which CPUs are local to this device: from the kernel's PCI tree, unless AMCX_NUMA=0 (AMCX_SYSFS_ROOT: another tree)
+  if (hipDeviceGetPCIBusId(c->pci_bus_id, (int)sizeof c->pci_bus_id, device) != hipSuccess) {
+    (void)hipGetLastError();
+    c->pci_bus_id[0] = '\0';
+  }
+  const char* numa_env = getenv("AMCX_NUMA");
+  if (c->pci_bus_id[0] != '\0' && !(numa_env != nullptr && numa_env[0] == '0')) {
+    const char* root = getenv("AMCX_SYSFS_ROOT");
+    const amcx::NumaPlace place = amcx::numa_place_of(root != nullptr && root[0] != '\0' ? root : "/sys", c->pci_bus_id);
+    if (!place.empty()) {
+      c->numa_node = place.node;
+      c->bind_cpus = place.cpus;
+      c->pool.set_cpus(c->bind_cpus);
+    }
+  }
   *ctx_out = c;
+  return AMCX_OK;
+}
+
+int amcx_ctx_bind_cpus(amcx_ctx* ctx, const int32_t* cpus, int32_t n_cpus) {
+  if (ctx == nullptr || n_cpus < 0 || (n_cpus > 0 && cpus == nullptr)) return AMCX_EINVAL;
+  std::vector<int> v;
+  for (int32_t i = 0; i < n_cpus; ++i) {
+    if (cpus[i] < 0 || cpus[i] >= CPU_SETSIZE) return AMCX_EINVAL;
+    v.push_back((int)cpus[i]);
+  }
+  ctx->bind_cpus = v;
+  if (v.empty()) ctx->numa_node = -1;
+  ctx->pool.set_cpus(ctx->bind_cpus);
+  return AMCX_OK;
+}
+
+int amcx_ctx_placement(const amcx_ctx* ctx, amcx_placement* out) {
+  if (ctx == nullptr || out == nullptr) return AMCX_EINVAL;
+  memset(out, 0, sizeof *out);
+  out->device = ctx->device;
+  out->numa_node = ctx->numa_node;
+  out->n_cpus = (int32_t)ctx->bind_cpus.size();
+  out->n_cpus_allowed = (int32_t)amcx::allowed_subset(ctx->bind_cpus).size();
+  out->first_cpu = ctx->bind_cpus.empty() ? -1 : ctx->bind_cpus.front();
+  out->last_cpu = ctx->bind_cpus.empty() ? -1 : ctx->bind_cpus.back();
+  snprintf(out->pci_bus_id, sizeof out->pci_bus_id, "%s", ctx->pci_bus_id);
+  return AMCX_OK;
+}
+
+int amcx_device_pci_bus_id(int32_t device, char* buf, int32_t buf_len) {
+  if (buf == nullptr || buf_len < 16) return AMCX_EINVAL;
+  buf[0] = '\0';
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+    (void)hipGetLastError();
+    return AMCX_ENODEV;
+  }
+  AMCX_HIP(hipDeviceGetPCIBusId(buf, buf_len, device));
+  for (char* p = buf; *p; ++p) *p = (char)tolower((unsigned char)*p);
+  return AMCX_OK;
+}
+
+int amcx_numa_place(const char* sysfs_root, const char* pci_bus_id, int32_t* node_out, int32_t* cpus_out,
+                    int32_t cpus_cap, int32_t* n_cpus_out) {
+  if (pci_bus_id == nullptr || node_out == nullptr || n_cpus_out == nullptr || cpus_cap < 0 ||
+      (cpus_cap > 0 && cpus_out == nullptr))
+    return AMCX_EINVAL;
+  const amcx::NumaPlace place = amcx::numa_place_of(sysfs_root != nullptr && sysfs_root[0] != '\0' ? sysfs_root : "/sys", pci_bus_id);
+  *node_out = place.empty() ? -1 : place.node;
+  *n_cpus_out = place.empty() ? 0 : (int32_t)place.cpus.size();
+  for (int32_t i = 0; i < *n_cpus_out && i < cpus_cap; ++i) cpus_out[i] = place.cpus[(size_t)i];
   return AMCX_OK;
 }
 
@@ -788,6 +892,78 @@ int amcx_kernel_name(int32_t frame_size, int32_t variant, char* buf, int32_t buf
                                                                        : "amcx_features18_block_kernel<0>";
   snprintf(buf, (size_t)buf_len, "%s", name);
   return AMCX_OK;
+}
+
+int amcx_probe_fma_rate(double seconds, void* hip_stream, double* wave_instr_per_s, double* clock_ghz) {
+  if (!(seconds > 0.0) || seconds > 60.0 || wave_instr_per_s == nullptr) return AMCX_EINVAL;
+  *wave_instr_per_s = 0.0;
+  if (clock_ghz) *clock_ghz = 0.0;
+  hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+  const int grid = cu_count();
+  if (grid <= 0) return AMCX_ENODEV;
+  const long long n_waves = (long long)grid * 16;
+  constexpr int kIters = 32768;                            // x 32 instructions x 4096 waves: ~5 ms a launch
+  float* sink = nullptr;
+  unsigned long long* ticks = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+  int rc = AMCX_OK;
+  auto fail = [&](hipError_t e, const char* what) { rc = hip_fail(e, what); };
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&sink), 4);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ticks), (size_t)n_waves * 16);
+  if (e == hipSuccess) e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  if (e == hipSuccess) e = hipEventCreate(&e2);
+  if (e != hipSuccess) {
+    fail(e, "fma probe setup");
+  } else {
+    auto launch = [&]() { hipLaunchKernelGGL(amcx_probe_fma_kernel, dim3((unsigned)grid), dim3(1024), 0, stream, kIters, sink, ticks); };
+    // one launch to learn its length, then `seconds` of back-to-back launches: the first half lets the board's power
+    // management settle the clock, the second half is timed
+    (void)hipEventRecord(e0, stream);
+    launch();
+    (void)hipEventRecord(e1, stream);
+    e = hipEventSynchronize(e1);
+    float one_ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&one_ms, e0, e1);
+    if (e != hipSuccess) {
+      fail(e, "fma probe launch");
+    } else {
+      if (!(one_ms > 0.01f)) one_ms = 0.01f;
+      long long n = (long long)(seconds * 1e3 / 2.0 / one_ms);
+      if (n < 1) n = 1;
+      if (n > 100000) n = 100000;
+      for (long long i = 0; i < n; ++i) launch();
+      (void)hipEventRecord(e1, stream);
+      for (long long i = 0; i < n; ++i) launch();
+      (void)hipEventRecord(e2, stream);
+      e = hipEventSynchronize(e2);
+      float ms = 0.f;
+      if (e == hipSuccess) e = hipEventElapsedTime(&ms, e1, e2);
+      if (e == hipSuccess) e = hipGetLastError();
+      if (e != hipSuccess || !(ms > 0.f)) {
+        fail(e, "fma probe timing");
+      } else {
+        *wave_instr_per_s = (double)n * (double)n_waves * (double)kIters * 32.0 / ((double)ms * 1e-3);
+        if (clock_ghz) {
+          std::vector<unsigned long long> h((size_t)n_waves * 2);
+          e = hipMemcpy(h.data(), ticks, h.size() * 8, hipMemcpyDeviceToHost);
+          if (e == hipSuccess) {
+            double cyc = 0.0, real = 0.0;
+            for (long long w = 0; w < n_waves; ++w) { cyc += (double)h[(size_t)(2 * w)]; real += (double)h[(size_t)(2 * w + 1)]; }
+            if (real > 0.0) *clock_ghz = cyc / (real * 10.0);       // s_memrealtime ticks at 100 MHz
+          } else {
+            fail(e, "fma probe read-back");
+          }
+        }
+      }
+    }
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (e2) (void)hipEventDestroy(e2);
+  if (sink) (void)hipFree(sink);
+  if (ticks) (void)hipFree(ticks);
+  return rc;
 }
 
 int amcx_probe_read_bw(const void* src_dev, int64_t n_bytes, float* partial_dev, void* hip_stream) {

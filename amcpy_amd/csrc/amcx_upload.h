@@ -14,8 +14,13 @@
 // (profiles/r3_h2d_probe.txt): 8 threads copy pageable -> pinned at 138 GB/s, the link does 57 GB/s.
 #pragma once
 
+#include <ctype.h>
 #include <errno.h>
+#include <pthread.h>
+#include <sched.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
 #if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
@@ -28,10 +33,117 @@
 #include <condition_variable>
 #include <functional>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
 namespace amcx {
+
+// ---- where a device's host work should run ------------------------------------------------------
+// One process can drive all eight GPUs of a node (DeviceFanOut, feature_extraction.py), each with its own staging
+// threads and pinned slots.  The node has two sockets; a GPU hangs off one of them, and a staging thread on the other
+// socket writes its pinned slot across the socket link before the copy engine reads it back across the same link.
+// The kernel's PCI sysfs tree says which CPUs are local to a device:
+//     <sysfs>/bus/pci/devices/<domain:bus:dev.fn>/numa_node        (-1: the platform does not say -- one node, a VM)
+//     <sysfs>/bus/pci/devices/<domain:bus:dev.fn>/local_cpulist    ("0-63,128-191")
+// numa_place_of reads the two; node -1, a missing file or an empty list give an empty place, and an empty place binds
+// nothing.  Host-only logic: tests feed it a fake tree (tests/test_host_cpu.py), stage_fuzz.cc runs it under the sanitizers.
+struct NumaPlace {
+  int node = -1;
+  std::vector<int> cpus;
+  bool empty() const { return node < 0 || cpus.empty(); }
+};
+
+// "0-3,8,10-11\n" -> {0,1,2,3,8,10,11}; anything malformed ends the list where it stops making sense
+inline std::vector<int> parse_cpulist(const char* text) {
+  std::vector<int> out;
+  const char* p = text;
+  while (p != nullptr && *p != '\0') {
+    while (*p == ' ' || *p == ',' || *p == '\n' || *p == '\t') ++p;
+    if (!isdigit((unsigned char)*p)) break;
+    char* end = nullptr;
+    long a = strtol(p, &end, 10), b = a;
+    p = end;
+    if (*p == '-') {
+      ++p;
+      if (!isdigit((unsigned char)*p)) break;
+      b = strtol(p, &end, 10);
+      p = end;
+    }
+    if (a < 0 || b < a || b >= 1 << 16) break;
+    for (long c = a; c <= b; ++c) out.push_back((int)c);
+  }
+  return out;
+}
+
+inline bool read_small_file(const std::string& path, std::string* out) {
+  FILE* f = fopen(path.c_str(), "r");
+  if (f == nullptr) return false;
+  char buf[4096];
+  const size_t n = fread(buf, 1, sizeof buf - 1, f);
+  fclose(f);
+  buf[n] = '\0';
+  *out = buf;
+  return true;
+}
+
+inline NumaPlace numa_place_of(const std::string& sysfs_root, const std::string& pci_bus_id) {
+  NumaPlace place;
+  std::string bdf = pci_bus_id;
+  for (auto& ch : bdf) ch = (char)tolower((unsigned char)ch);
+  if (bdf.empty() || bdf.find('/') != std::string::npos) return place;
+  const std::string dir = sysfs_root + "/bus/pci/devices/" + bdf + "/";
+  std::string text;
+  if (!read_small_file(dir + "numa_node", &text)) return place;
+  char* end = nullptr;
+  const long node = strtol(text.c_str(), &end, 10);
+  if (end == text.c_str() || node < 0) return place;
+  if (!read_small_file(dir + "local_cpulist", &text)) return place;
+  place.cpus = parse_cpulist(text.c_str());
+  if (!place.cpus.empty()) place.node = (int)node;
+  return place;
+}
+
+// the CPUs of `want` that the calling thread may run on at all (a container's cpuset, taskset): binding never
+// widens what the process was given.  Empty: nothing to bind to.
+inline std::vector<int> allowed_subset(const std::vector<int>& want) {
+  std::vector<int> out;
+  cpu_set_t cur;
+  CPU_ZERO(&cur);
+  if (pthread_getaffinity_np(pthread_self(), sizeof cur, &cur) != 0) return out;
+  for (int c : want)
+    if (c >= 0 && c < CPU_SETSIZE && CPU_ISSET(c, &cur)) out.push_back(c);
+  return out;
+}
+
+inline bool bind_this_thread(const std::vector<int>& cpus) {
+  if (cpus.empty()) return false;
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  for (int c : cpus)
+    if (c >= 0 && c < CPU_SETSIZE) CPU_SET(c, &set);
+  return pthread_setaffinity_np(pthread_self(), sizeof set, &set) == 0;
+}
+
+// the CALLING thread on `cpus` for the lifetime of the guard (it stages too, and what it allocates and first touches
+// in that time -- the pinned slots -- lands on that node); its own mask comes back afterwards
+class AffinityGuard {
+ public:
+  explicit AffinityGuard(const std::vector<int>& cpus) {
+    if (cpus.empty()) return;
+    CPU_ZERO(&old_);
+    if (pthread_getaffinity_np(pthread_self(), sizeof old_, &old_) != 0) return;
+    const std::vector<int> ok = allowed_subset(cpus);
+    bound_ = bind_this_thread(ok);
+  }
+  ~AffinityGuard() { if (bound_) (void)pthread_setaffinity_np(pthread_self(), sizeof old_, &old_); }
+  bool bound() const { return bound_; }
+  AffinityGuard(const AffinityGuard&) = delete;
+  AffinityGuard& operator=(const AffinityGuard&) = delete;
+ private:
+  cpu_set_t old_;
+  bool bound_ = false;
+};
 
 // ---- a fork-join pool whose caller works too ----------------------------------------------------
 // run(parts, f) calls f(0..parts-1) on the workers AND the calling thread and returns when all are
@@ -44,6 +156,15 @@ class Pool {
  public:
   ~Pool() { resize(1); }
   int size() const { return (int)workers_.size() + 1; }
+  // the CPUs the workers run on (empty: wherever the scheduler puts them); existing workers are replaced
+  void set_cpus(const std::vector<int>& cpus) {
+    if (cpus == cpus_) return;
+    const int n = size();
+    resize(1);
+    cpus_ = cpus;
+    resize(n);
+  }
+  const std::vector<int>& cpus() const { return cpus_; }
   void resize(int n) {             // n threads in all (the caller is one of them)
     if (n < 1) n = 1;
     if (n == size()) return;
@@ -93,6 +214,7 @@ class Pool {
     }
   }
   void loop() {
+    if (!cpus_.empty()) (void)bind_this_thread(allowed_subset(cpus_));
     unsigned long long seen = 0;
     for (;;) {
       // poll for the next run for a while (lock-free), then sleep on the condition variable
@@ -121,6 +243,7 @@ class Pool {
     }
   }
   std::vector<std::thread> workers_;
+  std::vector<int> cpus_;
   std::mutex m_;
   std::condition_variable wake_, done_;
   const std::function<void(int)>* job_ = nullptr;

@@ -400,6 +400,24 @@ def release_engines() -> None:
         _ENGINES.popitem()[1].close()
 
 
+def staging_threads_per_device(places, want: Optional[int] = None, allowed=None):
+    """Staging threads for each engine of a one-process fan-out.  ``places[i] = (numa node, [cpus local to device i])``
+    (``_lib.numa_place``; node -1: unknown).  An engine whose device has a known node shares that node's CPUs -- those
+    of them this process may run on (``allowed``, default ``os.sched_getaffinity(0)``) -- with the other engines on the
+    node; the rest share all allowed CPUs evenly, as before round 5.  At most ``want`` (default 8) and at least 1 each."""
+    allowed = set(os.sched_getaffinity(0)) if allowed is None else set(allowed)
+    want = max(1, int(want or 8))
+    on_node = {}
+    for node, _ in places:
+        on_node[node] = on_node.get(node, 0) + 1
+    out = []
+    for node, cpus in places:
+        local = len(allowed.intersection(cpus)) if node >= 0 else 0
+        share = local // on_node[node] if local else len(allowed) // len(places)
+        out.append(max(1, min(want, share)))
+    return out
+
+
 class DeviceFanOut:
     """``engine(rows) -> (F, 18) float32`` over SEVERAL devices from one process: one :class:`HipEngine` (context,
     streams, pinned slots, staging threads) per entry of ``devices`` and one host thread each -- the native call
@@ -419,12 +437,36 @@ class DeviceFanOut:
         if bad:
             raise ValueError(f"device index {bad[0]} out of range: {have} gfx950 device(s) visible")
         self.N, self.devices = int(frame_size), devices
-        # the staging threads of all devices share the host's cores
-        per = max(1, min(int(threads or 8), (os.cpu_count() or 1) // len(devices) or 1))
-        self.engines = [HipEngine(frame_size, d, chunk_bytes, threads=per) for d in devices]
-        self.threads = per
+        # the staging threads of all devices share the host's cores: a device's engine gets its share of the CPUs LOCAL to
+        # it (the socket it hangs off: _lib.numa_place reads the kernel's PCI tree; the context binds its threads and
+        # pinned slots there by itself), or of all CPUs when the platform does not say
+        self.places = [self._place(d) for d in devices]
+        per_dev = staging_threads_per_device(self.places, threads)
+        self.engines = []
+        try:
+            for d, n in zip(devices, per_dev):
+                self.engines.append(HipEngine(frame_size, d, chunk_bytes, threads=n))
+        except BaseException:
+            for e in self.engines:                          # a later device failed: the earlier ones' contexts, pinned slots
+                e.close()                                   # and staging threads are released, not leaked
+            raise
+        self.threads = min(per_dev)
         self._pool = ThreadPoolExecutor(max_workers=len(devices), thread_name_prefix="amcx-device")
         self.stats = {}
+
+    @staticmethod
+    def _place(device: int):
+        """(numa node, [local cpus]) of a device, (-1, []) if unknown or switched off (AMCX_NUMA=0)."""
+        if os.environ.get("AMCX_NUMA", "1")[:1] == "0":
+            return -1, []
+        try:
+            return _lib.numa_place(_lib.device_pci_bus_id(device), os.environ.get("AMCX_SYSFS_ROOT", ""))
+        except Exception:
+            return -1, []
+
+    def placement(self):
+        """What each engine's context bound itself to (amcx_ctx_placement), in device order."""
+        return [e._context().placement() for e in self.engines]
 
     def shares(self, rows: FrameRows):
         """[(rows of device i, where they go)]: ``("columns", k_lo, k_hi)`` or ``("rows", lo, hi)``."""

@@ -27,6 +27,15 @@ One JSON line on stdout (rank 0).  Extra objects:
                against the 8 TB/s HBM peak (MI355X_MICROARCH.md); `traffic`
                carries the PMC-derived HBM bytes per launch when a committed
                profile summary provides it (profiles/*.json), else null.
+               roofline.secondary.measured: the board's instruction-issue ceiling under its power cap, run
+               live after the timed region (amcx_probe_fma_rate, ~1 s of independent v_fma_f32), and this
+               kernel's own instruction rate against it; roofline.frac_of_measured_read_peak.
+  per_rank     (N > 1) one entry per rank: rank, device, PCI bus id, mean / min / max launch ms, frames per
+               launch, its own wall seconds, its device's FMA ceiling -- if the aggregate is short of N x, the
+               line says which rank, device or clock was slow; scaling_efficiency = value / (N x the best rank's
+               own kernel-only rate), rank_balance = slowest / fastest rank's kernel-only rate.
+  h2d_fanout   (N > 1) the real-data path over all N devices from ONE process (DeviceFanOut): rank 0, before it
+               touches a GPU, runs a fresh child that uploads one configs[1] modulation (3.49 GB complex128).
   cpu_baseline the oracle's reference-shaped per-frame evaluator on the host
                cores (kind "port"), on the configs[0] shape, rank 0 at N=1
                only; run BEFORE the GPU is initialised (worker processes).
@@ -327,6 +336,67 @@ def h2d_path(dev, frame_size: int = FRAME_SIZE, big: bool = True):
     return rec
 
 
+def fanout_child(n_devices: int, share_gpu: bool, frame_size: int, n_frames: int) -> int:
+    """`bench.py --fanout-child N`: the one-process multi-GPU real-data path, in a process of its own.  One configs[1]
+    modulation -- (26, n_frames, frame_size) complex128, Fortran-ordered as loadmat returns it -- through
+    feature_extraction.DeviceFanOut over N devices (device r %% visible with --share-gpu), once warm, once timed.
+    Prints ONE JSON object: GB/s of container bytes, frames/s, per-device seconds / frames / placement."""
+    import numpy as np  # noqa: F401
+    from amcpy_amd import _lib
+    from amcpy_amd.feature_extraction import DeviceFanOut, FrameRows
+    lib = _lib.load(skip_torch=True)                       # host-buffer path: no torch in this process
+    have = lib.amcx_device_count()
+    if have <= 0:
+        print(json.dumps({"error": "no gfx950 device visible"}))
+        return 0
+    devices = [r % have for r in range(n_devices)] if share_gpu else list(range(n_devices))
+    if max(devices) >= have:
+        print(json.dumps({"error": f"{n_devices} devices wanted, {have} visible"}))
+        return 0
+    rows = FrameRows(_fortran_container(N_SNR, n_frames, frame_size), N_SNR, n_frames)
+    fan = DeviceFanOut(frame_size, devices)
+    try:
+        fan(rows)                                          # warm: contexts, pinned slots, staging threads, kernels
+        t0 = time.perf_counter()
+        out = fan(rows)
+        wall = time.perf_counter() - t0
+        assert np.isfinite(out[:: max(1, out.shape[0] // 64)]).all()
+        F = rows.shape[0]
+        rec = {"GBps": F * frame_size * 16 / wall / 1e9, "frames_per_s": F / wall, "seconds": wall,
+               "devices": devices, "staging_threads": [e.threads for e in fan.engines],
+               "per_device_seconds": [e.stats.get("seconds") for e in fan.engines],
+               "per_device_frames": fan.stats.get("frames_per_device"),
+               "pcie_GBps": fan.stats.get("bytes_uploaded", 0) / wall / 1e9,
+               "placement": [{k: pl[k] for k in ("pci_bus_id", "numa_node", "n_cpus", "n_cpus_allowed")}
+                             for pl in fan.placement()],
+               "what": f"one process, {len(devices)} engines: ({N_SNR}, {n_frames}, {frame_size}) complex128 "
+                       f"Fortran-ordered = {F * frame_size * 16 / 1e9:.2f} GB cut along the frame axis; GBps = "
+                       f"container bytes / wall"}
+    finally:
+        fan.close()
+    print(json.dumps(_rounded(rec)), flush=True)
+    return 0
+
+
+def run_fanout_leg(n_devices: int, share_gpu: bool, frame_size: int, n_frames: int, time_limit: float = 300.0):
+    """Start the fan-out child from a process that has not touched the GPU and return its JSON object (or an
+    {"error": ...} -- never fatal to the headline)."""
+    import subprocess
+    cmd = [sys.executable, str(Path(__file__).resolve()), "--fanout-child", str(n_devices), "--frame-size", str(frame_size),
+           "--frames", str(n_frames)] + (["--share-gpu"] if share_gpu else [])
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "AMCX_BENCH_SELF_LAUNCHED"):
+        env.pop(k, None)                                  # the child is nobody's rank
+    try:
+        r = subprocess.run(cmd, env=env, stdin=subprocess.DEVNULL, capture_output=True, text=True, timeout=time_limit)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": f"fan-out child exited {r.returncode}: {r.stderr.strip()[-300:]}"}
+        return json.loads(lines[-1])
+    except Exception as exc:
+        return {"error": repr(exc)}
+
+
 def _valu_note(frames_per_s: float):
     """Secondary bounds of the N = 2048 kernel from this round's committed budget
     (profiles/r2_wave_budget.json: in-kernel clock, issue slots, ablations -- DESIGN.md 4.3)."""
@@ -391,15 +461,21 @@ def _free_port() -> int:
         return sk.getsockname()[1]
 
 
+_PARENT_PID = None
+
+
 def _die_with_parent():
     """preexec of a rank (its own session comes from start_new_session, so that the parent can take the whole rank
-    down, helper processes included): SIGKILL when the parent goes away, however that happens."""
+    down, helper processes included): SIGKILL when the parent goes away, however that happens -- including between
+    the fork and the prctl (then the parent pid seen here is no longer the one that forked)."""
     import ctypes
     import signal
     try:
         ctypes.CDLL(None, use_errno=True).prctl(1, signal.SIGKILL, 0, 0, 0)      # PR_SET_PDEATHSIG
     except Exception:
         pass
+    if _PARENT_PID is not None and os.getppid() != _PARENT_PID:
+        os._exit(1)
 
 
 def self_launch(n: int, argv, time_limit: float, script=None, build: bool = True) -> int:
@@ -419,6 +495,8 @@ def self_launch(n: int, argv, time_limit: float, script=None, build: bool = True
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     script = str(Path(__file__).resolve() if script is None else script)      # (another script: the process-handling tests)
     procs = []
+    global _PARENT_PID
+    _PARENT_PID = os.getpid()
 
     def kill_all(sig=signal.SIGKILL):
         for pr in procs:
@@ -428,8 +506,16 @@ def self_launch(n: int, argv, time_limit: float, script=None, build: bool = True
                 except (ProcessLookupError, PermissionError):
                     pass
 
+    def reap(timeout=5.0):
+        for pr in procs:                                   # no zombies, and what a killed rank still wrote is flushed
+            try:
+                pr.wait(timeout=timeout)
+            except Exception:
+                pass
+
     def on_signal(signum, _frame):
         kill_all()
+        reap()
         raise SystemExit(128 + signum)
 
     for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
@@ -463,6 +549,7 @@ def self_launch(n: int, argv, time_limit: float, script=None, build: bool = True
         return first_bad if first_bad >= 0 else 128 - first_bad      # a rank killed by a signal
     finally:
         kill_all()
+        reap()
 
 
 def main():
@@ -494,10 +581,15 @@ def main():
                          "run, e.g. two ranks sharing one GPU)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal: ranks take device local_rank %% device_count instead of one GPU each")
+    ap.add_argument("--no-fma-probe", action="store_true", help="skip the ~1 s instruction-issue ceiling probe")
+    ap.add_argument("--no-fanout", action="store_true", help="N > 1: skip the one-process fan-out upload leg")
+    ap.add_argument("--fanout-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--launch-timeout", type=float, default=1500.0,
                     help="self-launched ranks (--gpus N without a launcher) are killed after this many seconds")
     args = ap.parse_args()
     FS = args.frame_size
+    if args.fanout_child > 0:
+        raise SystemExit(fanout_child(args.fanout_child, args.share_gpu, FS, args.frames))
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
 
@@ -518,6 +610,11 @@ def main():
 
     if os.environ.get("AMCX_BENCH_SELF_LAUNCHED") != "1":
         _ensure_library(local_rank)
+    # N > 1: the one-process fan-out over all N devices, by a fresh child of rank 0 while no rank has touched its GPU
+    # yet (the others wait in the rendezvous below)
+    h2d_fanout = None
+    if world > 1 and rank == 0 and not args.no_fanout and not args.no_h2d:
+        h2d_fanout = run_fanout_leg(world, args.share_gpu, FS, min(args.frames, N_FRAMES))
     import torch
     import torch.distributed as dist
     from amcpy_amd import _lib, synth
@@ -578,7 +675,7 @@ def main():
         step()
         b.record()
     fence()
-    wall = time.perf_counter() - t0
+    wall = wall_own = time.perf_counter() - t0
     launch_ms = [a.elapsed_time(b) for a, b in ev]
     if use_dist:
         t = torch.tensor([wall], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
@@ -648,6 +745,15 @@ def main():
         torch.cuda.synchronize()
         read_peak = nbytes * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
+    # the bound that binds: the board's instruction-issue rate under its power cap, measured now (every rank: a slow
+    # device shows here), against the kernel's own rate
+    fma = None
+    if not args.no_fma_probe:
+        try:
+            fma = _lib.probe_fma_rate(1.0, torch.cuda.current_stream().cuda_stream)
+        except Exception as exc:
+            fma = {"error": repr(exc)}
+
     h2d = None
     if rank == 0 and world == 1 and not args.no_h2d:
         del arena
@@ -683,7 +789,18 @@ def main():
             gather = {"ms": (time.perf_counter() - t_g) * 1e3, "bytes_per_rank": int(local.nbytes),
                       "rows_on_rank0": None if full is None else int(full.shape[0]),
                       "what": "sharding.gather_rows, one step's result, all ranks -> rank 0"}
+    per_rank = None
     if use_dist:
+        try:
+            bus = _lib.device_pci_bus_id(dev_index)
+        except Exception:
+            bus = None
+        mine = {"rank": rank, "dev": dev_index, "bus": bus, "ms_mean": sum(launch_ms) / len(launch_ms),
+                "ms_min": min(launch_ms), "ms_max": max(launch_ms), "frames": frames_per_launch, "wall_s": wall_own,
+                "fma_G": None if not fma or "error" in fma else fma["wave_instr_per_s"] / 1e9,
+                "fma_GHz": None if not fma or "error" in fma else fma["clock_GHz"]}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
         dist.barrier()
         dist.destroy_process_group()
     if rank != 0:
@@ -724,11 +841,14 @@ def main():
             "launch_ms_min": srt[0], "launch_ms_median": srt[len(srt) // 2], "launch_ms_max": srt[-1],
             "frac_at_min": alg_bytes / (srt[0] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             "measured_read_peak_GBps": read_peak,
-            "secondary": _valu_note(value / world) if FS == FRAME_SIZE else None,
+            "frac_of_measured_read_peak": None if not read_peak else achieved / read_peak,
+            "secondary": _secondary(value / world, fma) if FS == FRAME_SIZE else None,
         },
         "wall_incl_d2h_ms": wall_d2h_ms,
         "h2d": h2d,
         "gather": gather,
+        **({} if per_rank is None else _scaling_block(per_rank, value, world)),
+        **({} if h2d_fanout is None else {"h2d_fanout": h2d_fanout}),
         "cpu_baseline": cpu,
         "cpu_baseline_reference_shaped": cpu_ref_shaped,
         "parity": _parity_block(),
@@ -736,6 +856,37 @@ def main():
     sys.stdout.flush()
     os.dup2(real_stdout, 1)
     print(json.dumps(_rounded(rec)), flush=True)
+
+
+def _secondary(frames_per_s_per_gpu: float, fma):
+    """The replayed budget of the N = 2048 kernel (profiles/r*_wave_budget.json) plus what THIS run measured: the
+    device's FMA ceiling under the power cap and the kernel's instruction rate (committed VALU instructions per frame x
+    the measured frames/s) against it."""
+    out = _valu_note(frames_per_s_per_gpu)
+    if out is None or fma is None:
+        return out
+    if "error" in fma:
+        out["measured"] = fma
+        return out
+    kern = out.get("valu_instr_per_frame", 0) * frames_per_s_per_gpu / 1e9
+    ceil = fma["wave_instr_per_s"] / 1e9
+    out["measured"] = {"fma_Gwaveinstr_per_s": ceil, "fma_clock_GHz": fma["clock_GHz"],
+                       "kernel_Gwaveinstr_per_s": kern, "ratio": kern / ceil if ceil else None,
+                       "what": "amcx_probe_fma_rate in this run: 4 waves/SIMD of independent v_fma_f32, no memory traffic, "
+                               "~0.5 s settle + 0.5 s timed; kernel = valu_instr_per_frame x this run's frames/s/GPU"}
+    return out
+
+
+def _scaling_block(per_rank, value, world):
+    """Which rank was slow?  Every rank's own kernel-only rate (frames per launch / mean launch time); the aggregate
+    against N x the best of them; the spread."""
+    rates = [r["frames"] / (r["ms_mean"] * 1e-3) for r in per_rank if r and r.get("ms_mean")]
+    out = {"per_rank": [{k: (float(f"{v:.6g}") if isinstance(v, float) else v) for k, v in r.items()} for r in per_rank]}
+    if rates:
+        out["scaling_efficiency"] = value / (world * max(rates))
+        out["rank_balance"] = min(rates) / max(rates)
+        out["sum_of_rank_rates"] = sum(rates)
+    return out
 
 
 def _rounded(x):

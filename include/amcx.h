@@ -76,8 +76,11 @@ extern "C" {
  * amcx_ctx_configure, amcx_ctx_upload_stats), device-ownership rule below made explicit;
  * 3 = single-read statistics with a caller workspace (amcx_group_stats_ws_f32,
  * amcx_group_stats_workspace_bytes), amcx_standardize_fit_transform_f32 / _workspace_bytes, and containers
- * read straight from their file (amcx_ctx_features18_strided_file, amcx_stage_file, AMCX_EIO). */
-#define AMCX_ABI_VERSION 3
+ * read straight from their file (amcx_ctx_features18_strided_file, amcx_stage_file, AMCX_EIO);
+ * 4 = host placement (amcx_numa_place, amcx_device_pci_bus_id, amcx_ctx_bind_cpus, amcx_ctx_placement: a context's
+ * staging threads and pinned slots on the CPUs local to its device) and the instruction-issue ceiling probe
+ * (amcx_probe_fma_rate). */
+#define AMCX_ABI_VERSION 4
 #define AMCX_NUM_FEATURES 18
 
 /* error codes */
@@ -301,6 +304,50 @@ int amcx_pack_planes_c64(const void* slab_dev, int32_t src_kind, int32_t n_plane
  */
 int amcx_probe_read_bw(const void* src_dev, int64_t n_bytes, float* partial_dev,
                        void* hip_stream);
+
+/*
+ * Instruction-issue ceiling probe -- the bound that binds this path on an MI355X (the board's power cap, then VALU
+ * issue: DESIGN.md section 4): one 16-wavefront workgroup per CU (four waves per SIMD, the N = 2048 kernel's
+ * occupancy) runs independent v_fma_f32 on registers, no memory traffic, back to back for `seconds` (0 < seconds <=
+ * 60) on hip_stream; the first half lets the clock settle, the second half is timed with HIP events.
+ * *wave_instr_per_s: wavefront-instructions per second of the whole device; *clock_ghz (may be NULL): the shader
+ * clock during the last launch (s_memtime cycles / s_memrealtime ticks).  Unlike the other device entries this one
+ * allocates scratch and SYNCHRONISES the stream.  bench.py reports the feature kernel's own instruction rate against
+ * it (roofline.secondary.measured).
+ */
+int amcx_probe_fma_rate(double seconds, void* hip_stream, double* wave_instr_per_s, double* clock_ghz);
+
+/*
+ * Host placement.  One process may drive every GPU of a node (the reference starts one process per modulation,
+ * feature_extraction.py:89-97; here amcpy_amd.feature_extraction.DeviceFanOut runs one context per device), and a
+ * context's staging threads and pinned slots belong on the socket its device hangs off.
+ *
+ * amcx_device_pci_bus_id: "dddd:bb:dd.f" (lower case) of visible device `device`; buf_len >= 16.
+ * amcx_numa_place: host-only (no GPU needed).  Reads <sysfs_root>/bus/pci/devices/<pci_bus_id>/numa_node and
+ *   .../local_cpulist (sysfs_root NULL or "" = "/sys").  *node_out = the node or -1, *n_cpus_out = how many CPUs
+ *   are local (0 with node -1), the first min(n, cpus_cap) of them in cpus_out (ascending).  A platform that does
+ *   not say (numa_node -1, a missing file, a malformed list) is not an error: node -1, no CPUs, nothing gets bound.
+ * amcx_ctx_create does this for its device by itself (environment: AMCX_NUMA=0 turns it off, AMCX_SYSFS_ROOT names
+ *   another tree); amcx_ctx_bind_cpus replaces the choice (n_cpus = 0: bind nothing).  Bound are: the context's
+ *   staging threads, and the CALLING thread for the duration of an upload large enough to use them (its own
+ *   affinity mask is restored on return) -- so the pinned slots, allocated on first use inside such a call, are placed
+ *   on that node too.  A binding never widens the mask the process was given (cpusets, taskset): CPUs outside it
+ *   are dropped, and if none is left nothing is bound.
+ * amcx_ctx_placement: what a context did.
+ */
+typedef struct amcx_placement {
+  int32_t device;
+  int32_t numa_node;        /* -1: unknown / unbound */
+  int32_t n_cpus;           /* CPUs local to the device (or given to amcx_ctx_bind_cpus) */
+  int32_t n_cpus_allowed;   /* ... of which the calling thread may use */
+  int32_t first_cpu, last_cpu;
+  char pci_bus_id[32];
+} amcx_placement;
+int amcx_device_pci_bus_id(int32_t device, char* buf, int32_t buf_len);
+int amcx_numa_place(const char* sysfs_root, const char* pci_bus_id, int32_t* node_out, int32_t* cpus_out,
+                    int32_t cpus_cap, int32_t* n_cpus_out);
+int amcx_ctx_bind_cpus(amcx_ctx* ctx, const int32_t* cpus, int32_t n_cpus);
+int amcx_ctx_placement(const amcx_ctx* ctx, amcx_placement* out);
 
 /*
  * Consumers directly behind the path, on the device-resident

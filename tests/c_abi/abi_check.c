@@ -68,6 +68,19 @@ int main(int argc, char** argv) {
     CHECK(amcx_standardize_fit_transform_f32(NULL, 4, 18, 18, cols, 2, NULL, 2, NULL, NULL, NULL, 0, NULL) == AMCX_EINVAL);
     CHECK(amcx_standardize_fit_transform_f32(NULL, 0, 18, 18, cols, 1, NULL, 1, NULL, NULL, NULL, 0, NULL) == AMCX_OK);
   }
+  /* version-4 additions: the placement mapper is host-only (a device that is not in the tree binds nothing), the
+   * others validate before touching a device */
+  {
+    int32_t node = 7, n = 7, cpus[4];
+    CHECK(amcx_numa_place("/nonexistent-sysfs", "0000:05:00.0", &node, cpus, 4, &n) == AMCX_OK && node == -1 && n == 0);
+    CHECK(amcx_numa_place(NULL, NULL, &node, cpus, 4, &n) == AMCX_EINVAL);
+    CHECK(amcx_numa_place(NULL, "0000:05:00.0", &node, NULL, 4, &n) == AMCX_EINVAL);
+    CHECK(amcx_ctx_bind_cpus(NULL, NULL, 0) == AMCX_EINVAL && amcx_ctx_placement(NULL, NULL) == AMCX_EINVAL);
+    double rate = -1.0;
+    CHECK(amcx_probe_fma_rate(0.0, NULL, &rate, NULL) == AMCX_EINVAL && amcx_probe_fma_rate(1.0, NULL, NULL, NULL) == AMCX_EINVAL);
+    char bus[8];
+    CHECK(amcx_device_pci_bus_id(0, bus, (int32_t)sizeof bus) == AMCX_EINVAL);
+  }
   if (argc < 4 || strcmp(argv[1], "compute") != 0) {
     /* without a GPU the host-buffer entries must refuse, not compute */
     if (amcx_device_count() <= 0) {

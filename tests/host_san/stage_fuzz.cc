@@ -225,6 +225,77 @@ void concurrent_pools(Rng& rng) {
   for (auto& th : callers) th.join();
 }
 
+// host placement (round 5): the cpulist parser on good and malformed text, the PCI-tree reader on a fake tree, and a
+// pool bound to a subset of the CPUs this process may use -- every part must run on one of them, the caller's own mask
+// must come back after the guard, and re-binding while workers exist must replace them cleanly
+void placement(const char* dir) {
+  auto eq = [](const std::vector<int>& a, std::initializer_list<int> b) { return a == std::vector<int>(b); };
+  if (!eq(amcx::parse_cpulist("0-3,8,10-11\n"), {0, 1, 2, 3, 8, 10, 11})) die("cpulist ranges");
+  if (!eq(amcx::parse_cpulist("5"), {5}) || !eq(amcx::parse_cpulist(""), {}) || !eq(amcx::parse_cpulist("\n"), {})) die("cpulist singles");
+  if (!eq(amcx::parse_cpulist("2-1"), {}) || !eq(amcx::parse_cpulist("1,x"), {1}) || !eq(amcx::parse_cpulist("3-"), {})) die("cpulist malformed");
+  if (!eq(amcx::parse_cpulist("0-1,99999999"), {0, 1})) die("cpulist out of range");
+  const std::string root = std::string(dir) + "/sys";
+  auto put = [&](const char* bdf, const char* node, const char* cpus) {
+    const std::string d = root + "/bus/pci/devices/" + bdf;
+    const std::string cmd = "mkdir -p '" + d + "'";
+    if (system(cmd.c_str()) != 0) die("mkdir");
+    if (node) { FILE* f = fopen((d + "/numa_node").c_str(), "w"); fputs(node, f); fclose(f); }
+    if (cpus) { FILE* f = fopen((d + "/local_cpulist").c_str(), "w"); fputs(cpus, f); fclose(f); }
+  };
+  put("0000:05:00.0", "0\n", "0-3,8-11\n");
+  put("0000:85:00.0", "1\n", "4-7,12-15\n");
+  put("0000:a5:00.0", "-1\n", "0-15\n");
+  put("0000:b5:00.0", "1\n", nullptr);
+  amcx::NumaPlace a = amcx::numa_place_of(root, "0000:05:00.0"), b = amcx::numa_place_of(root, "0000:85:00.0");
+  if (a.node != 0 || !eq(a.cpus, {0, 1, 2, 3, 8, 9, 10, 11}) || b.node != 1 || b.cpus.size() != 8 || b.cpus[0] != 4) die("place");
+  if (!amcx::numa_place_of(root, "0000:A5:00.0").empty()) die("node -1 must not bind");
+  if (!amcx::numa_place_of(root, "0000:b5:00.0").empty() || !amcx::numa_place_of(root, "0000:ff:00.0").empty() ||
+      !amcx::numa_place_of(root, "../x").empty() || !amcx::numa_place_of(root, "").empty()) die("missing files must not bind");
+  const std::string rm = "rm -rf '" + root + "'";
+  if (system(rm.c_str()) != 0) die("rm");
+
+  cpu_set_t mine;
+  CPU_ZERO(&mine);
+  if (pthread_getaffinity_np(pthread_self(), sizeof mine, &mine) != 0) die("getaffinity");
+  std::vector<int> usable;
+  for (int c = 0; c < CPU_SETSIZE; ++c) if (CPU_ISSET(c, &mine)) usable.push_back(c);
+  if (usable.empty()) die("no cpus");
+  std::vector<int> want(usable.begin(), usable.begin() + (usable.size() > 2 ? 2 : 1));
+  want.push_back(CPU_SETSIZE - 1);                                  // one this process (almost certainly) may not use: dropped
+  const std::vector<int> ok = amcx::allowed_subset(want);
+  if (ok.empty() || ok.size() > want.size()) die("allowed_subset");
+  amcx::Pool pool;
+  pool.resize(4);
+  pool.set_cpus(want);                                              // workers exist: they are replaced
+  if (pool.size() != 4) die("set_cpus changed the size");
+  {
+    amcx::AffinityGuard g(want);
+    if (!g.bound()) die("guard did not bind");
+    for (int it = 0; it < 50; ++it) {
+      std::atomic<int> off{0};
+      const std::function<void(int)> job = [&](int) {
+        const int cpu = sched_getcpu();
+        bool in = false;
+        for (int c : ok) in = in || c == cpu;
+        if (!in) off.fetch_add(1);
+      };
+      pool.run(16, job);
+      if (off.load() != 0) die("a part ran outside the bound CPUs", it, off.load());
+    }
+  }
+  cpu_set_t after;
+  CPU_ZERO(&after);
+  pthread_getaffinity_np(pthread_self(), sizeof after, &after);
+  if (!CPU_EQUAL(&mine, &after)) die("the caller's mask did not come back");
+  pool.set_cpus({});                                                // unbound again
+  std::atomic<int> ran{0};
+  const std::function<void(int)> job2 = [&](int) { ran.fetch_add(1); };
+  pool.run(8, job2);
+  if (ran.load() != 8) die("unbound pool lost parts");
+  amcx::AffinityGuard none((std::vector<int>()));
+  if (none.bound()) die("empty guard bound");
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -236,8 +307,9 @@ int main(int argc, char** argv) {
   const int files = fuzz_layouts(rng, dir, 60);
   hammer_pool(rng);
   concurrent_pools(rng);
+  placement(dir);
   rmdir(dir);
-  printf("STAGE_FUZZ_OK seed %llu: 60 layouts (%d also from a file, each truncated once), 1000 pool runs, 3 concurrent pools\n",
+  printf("STAGE_FUZZ_OK seed %llu: 60 layouts (%d also from a file, each truncated once), 1000 pool runs, 3 concurrent pools, placement\n",
          seed, files);
   return 0;
 }

@@ -1231,6 +1231,41 @@ def test_device_fan_out_reports_every_failing_device():
         fe.DeviceFanOut(8, [-1])
 
 
+def test_numa_mapper_on_a_fake_sysfs_tree(tmp_path):
+    """Host placement (include/amcx.h, ABI 4): amcx_numa_place reads <sysfs>/bus/pci/devices/<bdf>/{numa_node,
+    local_cpulist}.  A fake tree of two nodes and four devices (two per socket, the SMT siblings in the second range
+    as on the 2-socket EPYC hosts of an MI355X node) must give each device its socket's CPU set; a platform that says -1,
+    a device that is not there and a malformed list bind nothing; and staging_threads_per_device splits a node's CPUs
+    among the engines on it -- those of them this process may use at all."""
+    from amcpy_amd import _lib
+    from amcpy_amd.feature_extraction import staging_threads_per_device
+    tree = {"0000:05:00.0": (0, "0-15,32-47"), "0000:15:00.0": (0, "0-15,32-47"),
+            "0000:85:00.0": (1, "16-31,48-63"), "0000:95:00.0": (1, "16-31,48-63"),
+            "0000:a5:00.0": (-1, "0-63"), "0000:b5:00.0": (1, "garbage")}
+    for bdf, (node, cpus) in tree.items():
+        d = tmp_path / "bus" / "pci" / "devices" / bdf
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text(f"{node}\n")
+        (d / "local_cpulist").write_text(cpus + "\n")
+    node0 = list(range(0, 16)) + list(range(32, 48))
+    node1 = list(range(16, 32)) + list(range(48, 64))
+    places = [_lib.numa_place(bdf, str(tmp_path)) for bdf in list(tree)[:4]]
+    assert places == [(0, node0), (0, node0), (1, node1), (1, node1)]
+    assert _lib.numa_place("0000:05:00.0".upper(), str(tmp_path)) == (0, node0)            # HIP may hand out upper case
+    for bdf in ("0000:a5:00.0", "0000:b5:00.0", "0000:ff:00.0", "../../etc", ""):
+        assert _lib.numa_place(bdf, str(tmp_path)) == (-1, []), bdf
+    # every CPU allowed: 32 local CPUs over two engines each -> the wanted 8 (or the default 8); 12 wanted -> 12
+    assert staging_threads_per_device(places, None, allowed=range(64)) == [8, 8, 8, 8]
+    assert staging_threads_per_device(places, 12, allowed=range(64)) == [12, 12, 12, 12]
+    assert staging_threads_per_device(places, 64, allowed=range(64)) == [16, 16, 16, 16]
+    # a cpuset of 0-19: node 0 keeps 16 CPUs (8 each), node 1 only 4 (2 each)
+    assert staging_threads_per_device(places, None, allowed=range(20)) == [8, 8, 2, 2]
+    # nothing local allowed -> the old even split of what is allowed; unknown placement likewise; never below 1
+    assert staging_threads_per_device(places[:2], None, allowed=range(16, 24)) == [4, 4]
+    assert staging_threads_per_device([(-1, [])] * 4, None, allowed=range(8)) == [2, 2, 2, 2]
+    assert staging_threads_per_device([(-1, [])] * 4, None, allowed=range(2)) == [1, 1, 1, 1]
+
+
 def test_extract_cli_device_arguments(tmp_path):
     from amcpy_amd import main as cli
     assert cli._parse_devices("0,1,3") == [0, 1, 3] and cli._parse_devices("2") == [2] and cli._parse_devices("0,0") == [0, 0]
