@@ -103,13 +103,14 @@ class FileComplex:
     """A complex ``(n_snr, n_frames, L)`` container that is still in its FILE: the byte offsets of its real and
     imaginary arrays (column-major float32 / float64, how a level-5 .mat stores an uncompressed complex variable;
     ``imag_offset`` None: a real signal), or of ONE interleaved complex array (``interleaved=True``: a raw
-    complex64 / complex128 stream, C-ordered).  Nothing is read or mapped here: the engine's staging threads pread
+    complex64 / complex128 stream, C-ordered; with ``order="F"`` the {real, imag} compound dataset of a MATLAB -v7.3
+    file, whose bytes are the column-major variable).  Nothing is read or mapped here: the engine's staging threads pread
     the file block by block on their way to the pinned slots (``amcx_ctx_features18_strided_file``), so the
     variable never exists in host memory outside the page cache.  Indexing (tests, injected engines) goes
     through a memory mapping.  ``release()`` closes the descriptor."""
 
     def __init__(self, path, store_dtype, shape, real_offset: int, imag_offset: Optional[int] = None, *,
-                 interleaved: bool = False):
+                 interleaved: bool = False, order: Optional[str] = None):
         self.path = Path(path)
         self.store = np.dtype(store_dtype)
         self.interleaved = bool(interleaved)
@@ -121,12 +122,15 @@ class FileComplex:
         self.real_offset, self.imag_offset = int(real_offset), (None if imag_offset is None else int(imag_offset))
         self.dtype = self.store if self.interleaved else \
             np.dtype(np.complex64 if self.store == np.float32 else np.complex128)
-        # element strides: column-major for the split arrays of a .mat, row-major for a raw stream
+        # element strides: column-major for the split arrays of a .mat (and a -v7.3 compound), row-major for a raw stream
+        self.order = order if order is not None else ("C" if self.interleaved else "F")
+        if self.order not in ("C", "F"):
+            raise ValueError("order is 'C' or 'F'")
         st, acc = [], 1
-        for n in (self.shape if not self.interleaved else self.shape[::-1]):
+        for n in (self.shape if self.order == "F" else self.shape[::-1]):
             st.append(acc)
             acc *= n
-        self.strides_elems = tuple(st if not self.interleaved else st[::-1])
+        self.strides_elems = tuple(st if self.order == "F" else st[::-1])
         self.source = "file"
         self._fd, self._view, self._lock = None, None, threading.Lock()
 
@@ -151,13 +155,12 @@ class FileComplex:
 
     def _mapped(self):
         if self._view is None:
-            order = "C" if self.interleaved else "F"
-            re = np.memmap(self.path, dtype=self.store, mode="r", offset=self.real_offset, shape=self.shape, order=order)
+            re = np.memmap(self.path, dtype=self.store, mode="r", offset=self.real_offset, shape=self.shape, order=self.order)
             if self.interleaved:
                 self._view = re
             else:
                 im = None if self.imag_offset is None else \
-                    np.memmap(self.path, dtype=self.store, mode="r", offset=self.imag_offset, shape=self.shape, order="F")
+                    np.memmap(self.path, dtype=self.store, mode="r", offset=self.imag_offset, shape=self.shape, order=self.order)
                 self._view = SplitComplex(re, im)
         return self._view
 

@@ -9,8 +9,10 @@ chunked and deflate-compressed datasets all read the same way.
         x = fh["X"]                  # .shape, .dtype, x[a:b] -> numpy array of rows a .. b-1
         feats = extract_iq_pairs(x)
 
-Not a general binding: simple (non-compound) integer and IEEE float element types, whole rows along axis 0.
-`create_dataset` exists for the tests, which need a genuine HDF5 file to read back.
+Not a general binding: integer and IEEE float element types, plus the one compound MATLAB's ``-v7.3`` files use for
+complex arrays -- ``{real, imag}`` of two equal floats, read as complex64 / complex128 (amcpy_amd/matfile.py) --, whole
+rows along axis 0, string attributes (``MATLAB_class``).  `create_dataset` exists for the tests, which need a genuine
+HDF5 file to read back.
 
 The library is found through AMCX_LIBHDF5 (a path), ctypes.util.find_library("hdf5"), then the usual install
 locations; `available()` says whether one loaded.  Builds of libhdf5 are usually NOT thread-safe: every call into it
@@ -39,7 +41,7 @@ herr_t = ctypes.c_int
 H5F_ACC_RDONLY, H5F_ACC_TRUNC = 0, 2
 H5P_DEFAULT, H5S_ALL = 0, 0
 H5S_SELECT_SET = 0
-H5T_INTEGER, H5T_FLOAT = 0, 1
+H5T_INTEGER, H5T_FLOAT, H5T_STRING, H5T_COMPOUND = 0, 1, 3, 6
 H5T_SGN_NONE = 0
 H5T_ORDER_LE, H5T_ORDER_BE = 0, 1
 H5D_CHUNKED = 2
@@ -119,6 +121,19 @@ def _declare(lib):
         "H5Tget_size": (ctypes.c_size_t, [hid_t]),
         "H5Tget_sign": (ctypes.c_int, [hid_t]),
         "H5Tget_order": (ctypes.c_int, [hid_t]),
+        "H5Tcreate": (hid_t, [ctypes.c_int, ctypes.c_size_t]),
+        "H5Tinsert": (herr_t, [hid_t, ctypes.c_char_p, ctypes.c_size_t, hid_t]),
+        "H5Tget_nmembers": (ctypes.c_int, [hid_t]),
+        "H5Tget_member_name": (ctypes.c_void_p, [hid_t, ctypes.c_uint]),
+        "H5Tget_member_type": (hid_t, [hid_t, ctypes.c_uint]),
+        "H5Tget_member_offset": (ctypes.c_size_t, [hid_t, ctypes.c_uint]),
+        "H5Tis_variable_str": (ctypes.c_int, [hid_t]),
+        "H5free_memory": (herr_t, [ctypes.c_void_p]),
+        "H5Aexists": (ctypes.c_int, [hid_t, ctypes.c_char_p]),
+        "H5Aopen": (hid_t, [hid_t, ctypes.c_char_p, hid_t]),
+        "H5Aget_type": (hid_t, [hid_t]),
+        "H5Aread": (herr_t, [hid_t, hid_t, ctypes.c_void_p]),
+        "H5Aclose": (herr_t, [hid_t]),
         "H5Pcreate": (hid_t, [hid_t]),
         "H5Pclose": (herr_t, [hid_t]),
         "H5Pset_chunk": (herr_t, [hid_t, ctypes.c_int, P(hsize_t)]),
@@ -205,13 +220,17 @@ class Dataset:
         tid = lib.H5Dget_type(self._id)
         try:
             cls, size = lib.H5Tget_class(tid), int(lib.H5Tget_size(tid))
+            self.complex_pair = False
             if cls == H5T_FLOAT and size in (4, 8):
                 self.dtype = np.dtype(f"f{size}")
+                self.little_endian = lib.H5Tget_order(tid) == H5T_ORDER_LE
             elif cls == H5T_INTEGER and size in (1, 2, 4, 8):
                 self.dtype = np.dtype(("u" if lib.H5Tget_sign(tid) == H5T_SGN_NONE else "i") + str(size))
+                self.little_endian = lib.H5Tget_order(tid) == H5T_ORDER_LE
+            elif cls == H5T_COMPOUND:
+                self._describe_pair(lib, tid, size, name)
             else:
                 raise TypeError(f"{name!r}: element class {cls} of {size} bytes is not handled by hdf5_min")
-            self.little_endian = lib.H5Tget_order(tid) == H5T_ORDER_LE
         finally:
             lib.H5Tclose(tid)
         # a CONTIGUOUS dataset's bytes lie in one run of the file (no chunks, no filters): where, or None.  The engine's
@@ -239,13 +258,71 @@ class Dataset:
             finally:
                 lib.H5Pclose(dcpl)
 
+    def _describe_pair(self, lib, tid: int, size: int, name: str) -> None:
+        """The compound MATLAB -v7.3 stores a complex array as: members ``real`` at 0 and ``imag`` behind it, two equal
+        IEEE floats, nothing else -- element bytes = one interleaved complex number."""
+        members = []
+        for i in range(max(0, lib.H5Tget_nmembers(tid))):
+            raw = lib.H5Tget_member_name(tid, i)
+            mname = ctypes.string_at(raw).decode("latin-1") if raw else ""
+            if raw:
+                lib.H5free_memory(raw)
+            mt = lib.H5Tget_member_type(tid, i)
+            try:
+                members.append((mname, int(lib.H5Tget_member_offset(tid, i)), lib.H5Tget_class(mt), int(lib.H5Tget_size(mt)),
+                                lib.H5Tget_order(mt) == H5T_ORDER_LE))
+            finally:
+                lib.H5Tclose(mt)
+        ok = (len(members) == 2 and [m[0] for m in members] == ["real", "imag"] and all(m[2] == H5T_FLOAT for m in members)
+              and members[0][3] == members[1][3] and members[0][3] in (4, 8)
+              and members[0][1] == 0 and members[1][1] == members[0][3] and size == 2 * members[0][3])
+        if not ok:
+            raise TypeError(f"{name!r}: a compound other than MATLAB's {{real, imag}} pair is not handled by hdf5_min: {members}")
+        self.complex_pair = True
+        self.dtype = np.dtype(f"c{size}")
+        self.little_endian = members[0][4] and members[1][4]
+
+    def _memory_type(self, lib):
+        """(type id for H5Dread into ``self.dtype``, whether it must be closed)."""
+        if not self.complex_pair:
+            return _native_type(lib, self.dtype), False
+        part = np.dtype(f"f{self.dtype.itemsize // 2}")
+        tid = lib.H5Tcreate(H5T_COMPOUND, self.dtype.itemsize)
+        lib.H5Tinsert(tid, b"real", 0, _native_type(lib, part))
+        lib.H5Tinsert(tid, b"imag", part.itemsize, _native_type(lib, part))
+        return tid, True
+
+    def attr_string(self, name: str) -> Optional[str]:
+        """A fixed-length string attribute of the dataset (``MATLAB_class``), or None if there is none of that kind."""
+        lib = _lib()
+        with _LOCK:
+            if self._id < 0:
+                raise ValueError("dataset of a closed file")
+            if lib.H5Aexists(self._id, name.encode()) <= 0:
+                return None
+            aid = lib.H5Aopen(self._id, name.encode(), H5P_DEFAULT)
+            if aid < 0:
+                return None
+            tid = lib.H5Aget_type(aid)
+            try:
+                if lib.H5Tget_class(tid) != H5T_STRING or lib.H5Tis_variable_str(tid) > 0:
+                    return None
+                n = int(lib.H5Tget_size(tid))
+                buf = ctypes.create_string_buffer(n + 1)
+                if lib.H5Aread(aid, tid, buf) < 0:
+                    return None
+                return buf.raw[:n].split(b"\0", 1)[0].decode("latin-1").strip()
+            finally:
+                lib.H5Tclose(tid)
+                lib.H5Aclose(aid)
+
     @property
     def _parallel_chunks(self) -> bool:
         """Chunks of whole rows whose filters are at most shuffle + deflate, native little-endian elements: the raw chunks
         can be fetched from the library (cheap, under the lock) and inflated on several threads outside it."""
         lib = _lib()
         return (getattr(lib, "_amcx_raw_chunks", False) and self.chunks is not None and self.little_endian
-                and self.chunks[1:] == self.shape[1:] and len(self.filters) > 0
+                and not self.complex_pair and self.chunks[1:] == self.shape[1:] and len(self.filters) > 0
                 and self.filters in ((H5Z_FILTER_DEFLATE,), (H5Z_FILTER_SHUFFLE, H5Z_FILTER_DEFLATE)))
 
     def _read_chunks(self, lo: int, hi: int, out: np.ndarray) -> None:
@@ -262,12 +339,17 @@ class Dataset:
 
         def one(k: int) -> None:
             coord = _dims((k * rows,) + (0,) * (len(self.shape) - 1))
+            a, b = max(lo, k * rows), min(hi, (k + 1) * rows)
             with _LOCK:
                 if self._id < 0:
                     raise ValueError("dataset of a closed file")
+                lib.H5Eset_auto2(hid_t(0), None, None)       # the error stack's printer is per thread: quiet on this one too
                 stored = hsize_t(0)
-                if lib.H5Dget_chunk_storage_size(self._id, coord, ctypes.byref(stored)) < 0:
-                    raise OSError(f"{self.name!r}: chunk {k} has no storage size")
+                if lib.H5Dget_chunk_storage_size(self._id, coord, ctypes.byref(stored)) < 0 or stored.value == 0:
+                    # a chunk that was never written has no storage (libhdf5 1.10.6 reports that as an error): its rows are
+                    # the dataset's FILL VALUE, which only H5Dread knows
+                    flat[a - lo:b - lo] = self._read_rows(a, b).reshape(b - a, per_row)
+                    return
                 raw = None
                 if stored.value > 0:
                     raw = ctypes.create_string_buffer(int(stored.value))
@@ -275,10 +357,6 @@ class Dataset:
                     if lib.H5Dread_chunk(self._id, H5P_DEFAULT, coord, ctypes.byref(mask), raw) < 0:
                         raise OSError(f"{self._file.path}: reading chunk {k} of {self.name!r} failed")
                     mask = mask.value
-            a, b = max(lo, k * rows), min(hi, (k + 1) * rows)
-            if raw is None:                                   # never written: the fill value (0 by default)
-                flat[a - lo:b - lo] = 0
-                return
             data = raw.raw
             for pos in range(len(self.filters) - 1, -1, -1):  # undo the pipeline back to front; bit `pos` set: skipped
                 if mask & (1 << pos):
@@ -331,21 +409,31 @@ class Dataset:
         if self._parallel_chunks:
             self._read_chunks(lo, hi, out)
             return out
+        return self._read_rows(lo, hi, out)
+
+    def _read_rows(self, lo: int, hi: int, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """Rows lo .. hi-1 with one H5Dread of a hyperslab (the library decodes: any layout, any filter it has, the fill
+        value where nothing was written)."""
+        if out is None:
+            out = np.empty((hi - lo,) + self.shape[1:], dtype=self.dtype)
         lib = _lib()
         with _LOCK:
             if self._id < 0:
                 raise ValueError("dataset of a closed file")
             fspace = lib.H5Dget_space(self._id)
             mspace = lib.H5Screate_simple(len(out.shape), _dims(out.shape), None)
+            mtype, close_mtype = self._memory_type(lib)
             try:
                 start = _dims((lo,) + (0,) * (len(self.shape) - 1))
                 if lib.H5Sselect_hyperslab(fspace, H5S_SELECT_SET, start, None, _dims(out.shape), None) < 0:
                     raise OSError(f"{self.name!r}: selecting rows {lo}:{hi} failed")
-                if lib.H5Dread(self._id, _native_type(lib, self.dtype), mspace, fspace, H5P_DEFAULT,
+                if lib.H5Dread(self._id, mtype, mspace, fspace, H5P_DEFAULT,
                                out.ctypes.data_as(ctypes.c_void_p)) < 0:
                     raise OSError(f"{self._file.path}: reading rows {lo}:{hi} of {self.name!r} failed "
                                   "(file cut short, or a filter this libhdf5 lacks)")
             finally:
+                if close_mtype:
+                    lib.H5Tclose(mtype)
                 lib.H5Sclose(mspace)
                 lib.H5Sclose(fspace)
         return out

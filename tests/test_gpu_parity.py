@@ -1268,6 +1268,15 @@ def _check_two_rank_line(stdout):
     assert abs(total - 2 * per_rank * 3) < 1e-3 * total, (total, rec["value"], rec["ms_per_step"])
     assert rec["roofline"]["launch_ms_min"] <= rec["roofline"]["launch_ms_median"] <= rec["roofline"]["launch_ms_max"]
     assert rec["gather"]["rows_on_rank0"] == 2 * per_rank and rec["gather"]["bytes_per_rank"] == per_rank * 72, rec["gather"]
+    # round 5: the line says which rank / device was slow, and carries the one-process fan-out over the same devices
+    pr = rec["per_rank"]
+    assert [r["rank"] for r in pr] == [0, 1] and all(r["dev"] == 0 and r["frames"] == per_rank for r in pr), pr
+    assert all(r["bus"] and 0 < r["ms_min"] <= r["ms_mean"] <= r["ms_max"] and r["wall_s"] > 0 for r in pr), pr
+    assert all(r["fma_G"] and 100 < r["fma_G"] < 3000 for r in pr), pr
+    assert 0 < rec["scaling_efficiency"] <= 1.05 and 0 < rec["rank_balance"] <= 1.0, (rec["scaling_efficiency"], rec["rank_balance"])
+    fo = rec["h2d_fanout"]
+    assert "error" not in fo and fo["devices"] == [0, 0] and fo["GBps"] > 0 and len(fo["per_device_seconds"]) == 2, fo
+    assert sum(fo["per_device_frames"]) == 26 * 64 and [p["pci_bus_id"] for p in fo["placement"]] == [pr[0]["bus"]] * 2, fo
     return rec
 
 
@@ -1333,6 +1342,42 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
                              env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
         assert bad.returncode != 0 and "no GPU of its own" in bad.stderr, bad.stderr[-2000:]
         assert not [ln for ln in bad.stdout.splitlines() if ln.strip()], bad.stdout
+
+
+def test_fma_ceiling_probe_and_host_placement_on_this_box():
+    """ABI 4 on the device.  amcx_probe_fma_rate: the board's instruction-issue ceiling under its power cap -- between
+    the ~850 G wave-instructions/s rounds 1-4 measured under load and the 256 CUs x 4 SIMDs x 2.4 GHz / 2.0 cycles
+    ~ 1 230 G an uncapped chip could issue -- at a clock inside the part's range.  Placement: a context knows its
+    device's PCI bus id; where the kernel's tree names a NUMA node the staging threads are bound to CPUs this process
+    may use (never more than the node has), where it says -1 nothing is bound; an explicit binding is honoured and
+    results do not depend on any of it."""
+    torch = _torch()
+    from amcpy_amd import _lib
+    from amcpy_amd import feature_extraction as fe
+    got = _lib.probe_fma_rate(0.4, torch.cuda.current_stream().cuda_stream)
+    assert 400e9 < got["wave_instr_per_s"] < 1400e9 and 1.0 < got["clock_GHz"] < 2.6, got
+    bus = _lib.device_pci_bus_id(0)
+    assert len(bus.split(":")) == 3 and bus == bus.lower()
+    node, cpus = _lib.numa_place(bus)
+    rng = np.random.default_rng(11)
+    box = np.asfortranarray((rng.standard_normal((3, 40, 2048)) + 1j * rng.standard_normal((3, 40, 2048))))   # 3.9 MB: threaded path
+    rows = fe.FrameRows(box, 3, 40)
+    eng = fe.HipEngine(2048, 0, threads=4)
+    ref = eng(rows)
+    pl = eng._context().placement()
+    assert pl["pci_bus_id"] == bus and pl["device"] == 0 and pl["numa_node"] == node and pl["n_cpus"] == len(cpus)
+    assert pl["n_cpus_allowed"] <= pl["n_cpus"]
+    before = os.sched_getaffinity(0)
+    two = sorted(before)[:2]
+    eng._context().bind_cpus(two)
+    assert eng._context().placement()["n_cpus"] == len(two)
+    again = eng(rows)
+    assert os.sched_getaffinity(0) == before                         # the caller's own mask came back
+    eng._context().bind_cpus([])
+    unbound = eng(rows)
+    assert eng._context().placement()["numa_node"] == -1
+    assert np.array_equal(ref.view(np.int32), again.view(np.int32)) and np.array_equal(ref.view(np.int32), unbound.view(np.int32))
+    eng.close()
 
 
 def test_strided_engine_on_random_layouts():
