@@ -805,17 +805,44 @@ def _placement(world: int, device: Optional[int]) -> bool:
     return len({h for h, _ in where}) == 1
 
 
-def _already_extracted(out_path: Path, key: str, shape) -> bool:
+def _provenance(cfg: Config, mat_path: Path, key: str) -> dict:
+    """What a feature file was computed FROM and FOR: the shape (n_snr, n_frames, 18) says neither the frame size nor
+    which SNR labels or which input container -- a file written for another ``--frame-size``, or for a container that
+    has since been replaced, has the right shape and stale numbers."""
+    try:
+        st = Path(mat_path).stat()
+        src = {"input_size": st.st_size, "input_mtime_ns": st.st_mtime_ns}
+    except OSError:
+        src = {"input_size": None, "input_mtime_ns": None}
+    return {"frame_size": int(cfg.signals.frame_size), "num_frames": int(cfg.signals.num_frames),
+            "snr_values": [[int(k), str(v)] for k, v in cfg.signals.snr_values.items()],
+            "input": str(Path(mat_path).name), "variable": key, **src}
+
+
+def _provenance_path(out_path: Path) -> Path:
+    """Beside the feature file, not inside it: the .mat keeps exactly the two variables the reference writes
+    (feature_extraction.py:77-81), which is what its downstream loaders see."""
+    return out_path.with_name(out_path.stem + ".provenance.json")
+
+
+def _already_extracted(out_path: Path, key: str, shape, provenance: Optional[dict] = None) -> bool:
     """True if ``out_path`` is a complete feature file for this configuration: it holds ``key`` as a float32 array
-    of ``shape`` (and the ``Modulation`` string).  Only the variable headers are read (``scipy.io.whosmat``); a file
-    that is cut short, or was written for another frame count or SNR grid, does not qualify."""
+    of ``shape`` (and the ``Modulation`` string) -- only the variable headers are read (``scipy.io.whosmat``) -- AND the
+    provenance record written beside it equals ``provenance`` (frame size, SNR labels, frame count, the input
+    container's name, size and modification time).  A file that is cut short, was written for another frame size / SNR
+    grid / container, or has no record (written before records existed, or by the reference) does not qualify."""
+    import json
     import scipy.io
     try:
         seen = {name: (tuple(shp), cls) for name, shp, cls in scipy.io.whosmat(str(out_path))}
         if seen.get(key) != (tuple(shape), "single") or "Modulation" not in seen:
             return False
         size = out_path.stat().st_size
-        return size >= 4 * int(np.prod(shape))             # the array's bytes are really there
+        if size < 4 * int(np.prod(shape)):                  # the array's bytes are really there
+            return False
+        if provenance is None:
+            return True
+        return json.loads(_provenance_path(out_path).read_text()) == provenance
     except Exception:
         return False
 
@@ -826,8 +853,9 @@ def run_extraction(cfg: Config, *, compute=None, device: Optional[int] = None, d
     ``{mod}_features.mat`` per entry of ``cfg.signals.modulations_with_noise``.
     ``devices``: several GPU indices driven from THIS process (:class:`DeviceFanOut`; not together with a process
     group of several ranks, where every rank has its one ``device``).
-    ``resume``: modulations whose feature file is already there, complete and of this configuration's shape, are
-    skipped -- the per-modulation file is the path's natural resume unit (the reference recomputes everything,
+    ``resume``: modulations whose feature file is already there, complete, of this configuration's shape AND recorded
+    (``{mod}_features.provenance.json`` beside it) as computed for this frame size, these SNR labels and this very input
+    container (name, size, modification time) are skipped -- the per-modulation file is the path's natural resume unit (the reference recomputes everything,
     all-or-nothing per file; a file is written by ONE savemat call at the end of its modulation, here as there)."""
     import scipy.io
 
@@ -857,7 +885,8 @@ def run_extraction(cfg: Config, *, compute=None, device: Optional[int] = None, d
         if rank == 0:
             shape = (len(cfg.signals.snr_values), cfg.signals.num_frames, 18)
             todo = [m for m in mods if not _already_extracted(cfg.paths.calculated_features / f"{m}_features.mat",
-                                                              cfg.signals.mat_info[m], shape)]
+                                                              cfg.signals.mat_info[m], shape,
+                                                              _provenance(cfg, mat_path, cfg.signals.mat_info[m]))]
             if verbose and len(todo) < len(mods):
                 print(f"resume: {len(mods) - len(todo)} of {len(mods)} feature files are complete, computing {todo}")
         if world > 1:                                       # every rank loops over the same modulations
@@ -879,9 +908,12 @@ def run_extraction(cfg: Config, *, compute=None, device: Optional[int] = None, d
         # written aside and renamed: an interrupted run never leaves a partial file under the final name (what
         # resume= and every downstream loader look at)
         tmp_path = out_path.with_name(f"{out_path.stem}.{os.getpid()}.tmp.mat")
+        record = _provenance_path(out_path)
         try:
+            record.unlink(missing_ok=True)                  # never a fresh record beside an old file, or an old one beside a new
             scipy.io.savemat(str(tmp_path), {"Modulation": mod, key: feats})
             os.replace(tmp_path, out_path)
+            record.write_text(__import__("json").dumps(provenance[mod]) + "\n")
         finally:
             tmp_path.unlink(missing_ok=True)
         if verbose:
@@ -891,6 +923,9 @@ def run_extraction(cfg: Config, *, compute=None, device: Optional[int] = None, d
     # uncompressed variables go from the file to the pinned slots inside the native engine (AMCX_DIRECT_FILE=0: read /
     # map them in Python first, the round-3 path kept for A/B runs); an injected engine gets arrays
     direct = compute is None and os.environ.get("AMCX_DIRECT_FILE", "1") != "0"
+    # what each file is computed from, taken BEFORE the container is read: a container replaced mid-run leaves a record
+    # that no longer matches it
+    provenance = {m: _provenance(cfg, mat_path, cfg.signals.mat_info[m]) for m in mods}
     writer = ThreadPoolExecutor(max_workers=1, thread_name_prefix="amcx-writer") if rank == 0 else None
     writes = []
     published: List[Path] = []          # rank 0: shared files not yet removed

@@ -318,45 +318,47 @@ class Dataset:
 
     @property
     def _parallel_chunks(self) -> bool:
-        """Chunks of whole rows whose filters are at most shuffle + deflate, native little-endian elements: the raw chunks
-        can be fetched from the library (cheap, under the lock) and inflated on several threads outside it."""
+        """Chunks whose filters are at most shuffle + deflate, little-endian elements: the raw chunks can be fetched from
+        the library (cheap, under the lock) and inflated on several threads outside it.  (MATLAB's -v7.3 default is
+        chunked + deflate with a chunk shape of its own choosing; RadioML's is chunks of whole rows.)"""
         lib = _lib()
         return (getattr(lib, "_amcx_raw_chunks", False) and self.chunks is not None and self.little_endian
-                and not self.complex_pair and self.chunks[1:] == self.shape[1:] and len(self.filters) > 0
+                and len(self.filters) > 0
                 and self.filters in ((H5Z_FILTER_DEFLATE,), (H5Z_FILTER_SHUFFLE, H5Z_FILTER_DEFLATE)))
 
     def _read_chunks(self, lo: int, hi: int, out: np.ndarray) -> None:
         """Rows lo .. hi-1 into ``out`` chunk by chunk: H5Dread_chunk hands over a chunk as it is stored, zlib inflates it and
         the byte shuffle is undone here, on a few threads (zlib and numpy release the GIL) -- libhdf5's own H5Dread inflates
-        on the calling thread, under this module's lock."""
+        on the calling thread, under this module's lock.  Any chunk grid: a chunk lands in the block of ``out`` it covers."""
+        import itertools
         import zlib
         from concurrent.futures import ThreadPoolExecutor
         lib = _lib()
-        rows, item = self.chunks[0], self.dtype.itemsize
-        per_row = int(np.prod(self.shape[1:], dtype=np.int64)) if len(self.shape) > 1 else 1
-        chunk_bytes = rows * per_row * item
-        flat = out.reshape(hi - lo, per_row)
+        cshape, item = self.chunks, self.dtype.itemsize
+        chunk_bytes = int(np.prod(cshape, dtype=np.int64)) * item
 
-        def one(k: int) -> None:
-            coord = _dims((k * rows,) + (0,) * (len(self.shape) - 1))
-            a, b = max(lo, k * rows), min(hi, (k + 1) * rows)
+        def one(index) -> None:
+            origin = tuple(i * c for i, c in zip(index, cshape))
+            coord = _dims(origin)
+            # the part of the chunk inside the dataset and inside [lo, hi)
+            begin = (max(lo, origin[0]),) + origin[1:]
+            end = (min(hi, origin[0] + cshape[0]),) + tuple(min(n, o + c) for n, o, c in zip(self.shape[1:], origin[1:], cshape[1:]))
+            dst = (slice(begin[0] - lo, end[0] - lo),) + tuple(slice(a, b) for a, b in zip(begin[1:], end[1:]))
             with _LOCK:
                 if self._id < 0:
                     raise ValueError("dataset of a closed file")
                 lib.H5Eset_auto2(hid_t(0), None, None)       # the error stack's printer is per thread: quiet on this one too
                 stored = hsize_t(0)
                 if lib.H5Dget_chunk_storage_size(self._id, coord, ctypes.byref(stored)) < 0 or stored.value == 0:
-                    # a chunk that was never written has no storage (libhdf5 1.10.6 reports that as an error): its rows are
-                    # the dataset's FILL VALUE, which only H5Dread knows
-                    flat[a - lo:b - lo] = self._read_rows(a, b).reshape(b - a, per_row)
+                    # a chunk that was never written has no storage (libhdf5 1.10.6 reports that as an error): its elements
+                    # are the dataset's FILL VALUE, which only H5Dread knows
+                    out[dst] = self._read_hyperslab(begin, tuple(b - a for a, b in zip(begin, end)))
                     return
-                raw = None
-                if stored.value > 0:
-                    raw = ctypes.create_string_buffer(int(stored.value))
-                    mask = ctypes.c_uint32(0)
-                    if lib.H5Dread_chunk(self._id, H5P_DEFAULT, coord, ctypes.byref(mask), raw) < 0:
-                        raise OSError(f"{self._file.path}: reading chunk {k} of {self.name!r} failed")
-                    mask = mask.value
+                raw = ctypes.create_string_buffer(int(stored.value))
+                mask = ctypes.c_uint32(0)
+                if lib.H5Dread_chunk(self._id, H5P_DEFAULT, coord, ctypes.byref(mask), raw) < 0:
+                    raise OSError(f"{self._file.path}: reading chunk {index} of {self.name!r} failed")
+                mask = mask.value
             data = raw.raw
             for pos in range(len(self.filters) - 1, -1, -1):  # undo the pipeline back to front; bit `pos` set: skipped
                 if mask & (1 << pos):
@@ -369,18 +371,21 @@ class Dataset:
                     n = len(data) // item
                     data = np.frombuffer(data, dtype=np.uint8, count=n * item).reshape(item, n).T.tobytes()
             if len(data) != chunk_bytes:
-                raise OSError(f"{self.name!r}: chunk {k} decodes to {len(data)} bytes, expected {chunk_bytes}")
-            block = np.frombuffer(data, dtype=self.dtype).reshape(rows, per_row)
-            flat[a - lo:b - lo] = block[a - k * rows:b - k * rows]
+                raise OSError(f"{self.name!r}: chunk {index} decodes to {len(data)} bytes, expected {chunk_bytes}")
+            block = np.frombuffer(data, dtype=self.dtype).reshape(cshape)
+            src = tuple(slice(a - o, b - o) for a, b, o in zip(begin, end, origin))
+            out[dst] = block[src]
 
-        ks = range(lo // rows, (hi - 1) // rows + 1)
-        workers = min(len(ks), max(1, min(8, (os.cpu_count() or 2))))
+        grid = [range(lo // cshape[0], (hi - 1) // cshape[0] + 1)] + \
+               [range((n + c - 1) // c) for n, c in zip(self.shape[1:], cshape[1:])]
+        todo = list(itertools.product(*grid))
+        workers = min(len(todo), max(1, min(8, (os.cpu_count() or 2))))
         if workers <= 1:
-            for k in ks:
-                one(k)
+            for index in todo:
+                one(index)
         else:
             with ThreadPoolExecutor(max_workers=workers, thread_name_prefix="amcx-h5") as ex:
-                list(ex.map(one, ks))
+                list(ex.map(one, todo))
 
     def __len__(self) -> int:
         return self.shape[0]
@@ -412,10 +417,13 @@ class Dataset:
         return self._read_rows(lo, hi, out)
 
     def _read_rows(self, lo: int, hi: int, out: Optional[np.ndarray] = None) -> np.ndarray:
-        """Rows lo .. hi-1 with one H5Dread of a hyperslab (the library decodes: any layout, any filter it has, the fill
-        value where nothing was written)."""
+        """Rows lo .. hi-1 with one H5Dread (the library decodes: any layout, any filter it has, the fill value where
+        nothing was written)."""
+        return self._read_hyperslab((lo,) + (0,) * (len(self.shape) - 1), (hi - lo,) + self.shape[1:], out)
+
+    def _read_hyperslab(self, start, count, out: Optional[np.ndarray] = None) -> np.ndarray:
         if out is None:
-            out = np.empty((hi - lo,) + self.shape[1:], dtype=self.dtype)
+            out = np.empty(tuple(count), dtype=self.dtype)
         lib = _lib()
         with _LOCK:
             if self._id < 0:
@@ -424,12 +432,11 @@ class Dataset:
             mspace = lib.H5Screate_simple(len(out.shape), _dims(out.shape), None)
             mtype, close_mtype = self._memory_type(lib)
             try:
-                start = _dims((lo,) + (0,) * (len(self.shape) - 1))
-                if lib.H5Sselect_hyperslab(fspace, H5S_SELECT_SET, start, None, _dims(out.shape), None) < 0:
-                    raise OSError(f"{self.name!r}: selecting rows {lo}:{hi} failed")
+                if lib.H5Sselect_hyperslab(fspace, H5S_SELECT_SET, _dims(start), None, _dims(out.shape), None) < 0:
+                    raise OSError(f"{self.name!r}: selecting {tuple(count)} at {tuple(start)} failed")
                 if lib.H5Dread(self._id, mtype, mspace, fspace, H5P_DEFAULT,
                                out.ctypes.data_as(ctypes.c_void_p)) < 0:
-                    raise OSError(f"{self._file.path}: reading rows {lo}:{hi} of {self.name!r} failed "
+                    raise OSError(f"{self._file.path}: reading {tuple(count)} at {tuple(start)} of {self.name!r} failed "
                                   "(file cut short, or a filter this libhdf5 lacks)")
             finally:
                 if close_mtype:

@@ -73,15 +73,25 @@ def _run_as_rank(cfg, args) -> None:
         dev = local % max(1, n_dev)
     else:
         dev = local
-    if dev >= n_dev:
-        raise SystemExit(f"rank {rank}: no GPU {dev} ({n_dev} visible); one rank per GPU, or AMCX_SHARE_GPU=1")
-    torch.cuda.set_device(dev)
+    problem = None if dev < n_dev else f"rank {rank}: no GPU {dev} ({n_dev} visible); one rank per GPU, or AMCX_SHARE_GPU=1"
     backend = os.environ.get("AMCX_DIST_BACKEND", "nccl")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # Every rank says whether it can take part BEFORE the process group exists: a rank that has no device must not leave
+    # the others waiting in the rendezvous until the store times out (a launcher that tears the job down on the first
+    # failure hides this; one that does not, hangs).  The launcher's store carries one status word per rank.
+    # (torch's own env:// rendezvous: it knows whether the launcher's agent already serves the store -- torch.distributed.run
+    # does -- or rank 0 has to)
+    store, _, _ = next(dist.rendezvous("env://", rank=rank, world_size=world))
+    store.set(f"amcx/status/{rank}", problem or "ok")
+    problems = [store.get(f"amcx/status/{r}").decode() for r in range(world)]         # get() waits for the key
+    problems = [q for q in problems if q != "ok"]
+    if problems:
+        raise SystemExit("; ".join(problems))
+    torch.cuda.set_device(dev)
     if backend == "nccl":
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+        dist.init_process_group("nccl", store=store, rank=rank, world_size=world, device_id=torch.device("cuda", dev))
     else:
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        dist.init_process_group(backend, store=store, rank=rank, world_size=world)
     try:
         run_extraction(cfg, device=dev, verbose=rank == 0, resume=args.resume)
     finally:

@@ -19,8 +19,16 @@ in the second word) and data padded to 8 bytes.  miMATRIX (14) holds sub-element
 (class in byte 0, complex = bit 0x0800), dimensions (int32), name (int8), real part, imaginary
 part.  miCOMPRESSED (15) wraps one zlib-deflated miMATRIX.  Anything this reader does not take on
 -- big-endian files, integer-compressed numeric data, sparse / cell / struct / char variables, level
-4 or 7.3 (HDF5) files -- goes to ``scipy.io.loadmat``, whose result for the variable is returned
-as it is.
+4 files -- goes to ``scipy.io.loadmat``, whose result for the variable is returned as it is.
+
+``-v7.3`` files are HDF5 behind a 512-byte MATLAB header, and the only form MATLAB has for a variable above 2 GB -- one
+BASELINE configs[1] modulation is 3.49 GB of complex128.  ``scipy.io.loadmat`` refuses them ("Please use HDF reader"),
+and so does the reference (feature_extraction.py:46-47).  :func:`load_variable_v73` reads them through
+:mod:`amcpy_amd.hdf5_min`: a variable is a root-level dataset with its dimensions reversed (the bytes are the
+column-major variable), a complex one the compound ``{real, imag}``, the class in the ``MATLAB_class`` attribute.  A
+CONTIGUOUS dataset is only located (``H5Dget_offset``) and read from the file by the engine's staging threads as
+interleaved complex128 / complex64; a chunked or compressed one is decoded by libhdf5.  Classes other than ``double`` /
+``single`` and files without a usable libhdf5 fall through to ``scipy.io.loadmat`` and its own error.
 
 Mapping is free, but the first touch of every mapped page is a minor fault, and those do not scale: 13-18 GB/s
 from one thread, 22 GB/s from eight (`profiles/r3_read_probe.txt`) -- 30 ms for a 436 MB variable whose upload
@@ -285,6 +293,50 @@ def compressed_variable_bytes(mat_path) -> int:
         return 1
 
 
+_HDF5_MAGIC = b"\x89HDF\r\n\x1a\n"
+
+
+def is_v73(mat_path) -> bool:
+    """True for an HDF5 file: the signature at offset 0, or behind the 512-byte header a MATLAB -v7.3 file carries (the
+    format allows a user block of 512, 1024, ... bytes; MATLAB writes 512)."""
+    try:
+        with open(mat_path, "rb") as fh:
+            head = fh.read(520)
+    except OSError:
+        return False
+    return head[:8] == _HDF5_MAGIC or (head[:10] == b"MATLAB 7.3" and head[512:520] == _HDF5_MAGIC)
+
+
+def load_variable_v73(mat_path, key: str, direct: bool = False):
+    """The variable ``key`` of a MATLAB -v7.3 (HDF5) file in MATLAB's shape: a :class:`FileComplex` when ``direct`` and
+    the dataset is contiguous (nothing read: offsets into the file, interleaved complex or one real array, column-major),
+    otherwise a Fortran-ordered complex / real ndarray decoded by libhdf5 -- what ``loadmat`` returns for a level-5 file
+    of the same data.  ``KeyError``: no such variable; ``_Unsupported``: not a double / single numeric array, or no
+    libhdf5 to read it with."""
+    from . import hdf5_min
+    from .feature_extraction import FileComplex
+    if not hdf5_min.available():
+        raise _Unsupported("no HDF5 C library")
+    with hdf5_min.File(mat_path) as fh:
+        if key not in fh:
+            raise KeyError(f"{mat_path} has no variable {key!r}")
+        try:
+            ds = fh[key]
+        except (TypeError, ValueError) as exc:              # a group (struct / cell), a compound that is not {real, imag}
+            raise _Unsupported(str(exc))
+        cls = ds.attr_string("MATLAB_class")
+        want = {"double": 8, "single": 4}.get(cls)
+        part = ds.dtype.itemsize // (2 if ds.complex_pair else 1)
+        if want is None or ds.dtype.kind not in "fc" or part != want:
+            raise _Unsupported(f"MATLAB_class {cls!r} stored as {ds.dtype}")
+        dims = tuple(ds.shape[::-1])                         # MATLAB's shape
+        if direct and len(dims) == 3 and ds.file_offset is not None and ds.little_endian and ds.chunks is None:
+            if ds.complex_pair:
+                return FileComplex(mat_path, ds.dtype, dims, ds.file_offset, interleaved=True, order="F")
+            return FileComplex(mat_path, ds.dtype, dims, ds.file_offset, None)
+        return ds[:].T                                       # (L, K, S) C-ordered -> (S, K, L) Fortran-ordered view
+
+
 def load_variable(mat_path, key: str, pool: Optional[BufferPool] = None, direct: bool = False):
     """One variable of the container.  ``direct``: a :class:`FileComplex` -- offsets into the file, nothing read;
     the engine's staging threads read it (``source == "file"``; uncompressed variables only, anything else falls
@@ -293,6 +345,13 @@ def load_variable(mat_path, key: str, pool: Optional[BufferPool] = None, direct:
     was read into its buffers -- call ``release()`` on the result when done with it) when the fast reader applies,
     otherwise what ``scipy.io.loadmat`` returns for it."""
     from .feature_extraction import FileComplex, SplitComplex
+    if is_v73(mat_path):
+        try:
+            return load_variable_v73(mat_path, key, direct)
+        except _Unsupported:
+            import scipy.io                                     # its own words for a file / class it does not read
+            data = scipy.io.loadmat(str(mat_path), variable_names=[key])
+            return np.asarray(data[key])
     if direct:
         try:
             dt, dims, d_re, d_im = locate_variable_v5(Path(mat_path), key)

@@ -241,16 +241,11 @@ def _pmc_traffic(frames_per_launch: int, frame_size: int):
 
 
 def _parity_block():
-    """Three numbers per frame size, replayed from the committed sweep (tests/manual/parity_sweep.py on the GPU box,
-    builder-run), NOT measured in this run -- the live parity gate is `pytest -m gpu`; the per-feature arrays stay in
-    the profile file."""
-    for name in ("r4_parity_summary.json", "r3_parity_summary.json", "r2_parity_summary.json"):
-        d = _committed_json(name)
-        if d is not None:
-            return {"source": f"profiles/{name} (replayed, not measured in this run)",
-                    "worst_scaled": {n: float(f"{v['worst_scaled']:.3g}") for n, v in d.get("sizes", {}).items()},
-                    "beyond_unfloored": {n: v.get("beyond_unfloored") for n, v in d.get("sizes", {}).items()}}
-    return None
+    """Where parity is established -- not a replay of numbers: the live gate is `pytest -m gpu` (the driver runs it), whose
+    test_full_snr_grid_against_oracle covers 6 modulations x 26 SNRs x 8 frames at N = 1024 / 2048 / 4096 with zero frames
+    beyond the unfloored criterion."""
+    return {"source": "pytest -m gpu (tests/test_gpu_parity.py: golden fixtures, full SNR grid, 1 024-frame samples of the "
+                      "full-size shards); no parity number is replayed into this line"}
 
 
 def _committed_json(name: str):

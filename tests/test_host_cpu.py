@@ -509,6 +509,105 @@ def test_hdf5_min_reads_the_container_h5py_wrote():
         extract_radioml_hdf5(path, key="W", compute=compute)
 
 
+def _mat73_variable(mi: int, mod: str):
+    """The arrays tests/golden/make_mat73_like.py wrote, rebuilt from their seeds (numpy only)."""
+    from amcpy_amd import synth
+    rows = [synth.host_block(mod, snr, 5, 300, seed=7300 + 10 * mi + si).astype(np.complex128) * (1.0 + 1e-9 * (mi + 1))
+            for si, snr in enumerate((0.0, 10.0))]
+    return np.stack(rows)
+
+
+def test_mat73_container_reads_bit_for_bit(tmp_path):
+    """MATLAB -v7.3 containers (HDF5 behind a 512-byte header; the only form MATLAB has for a variable above 2 GB -- one
+    BASELINE configs[1] modulation is 3.49 GB -- and one the reference's loadmat refuses, feature_extraction.py:46-47).
+    tests/golden/mat73_like.mat was written by the real h5py in MATLAB's layout: reversed dimensions, {real, imag}
+    compounds, MATLAB_class attributes; six double-complex variables stored chunked + deflate / chunked / contiguous, a
+    single-complex one, a real one, a char one.  Every numeric variable must come back with the bytes it was written
+    from (SHA-256 in mat73_like.json), through the decoded path and -- contiguous ones -- as offsets into the file; a
+    char variable and a missing one give the reader's own errors; a chunk nobody wrote reads as the fill value."""
+    import hashlib
+    import json
+    from amcpy_amd import hdf5_min, matfile
+    from amcpy_amd.feature_extraction import FileComplex, FrameRows
+    if not hdf5_min.available():
+        pytest.skip("no HDF5 C library on this machine")
+    path = REPO / "tests" / "golden" / "mat73_like.mat"
+    meta = json.loads((REPO / "tests" / "golden" / "mat73_like.json").read_text())
+    assert matfile.is_v73(path) and not matfile.is_v73(REPO / "tests" / "golden" / "kat_n10.json")
+    sha = meta["sha256_column_major"]
+
+    def digest(a):
+        return hashlib.sha256(np.asfortranarray(a).tobytes(order="F")).hexdigest()
+
+    names = ["signal_bpsk", "signal_qpsk", "signal_8psk", "signal_qam16", "signal_qam64", "signal_noise"]
+    for mi, (name, mod) in enumerate(zip(names, ["BPSK", "QPSK", "8PSK", "16QAM", "64QAM", "WGN"])):
+        want = _mat73_variable(mi, mod)
+        assert digest(want) == sha[name]                             # the fixture is what its script says it is
+        got = matfile.load_variable(path, name)
+        assert isinstance(got, np.ndarray) and got.dtype == np.complex128 and got.shape == (2, 5, 300) and got.flags.f_contiguous
+        assert digest(got) == sha[name], name
+        direct = matfile.load_variable(path, name, None, True)
+        if meta["layout"][name] == "contiguous":
+            assert isinstance(direct, FileComplex) and direct.interleaved and direct.order == "F"
+            assert direct.strides_elems == (1, 2, 10) and direct.shape == (2, 5, 300)
+            assert digest(np.asarray(direct[:])) == sha[name]
+            rows = FrameRows(direct, 2, 5)                           # frames as the engine's stand-ins see them
+            assert np.array_equal(rows.to_array(), want.reshape(10, 300))
+            direct.release()
+        else:
+            assert isinstance(direct, np.ndarray) and digest(direct) == sha[name]
+    single = matfile.load_variable(path, "signal_single", None, True)
+    assert isinstance(single, FileComplex) and single.dtype == np.complex64 and digest(np.asarray(single[:])) == sha["signal_single"]
+    assert digest(matfile.load_variable(path, "signal_single")) == sha["signal_single"]
+    real = matfile.load_variable(path, "signal_real")
+    assert real.dtype == np.float64 and digest(real) == sha["signal_real"]
+    real_d = matfile.load_variable(path, "signal_real", None, True)
+    assert isinstance(real_d, FileComplex) and not real_d.interleaved and real_d.imag_offset is None
+    assert np.array_equal(np.asarray(real_d[:]).real, real) and not np.asarray(real_d[:]).imag.any()
+    with pytest.raises(KeyError):
+        matfile.load_variable(path, "signal_absent")
+    with pytest.raises(NotImplementedError, match="v7.3"):          # scipy's own words for what this reader leaves alone
+        matfile.load_variable(path, "note")
+    with hdf5_min.File(path) as fh:
+        part = fh["partly_written"]
+        assert part._parallel_chunks and part.chunks == (8, 6)
+        for sl in (slice(None), slice(3, 30), slice(16, 24)):
+            got = part[sl]
+            assert got.shape[0] == len(range(*sl.indices(40)))
+        assert hashlib.sha256(part[:].tobytes()).hexdigest() == sha["partly_written"]
+        assert (part[0:8] == 2.5).all() and (part[16:32] == 2.5).all() and not (part[8:16] == 2.5).all()
+        assert fh["signal_bpsk"].attr_string("MATLAB_class") == "double" and fh["signal_bpsk"].attr_string("absent") is None
+        assert fh["signal_bpsk"][37:222].shape == (185, 5, 2) and np.array_equal(fh["signal_bpsk"][37:222], fh["signal_bpsk"][:][37:222])
+
+
+def test_run_extraction_takes_a_mat73_container(tmp_path):
+    """run_extraction on the -v7.3 container (stand-in engine, no GPU here) writes the same six feature files as on a
+    level-5 container of the same arrays -- contiguous variables as offsets into the file, compressed ones decoded."""
+    import shutil
+    import scipy.io
+    from amcpy_amd import hdf5_min
+    from amcpy_amd.config import Config, Paths, SignalConfig
+    from amcpy_amd.feature_extraction import run_extraction
+    if not hdf5_min.available():
+        pytest.skip("no HDF5 C library on this machine")
+    outs = {}
+    for kind in ("v73", "v5"):
+        cfg = Config(paths=Paths(root=tmp_path / kind),
+                     signals=SignalConfig(snr_values={0: "0", 1: "10"}, num_frames=5, frame_size=256))
+        cfg.paths.ensure_dirs()
+        target = cfg.paths.mat_data / cfg.paths.mat_filename
+        if kind == "v73":
+            shutil.copy(REPO / "tests" / "golden" / "mat73_like.mat", target)
+        else:
+            scipy.io.savemat(str(target), {cfg.signals.mat_info[m]: _mat73_variable(i, m)
+                                           for i, m in enumerate(cfg.signals.modulations_with_noise)})
+        run_extraction(cfg, compute=lambda x: _marker_features(x[:, :256]), verbose=False)
+        outs[kind] = {m: scipy.io.loadmat(str(cfg.paths.calculated_features / f"{m}_features.mat"))[cfg.signals.mat_info[m]]
+                      for m in cfg.signals.modulations_with_noise}
+    for m, a in outs["v73"].items():
+        assert a.shape == (2, 5, 18) and a.dtype == np.float32 and np.array_equal(a, outs["v5"][m]), m
+
+
 def test_hdf5_min_round_trip_and_concurrent_readers(tmp_path):
     """Files hdf5_min writes itself -- contiguous, chunked, chunked + deflate -- read back bit for bit, also from several
     threads at once (libhdf5 builds are usually not thread-safe: every call is made under one lock; extract_iq_pairs slices
@@ -1485,6 +1584,41 @@ def test_run_extraction_resume_skips_complete_files(tmp_path):
     for m in mods:
         got = scipy.io.loadmat(str(cfg.paths.calculated_features / f"{m}_features.mat"))[cfg.signals.mat_info[m]]
         assert got.dtype == np.float32 and np.array_equal(got, ref[m]), m
+    calls.clear()
+    # round 5 (provenance beside every file): a file of the right SHAPE that was computed for something else is stale.
+    # Another frame size -- the shape (n_snr, n_frames, 18) does not say N:
+    fe.run_extraction(cfg, compute=compute, verbose=False, resume=True)
+    assert calls == []
+    cfg12 = Config(paths=Paths(root=tmp_path), signals=SignalConfig(snr_values={0: "0", 1: "10"}, num_frames=5, frame_size=12))
+    fe.run_extraction(cfg12, compute=lambda b: (calls.append(b.shape[0]), _marker_features(np.asarray(b)[:, :12]))[1],
+                      verbose=False, resume=True)
+    assert len(calls) == len(mods)
+    calls.clear()
+    fe.run_extraction(cfg, compute=compute, verbose=False, resume=True)       # ... and back: all six again
+    assert len(calls) == len(mods)
+    calls.clear()
+    # other SNR labels of the same count
+    cfg_snr = Config(paths=Paths(root=tmp_path), signals=SignalConfig(snr_values={0: "0", 1: "20"}, num_frames=5, frame_size=16))
+    fe.run_extraction(cfg_snr, compute=compute, verbose=False, resume=True)
+    assert len(calls) == len(mods)
+    calls.clear()
+    fe.run_extraction(cfg, compute=compute, verbose=False, resume=True)
+    assert len(calls) == len(mods)
+    calls.clear()
+    # a file without a record (the reference's own output, or an older build's) is not trusted; one whose input
+    # container has been replaced since is not either
+    (cfg.paths.calculated_features / f"{mods[3]}_features.provenance.json").unlink()
+    container = cfg.paths.mat_data / cfg.paths.mat_filename
+    fe.run_extraction(cfg, compute=compute, verbose=False, resume=True)
+    assert len(calls) == 1
+    calls.clear()
+    st = container.stat()
+    os.utime(container, ns=(st.st_atime_ns, st.st_mtime_ns + 5_000_000_000))
+    fe.run_extraction(cfg, compute=compute, verbose=False, resume=True)
+    assert len(calls) == len(mods)
+    # the .mat itself still holds exactly what the reference writes (feature_extraction.py:77-81)
+    keys = {k for k in scipy.io.loadmat(str(cfg.paths.calculated_features / f"{mods[0]}_features.mat")) if not k.startswith("__")}
+    assert keys == {"Modulation", cfg.signals.mat_info[mods[0]]}
     calls.clear()
     fe.run_extraction(cfg, compute=compute, verbose=False)                    # without resume: the reference's behaviour
     assert len(calls) == len(mods)
