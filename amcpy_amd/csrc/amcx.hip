@@ -12,6 +12,7 @@
 #include "amcx_block_kernel.h"
 #include "amcx_wave_kernel.h"
 #include "amcx_quad_kernel.h"
+#include "amcx_group_kernel.h"
 #include "amcx_post_kernels.h"
 #include "amcx_pack_kernel.h"
 #include "amcx_upload.h"
@@ -35,11 +36,12 @@ bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
 int resolve_variant(int32_t frame_size, int32_t variant) {
   if (frame_size < AMCX_MIN_FRAME_SIZE || frame_size > AMCX_MAX_FRAME_SIZE) return AMCX_EINVAL;
+  const bool block_ok = frame_size <= AMCX_MAX_BLOCK_FRAME_SIZE;      // above it only the powers of two have a kernel
   switch (variant) {
     case AMCX_VARIANT_AUTO:
-      return amcx::wave_supports(frame_size) ? AMCX_VARIANT_WAVE : AMCX_VARIANT_BLOCK;
+      return amcx::wave_supports(frame_size) ? AMCX_VARIANT_WAVE : block_ok ? AMCX_VARIANT_BLOCK : AMCX_ENOTSUP;
     case AMCX_VARIANT_BLOCK:
-      return AMCX_VARIANT_BLOCK;
+      return block_ok ? AMCX_VARIANT_BLOCK : AMCX_ENOTSUP;
     case AMCX_VARIANT_WAVE:
       return amcx::wave_supports(frame_size) ? AMCX_VARIANT_WAVE : AMCX_ENOTSUP;
     default:
@@ -95,7 +97,7 @@ int launch_block(const float2* iq, int64_t n_frames, int32_t N, int64_t row_stri
   // race between one's attribute and the other's launch.
   {
     static bool attr_set[4][64] = {};
-    constexpr int kMaxLds = 16 * AMCX_MAX_FRAME_SIZE + amcx::kBlockScratchBytes + amcx::kBlockTwiddleBytes;
+    constexpr int kMaxLds = 16 * AMCX_MAX_BLOCK_FRAME_SIZE + amcx::kBlockScratchBytes + amcx::kBlockTwiddleBytes;
     int dev = 0;
     AMCX_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64 || !attr_set[mode][dev]) {
@@ -218,14 +220,19 @@ int amcx_features18_c64_ex(const void* iq_dev, int64_t n_frames, int32_t frame_s
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
   const float2* iq = static_cast<const float2*>(iq_dev);
   if (v == AMCX_VARIANT_WAVE) {
-    // N = 8192: four waves per frame (amcx_quad_kernel.h); every other wave size: one wave per frame
+    // N = 8192: four waves per frame (amcx_quad_kernel.h); 16384 / 32768: eight / sixteen (amcx_group_kernel.h); every other
+    // wave size: one wave per frame
     hipError_t e;
     if (frame_size == amcx::quad::kN)
       e = amcx::quad::launch_quad(iq, n_frames, row_stride_elems, out_dev, out_row_stride, stream, cu_count());
+    else if (frame_size == amcx::group::G<8>::kN)
+      e = amcx::group::launch_group<8>(iq, n_frames, row_stride_elems, out_dev, out_row_stride, stream, cu_count());
+    else if (frame_size == amcx::group::G<16>::kN)
+      e = amcx::group::launch_group<16>(iq, n_frames, row_stride_elems, out_dev, out_row_stride, stream, cu_count());
     else
       e = amcx::launch_wave(iq, n_frames, frame_size, row_stride_elems, out_dev, out_row_stride, stream, cu_count());
     if (e != hipSuccess) return hip_fail(e, "wave kernel launch");
-    // every throughput kernel (N = 128 ... 4096 one wave per frame, N = 8192 the quad) has re-run the frames outside its
+    // every throughput kernel (N = 128 ... 4096 one wave per frame, N = 8192 the quad, 16384 / 32768 the group) has re-run the frames outside its
     // fp32 sums' range itself -- one launch, rows final -- and finished frames with a phase step within an angle rounding
     // of +-pi in its finaliser.
     return AMCX_OK;

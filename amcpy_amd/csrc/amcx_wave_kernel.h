@@ -1237,7 +1237,7 @@ __global__ __launch_bounds__(Cfg<N>::kThreads, (Cfg<N>::kWavesPerWG + 3) / 4) vo
 }  // namespace wave
 
 inline bool wave_supports(int frame_size) {
-  return frame_size >= 128 && frame_size <= 8192 && (frame_size & (frame_size - 1)) == 0;
+  return frame_size >= 128 && frame_size <= 32768 && (frame_size & (frame_size - 1)) == 0;
 }
 
 inline const char* wave_kernel_name(int frame_size) {
@@ -1249,6 +1249,8 @@ inline const char* wave_kernel_name(int frame_size) {
     case 2048: return "amcx_features18_wave_kernel<2048>";
     case 4096: return "amcx_features18_wave_kernel<4096>";
     case 8192: return "amcx_features18_quad_kernel";
+    case 16384: return "amcx_features18_group_kernel<8>";
+    case 32768: return "amcx_features18_group_kernel<16>";
     default: return "";
   }
 }
@@ -1287,7 +1289,7 @@ inline hipError_t launch_wave(const float2* iq, int64_t n_frames, int32_t frame_
     case 1024: return launch_wave_n<1024>(iq, n_frames, row_stride, out, out_stride, stream, cus);
     case 2048: return launch_wave_n<2048>(iq, n_frames, row_stride, out, out_stride, stream, cus);
     case 4096: return launch_wave_n<4096>(iq, n_frames, row_stride, out, out_stride, stream, cus);
-    default: return hipErrorNotSupported;       // 8192 has a kernel of its own (amcx.hip)
+    default: return hipErrorNotSupported;       // 8192, 16384, 32768 have kernels of their own (amcx.hip)
   }
 }
 

@@ -14,7 +14,9 @@ Fixtures:
   kat_n10.json            the reference's own known-answer vector and table
                           (features.py:240-255, 286-305) restated as data
   frames_n{N}.npz         N in {128, 256, 512, 1000, 1024, 2048, 4096}: 6 mods x 3 SNR x 2 frames
-                          (N = 5000, 8192: 6 mods x 1 SNR x 2) complex64 inputs (1000 and 5000: the block kernel's
+                          (N = 5000, 8192, 16384, 32768: 6 mods x 1 SNR x 2; from 16384 on the fixtures of every kind hold
+                          the SHA-256 of their inputs instead of the inputs, which frames_inputs / edges_inputs /
+                          range_inputs below rebuild with numpy alone) complex64 inputs (1000 and 5000: the block kernel's
                           two Bluestein forms); golden64 (reference on complex128
                           input, float32-stored as feature_extraction.py:35,56
                           does) + its unrounded float64; golden32 (reference on
@@ -102,7 +104,12 @@ def capture_kat(rfeat):
     (OUT / "kat_n10.json").write_text(json.dumps(doc, indent=1))
 
 
-def capture_frames(rfeat, N):
+SEEDED_FROM = 16384       # fixtures of frames this long hold no inputs: their SHA-256 and the recipe below rebuild them
+
+
+def frames_inputs(N):
+    """(complex64 (F, N) inputs, tags) of frames_n{N}.npz -- numpy only, no reference: the tests rebuild the inputs of
+    the large fixtures with this (tests/conftest.py:load_npz) and check them against the stored SHA-256."""
     from amcpy_amd import synth
     snrs = (-10.0, 4.0, 20.0) if N <= 4096 else (4.0,)        # N = 5000, 8192: 12 frames keep the fixture under 1 MB
     frames, tags = [], []
@@ -111,13 +118,23 @@ def capture_frames(rfeat, N):
             blk = synth.host_block(mod, snr, 2, N, seed=1000 + 10 * mi + si)
             frames.append(blk)
             tags += [f"{mod}@{snr:g}dB#{k}" for k in range(2)]
-    x = np.concatenate(frames, axis=0).astype(np.complex64)
+    return np.concatenate(frames, axis=0).astype(np.complex64), tags
+
+
+def _sha(a) -> str:
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def capture_frames(rfeat, N):
+    x, tags = frames_inputs(N)
     g64 = np.stack([_ref18(rfeat, f, np.complex128) for f in x])
     g32 = np.stack([_ref18(rfeat, f, np.complex64) for f in x])
     mom = np.stack([_ref_moments(rfeat, f) for f in x])
-    np.savez(OUT / f"frames_n{N}.npz", iq=x, golden64_f64=g64,
+    inputs = {"iq": x} if N < SEEDED_FROM else {"iq_sha256": np.array(_sha(x)), "iq_recipe": np.array(f"frames_inputs({N})")}
+    np.savez(OUT / f"frames_n{N}.npz", golden64_f64=g64,
              golden64=g64.astype(np.float32), golden32=g32.astype(np.float32),
-             moments=mom, tags=np.array(tags))
+             moments=mom, tags=np.array(tags), **inputs)
 
 
 def edge_frames(N):
@@ -147,14 +164,19 @@ def edge_frames(N):
     return z
 
 
-def capture_edges(rfeat, N):
+def edges_inputs(N):
     z = edge_frames(N)
     names = sorted(z)
-    x = np.stack([z[k] for k in names])
+    return np.stack([z[k] for k in names]), names
+
+
+def capture_edges(rfeat, N):
+    x, names = edges_inputs(N)
     g64 = np.stack([_ref18(rfeat, f, np.complex128) for f in x])
     g32 = np.stack([_ref18(rfeat, f, np.complex64) for f in x])
-    np.savez(OUT / f"edges_n{N}.npz", iq=x, names=np.array(names), golden64_f64=g64,
-             golden64=g64.astype(np.float32), golden32=g32.astype(np.float32))
+    inputs = {"iq": x} if N < SEEDED_FROM else {"iq_sha256": np.array(_sha(x)), "iq_recipe": np.array(f"edges_inputs({N})")}
+    np.savez(OUT / f"edges_n{N}.npz", names=np.array(names), golden64_f64=g64,
+             golden64=g64.astype(np.float32), golden32=g32.astype(np.float32), **inputs)
 
 
 def capture_roundtrip(rfe, rcfg):
@@ -267,21 +289,31 @@ def range_extreme_frames(N):
             for k, v in base.items()}
 
 
-def capture_range(rfeat, N):
+def range_extreme_inputs(N):
     ze = range_extreme_frames(N)
     names_e = sorted(ze)
-    xe = np.stack([ze[k] for k in names_e])
-    ge = np.stack([_ref18(rfeat, f, np.complex128) for f in xe])
-    with np.errstate(all="ignore"):
-        np.savez(OUT / f"range_extreme_n{N}.npz", iq=xe, names=np.array(names_e), golden64_f64=ge,
-                 golden64=ge.astype(np.float32))
+    return np.stack([ze[k] for k in names_e]), names_e
+
+
+def range_inputs(N):
     z = range_frames(N)
     names = sorted(z)
-    x = np.stack([z[k] for k in names])
+    return np.stack([z[k] for k in names]), names
+
+
+def capture_range(rfeat, N):
+    xe, names_e = range_extreme_inputs(N)
+    ge = np.stack([_ref18(rfeat, f, np.complex128) for f in xe])
+    inputs = {"iq": xe} if N < SEEDED_FROM else {"iq_sha256": np.array(_sha(xe)), "iq_recipe": np.array(f"range_extreme_inputs({N})")}
+    with np.errstate(all="ignore"):
+        np.savez(OUT / f"range_extreme_n{N}.npz", names=np.array(names_e), golden64_f64=ge,
+                 golden64=ge.astype(np.float32), **inputs)
+    x, names = range_inputs(N)
     g64 = np.stack([_ref18(rfeat, f, np.complex128) for f in x])
     with np.errstate(all="ignore"):
         g32 = g64.astype(np.float32)               # what feature_extraction.py:35,56 stores: inf / 0 at the ends
-    np.savez(OUT / f"range_n{N}.npz", iq=x, names=np.array(names), golden64_f64=g64, golden64=g32)
+    inputs = {"iq": x} if N < SEEDED_FROM else {"iq_sha256": np.array(_sha(x)), "iq_recipe": np.array(f"range_inputs({N})")}
+    np.savez(OUT / f"range_n{N}.npz", names=np.array(names), golden64_f64=g64, golden64=g32, **inputs)
 
 
 def capture_roundtrip_f64(rfe, rcfg):
@@ -381,11 +413,11 @@ def main():
             print(f"{name:28s} {(OUT / name).stat().st_size:9d} B")
         return
     capture_kat(rfeat)
-    for N in (128, 256, 512, 1000, 1024, 2048, 4096, 5000, 8192):
+    for N in (128, 256, 512, 1000, 1024, 2048, 4096, 5000, 8192, 16384, 32768):
         capture_frames(rfeat, N)
-    for N in (1000, 1024, 2048, 4096, 8192):
+    for N in (1000, 1024, 2048, 4096, 8192, 16384, 32768):
         capture_edges(rfeat, N)
-    for N in (2048, 4096, 8192):
+    for N in (2048, 4096, 8192, 16384, 32768):
         capture_range(rfeat, N)
     capture_roundtrip(rfe, rcfg)
     capture_roundtrip_f64(rfe, rcfg)

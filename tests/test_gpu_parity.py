@@ -45,7 +45,7 @@ def _run(frames, variant, frame_size=None):
 
 def _variants_for(N):
     from amcpy_amd import _lib
-    out = ["block"]
+    out = ["block"] if N <= 8192 else []             # AMCX_MAX_BLOCK_FRAME_SIZE: above it only the powers of two, one kernel each
     try:
         _lib.kernel_name(N, _lib.VARIANT_WAVE)
         out.append("wave")
@@ -179,8 +179,8 @@ def test_random_frames_against_oracle():
     """Seeded synthetic frames the oracle finishes in seconds, every modulation
     and a wide SNR range, each power-of-two size the fast kernel serves."""
     from amcpy_amd import synth
-    for N in (128, 256, 512, 1024, 2048, 4096, 8192):
-        blocks = [synth.host_block(m, snr, 8, N, seed=77 + 13 * i + j)
+    for N in (128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768):
+        blocks = [synth.host_block(m, snr, 8 if N <= 8192 else 3, N, seed=77 + 13 * i + j)
                   for i, m in enumerate(synth.MODS6) for j, snr in enumerate((-20.0, -6.0, 8.0, 30.0))]
         x = np.concatenate(blocks).astype(np.complex64)
         gold = orc.features18_batch(x)
@@ -273,6 +273,59 @@ def test_wave_kernel_8192():
     assert np.array_equal(_run(x[perm], "wave"), got[perm], equal_nan=True)
 
 
+@pytest.mark.parametrize("N,W", [(16384, 8), (32768, 16)])
+def test_group_kernels_16384_and_32768(N, W):
+    """N = 16384 / 32768: eight / sixteen waves per frame (amcx_group_kernel.h) -- 2048-sample blocks in registers, two
+    radix stages across the group through LDS (2 then 4; 4 then 4), W register FFTs; frame_size is a free integer in the
+    reference (config.py:96, np.fft.fft: features.py:68).  Against the oracle; pure tones on bins of every residue mod W
+    (each residue is one wave's FFT, and the stage twiddles decide whether its energy arrives); ragged batches, fewer
+    batches than workgroups, one frame alone, a permutation: rows bit-identical whatever the position; a NaN, an
+    infinite and an all-zero frame in the middle; frames outside the fp32 sums' range re-run in the same launch."""
+    from amcpy_amd import synth, _lib
+    assert _lib.kernel_name(N, _lib.VARIANT_AUTO) == f"amcx_features18_group_kernel<{W}>"
+    assert _lib.kernel_name(N, _lib.VARIANT_WAVE) == _lib.kernel_name(N)
+    x = np.concatenate([synth.host_block(m, snr, 9, N, seed=N + i)
+                        for i, (m, snr) in enumerate((("BPSK", -5.0), ("QPSK", 3.0), ("64QAM", 20.0), ("WGN", 0.0)))])
+    n = np.arange(N)
+    bins = [(W * 37 + r) % N for r in range(W)] + [N - 1, N // 2, N // 2 + 1, 1]
+    for k, b in enumerate(bins):
+        x[k] = np.exp(2j * np.pi * b * n / N).astype(np.complex64)
+    T = len(bins)
+    gold = orc.features18_batch(x)
+    got = _run(x, "wave")
+    assert np.all(np.abs(got[:T, 0] / N - 1.0) < 1e-5), got[:T, 0] / N                  # |X|^2 / N = N on every residue
+    _assert_parity(got[T:], gold[T:], x[T:], f"group N={N}")
+    for count in (1, 2, 3, 5, 7, 17, 33):
+        sub = _run(x[:count], "wave")
+        assert np.array_equal(sub, got[:count], equal_nan=True), count
+    perm = np.random.default_rng(8).permutation(x.shape[0])
+    assert np.array_equal(_run(x[perm], "wave"), got[perm], equal_nan=True)
+    # bad frames stay to themselves
+    y = x.copy()
+    y[T + 1, N // 2] = np.nan
+    y[T + 4, 5] = complex(np.inf, 0.0)
+    y[T + 6] = 0
+    bad = _run(y, "wave")
+    assert np.isnan(bad[T + 1]).all() and np.isnan(bad[T + 4]).all()
+    keep = np.ones(len(x), bool)
+    keep[[T + 1, T + 4, T + 6]] = False
+    assert np.array_equal(bad[keep], got[keep])
+    zero = orc.features18_batch(y[T + 6:T + 7])[0]
+    assert (np.isnan(bad[T + 6]) == np.isnan(zero)).all() and np.allclose(bad[T + 6][~np.isnan(zero)], zero[~np.isnan(zero)])
+    # out of the fp32 sums' range, scattered through batches and across an epoch's mask words: the scaling laws hold exactly
+    z = np.tile(x[T:T + 8], (9, 1))                                                    # 72 frames
+    sc = np.ones(len(z), np.float32)
+    sc[[0, 5, 31, 32, 33, 64, 71]] = [2.0 ** 30, 2.0 ** -40, 2.0 ** 24, 2.0 ** 26, 2.0 ** -34, 2.0 ** 28, 2.0 ** -30]
+    zs = (z * sc[:, None]).astype(np.complex64)
+    a, b = _run(z, "wave").astype(np.float64), _run(zs, "wave").astype(np.float64)
+    order = np.array([2, 0, 0, 0, 0, 1, 0.5, 0, 0, 2, 2, 4, 4, 4, 6, 6, 6, 6])
+    with np.errstate(over="ignore", under="ignore", invalid="ignore"):
+        want = (a * sc[:, None].astype(np.float64) ** order[None, :]).astype(np.float32)
+    fin = np.isfinite(want) & (want != 0)
+    assert np.allclose(b.astype(np.float32)[fin], want[fin], rtol=3e-6, atol=0), np.abs(b.astype(np.float32)[fin] / want[fin] - 1).max()
+    assert (np.isinf(want) == np.isinf(b)).all()
+
+
 def test_bad_frames_do_not_leak_into_neighbours():
     """Grouped short frames share FFT passes 2-3 and a finaliser batch; the ping-pong variants
     share registers across frames: a NaN / Inf / all-zero frame in the middle of a batch must
@@ -304,7 +357,7 @@ def test_bad_frames_do_not_leak_into_neighbours():
 def test_results_do_not_depend_on_batch_position():
     """Same property for the long-frame variants and the block kernel."""
     from amcpy_amd import synth
-    for N, F in ((128, 517), (512, 333), (1024, 301), (2048, 203), (4096, 101), (8192, 67), (100, 57)):
+    for N, F in ((128, 517), (512, 333), (1024, 301), (2048, 203), (4096, 101), (8192, 67), (16384, 37), (32768, 21), (100, 57)):
         x = synth.host_block("64QAM", 8.0, F, N, seed=N)
         perm = np.random.default_rng(N).permutation(F)
         for variant in _variants_for(N):
@@ -390,6 +443,12 @@ def test_argument_errors():
     assert f(None, 2, 64, 64, o.data_ptr(), 18, None) == _lib.EINVAL
     assert f(x.data_ptr(), 2, 1, 64, o.data_ptr(), 18, None) == _lib.EINVAL       # N < 2
     assert f(x.data_ptr(), 2, 1 << 20, 1 << 20, o.data_ptr(), 18, None) == _lib.EINVAL
+    assert f(x.data_ptr(), 2, 65536, 65536, o.data_ptr(), 18, None) == _lib.EINVAL          # AMCX_MAX_FRAME_SIZE is 32768
+    assert f(x.data_ptr(), 2, 32769, 32769, o.data_ptr(), 18, None) == _lib.EINVAL
+    # 8193 ... 32767 other than 16384: in range, but no kernel (the block kernel ends at AMCX_MAX_BLOCK_FRAME_SIZE)
+    assert f(x.data_ptr(), 2, 10000, 10000, o.data_ptr(), 18, None) == _lib.ENOTSUP
+    assert f(x.data_ptr(), 2, 8193, 8193, o.data_ptr(), 18, None) == _lib.ENOTSUP
+    assert lib.amcx_features18_c64_ex(x.data_ptr(), 2, 16384, 16384, o.data_ptr(), 18, None, _lib.VARIANT_BLOCK) == _lib.ENOTSUP
     assert f(None, 0, 64, 64, None, 18, None) == _lib.OK                          # empty batch
     assert lib.amcx_features18_c64_ex(x.data_ptr(), 2, 100, 100, o.data_ptr(), 18, None,
                                       _lib.VARIANT_WAVE) == _lib.ENOTSUP
@@ -745,7 +804,7 @@ def test_launch_is_graph_capturable():
     assert torch.equal(out, want)
 
 
-@pytest.mark.parametrize("N", [2048, 4096, 8192])
+@pytest.mark.parametrize("N", [2048, 4096, 8192, 16384, 32768])
 def test_dynamic_range_matches_the_float32_stored_reference(N):
     """Frames of ordinary shape at scales 1e-12 ... 1e12, one whose halves differ by ten orders
     of magnitude and one with a single 5e7 sample (tests/golden/range_n{N}.npz, captured from
@@ -762,7 +821,7 @@ def test_dynamic_range_matches_the_float32_stored_reference(N):
         stored = gold64.astype(np.float32)
     assert np.array_equal(stored, gold32, equal_nan=True)
     strict = [i for i in range(18) if i < 9 or i == 10]
-    for variant in VARIANTS_POW2:
+    for variant in (VARIANTS_POW2 if N <= 8192 else ["wave"]):
         got = _run(x, variant)
         special = ~np.isfinite(gold32) | (gold32 == 0)
         bad = np.argwhere(special & (got != gold32))
@@ -1241,7 +1300,7 @@ def test_out_of_range_frames_scattered_over_a_full_grid(N):
     assert np.array_equal(got[kinds == 0], ref[pick][kinds == 0].astype(np.float32), equal_nan=True)
 
 
-@pytest.mark.parametrize("N", [2048, 4096, 8192])
+@pytest.mark.parametrize("N", [2048, 4096, 8192, 16384, 32768])
 def test_ends_of_float32_through_the_range_pass(N):
     """range_extreme_n{N}.npz (captured from the reference): the range fixture's frames at 1e-30, 1e-20,
     1e20 and 1e30 -- |x|^2 itself leaves float32.  The reference, evaluating in complex128, still returns
@@ -1252,7 +1311,8 @@ def test_ends_of_float32_through_the_range_pass(N):
     g = load_npz(f"range_extreme_n{N}.npz")
     x, names, gold32 = g["iq"], [str(n) for n in g["names"]], g["golden64"]
     S = orc.conditioning_scales(x.astype(np.complex128))
-    for variant in VARIANTS_POW2:            # the block kernel stages every frame times a power of two as well
+    variants = VARIANTS_POW2 if N <= 8192 else ["wave"]
+    for variant in variants:                 # the block kernel stages every frame times a power of two as well
         _check_ends_of_float32(_run(x, variant), gold32, S, names, variant)
     # non-power-of-two frame sizes (block kernel, Bluestein): the first 1000 samples of the same frames vs the oracle
     x1000 = np.ascontiguousarray(x[:, :1000])
@@ -1260,7 +1320,7 @@ def test_ends_of_float32_through_the_range_pass(N):
         gold1000 = orc.features18_batch(x1000.astype(np.complex128)).astype(np.float32)
     _check_ends_of_float32(_run(x1000, "auto"), gold1000, orc.conditioning_scales(x1000.astype(np.complex128)), names, "N=1000")
     # an all-zero frame is still a zero frame (not flagged, not scaled): NaN pattern of the reference
-    for variant in VARIANTS_POW2:
+    for variant in variants:
         z = _run(np.zeros((1, N), np.complex64), variant)[0]
         assert np.isnan(z[[3, 7, 8]]).all() and np.all(z[[0, 1, 2, 4, 5, 6] + list(range(9, 18))] == 0)
 

@@ -52,7 +52,9 @@ for n, cs in summary["counters_mean_per_dispatch"].items():
     if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
         rd, wr = cs["FETCH_SIZE"] * 1024 * 2, cs["WRITE_SIZE"] * 1024
         m = re.search(r"wave_kernel<(\d+)>", n)
-        fs = int(m.group(1)) if m else 8192 if "quad_kernel" in n else int(os.environ.get("AMCX_PROFILE_FRAME_SIZE", 2048))
+        g = re.search(r"group_kernel<(\d+)>", n)               # N = 2048 x the number of waves per frame
+        fs = int(m.group(1)) if m else 2048 * int(g.group(1)) if g else 8192 if "quad_kernel" in n else \
+            int(os.environ.get("AMCX_PROFILE_FRAME_SIZE", 2048))
         summary["pmc_traffic"] = {"kernel": n, "frame_size": fs, "frames_per_launch": frames,
                                   "fetch_bytes_corrected": rd, "write_bytes": wr,
                                   "hbm_bytes_per_frame": (rd + wr) / frames,
