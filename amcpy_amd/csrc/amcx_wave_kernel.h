@@ -4,7 +4,7 @@
 // live in tools/experiments/ (patches against a named commit); nothing of them is compiled here.
 //
 // Why not "one 256-thread workgroup per frame": this path is bound by the board's power cap
-// and by VALU issue, not by HBM (~105 fp32 VALU instructions per sample; DESIGN.md section
+// and by VALU issue, not by HBM (~105 fp32 VALU instructions per sample; DESIGN.md section 4.6, HISTORY.md section
 // 4.3), so the design minimises instructions per sample:
 //   * 16-64 samples per lane amortise every cross-lane reduction over 4-8x more
 //     work than a 256-thread block would (8 samples per lane at N = 2048);
@@ -54,7 +54,7 @@
 // N = 2048: 128 VGPRs; two lane-dependent values, 12 bytes, are spilled in the prologue: one 32-bit reload per frame at the
 // end of the wave reduction, one 64-bit reload per batch of four: amcpy_amd/csrc/kernel_resources.json; the exchange buffer at its exact 8672 bytes and batches of four frames make
 // the LDS fit): 4.3 % fewer SIMD cycles per frame than with 12 waves, of which the power cap takes 2.5 % back
-// as clock -- +1.2 ... +1.9 % frames/s for the kernel alone, +0.5 % through the library's step (DESIGN.md section 4.1;
+// as clock -- +1.2 ... +1.9 % frames/s for the kernel alone, +0.5 % through the library's step (HISTORY.md section 4.1;
 // tools/experiments/r5_lab_branches.patch holds the 12-wave form).
 // (Two 6-wave workgroups did NOT co-reside at the 160 VGPRs of round 1a: their waves
 // landed 2,2,1,1 on the SIMDs, profiles/r1a.)  LDS per workgroup at N = 2048:

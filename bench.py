@@ -394,7 +394,7 @@ def run_fanout_leg(n_devices: int, share_gpu: bool, frame_size: int, n_frames: i
 
 def _valu_note(frames_per_s: float):
     """Secondary bounds of the N = 2048 kernel from this round's committed budget
-    (profiles/r2_wave_budget.json: in-kernel clock, issue slots, ablations -- DESIGN.md 4.3)."""
+    (profiles/r2_wave_budget.json: in-kernel clock, issue slots, ablations -- DESIGN.md 4.6, HISTORY.md 4.3)."""
     b, name = None, None
     for name in ("r4_wave_budget.json", "r3_wave_budget.json", "r2_wave_budget.json"):
         b = _committed_json(name)

@@ -913,7 +913,7 @@ def test_run_extraction_on_a_mat73_container_equals_the_level5_one(tmp_path):
 # |got - golden64| <= 1e-5 max(|golden64|, S) with the kernels of this round: {modulation: flat frame indices}.  Every
 # other one of the 6 000 frames meets it -- configs[0] is judged by the strict rule too, not only by the large-sample
 # one.  (A frame lands here when a whole sixth-order moment cancels by chance -- |mean x^6| = 0.003 where mean |x|^6 = 7
-# -- so that S collapses; its absolute error is 1e-8 of the summands' scale.  DESIGN.md section 2.)
+# -- so that S collapses; its absolute error is 1e-8 of the summands' scale.  HISTORY.md section 2.)
 CLI_UNFLOORED_EXCEPTIONS = {"WGN": [106]}
 
 

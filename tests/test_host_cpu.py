@@ -1478,7 +1478,7 @@ def test_staging_half_under_the_sanitizers(tmp_path, name, flags):
 
 
 def test_kernel_resources_match_the_committed_table():
-    """The register / spill / scratch claims made in DESIGN.md section 4 and in the kernel headers are read off the
+    """The register / spill / scratch claims made in DESIGN.md section 4.5 and in the kernel headers are read off the
     BUILT library (its gfx950 code object's metadata, tools/resource_usage.py) and held to
     amcpy_amd/csrc/kernel_resources.json: a kernel that starts to spill, grows past a wave-per-SIMD step (128 / 168 /
     256 VGPRs) or appears / disappears without the table being updated fails here.  Product kernels only: the library
@@ -1503,6 +1503,22 @@ def test_kernel_resources_match_the_committed_table():
     # spilled register is a 256-byte transaction per wave that reaches HBM: the first version moved 4x the frame's bytes)
     assert got["group::amcx_features18_group_kernel<16>"]["vgpr"] <= 128 and got["group::amcx_features18_group_kernel<16>"]["spill"] <= 16
     assert got["group::amcx_features18_group_kernel<8>"]["vgpr"] <= 256
+
+
+def test_cited_profiles_exist():
+    """DESIGN.md describes the tree as it is and HISTORY.md how it got there; every number in either names the
+    profiles/ file it comes from.  A citation of a file that is not in the tree is a claim without evidence: every
+    `profiles/<name>` and every back-quoted `r<round>_<name>.{json,jsonl,txt,csv}` in the documents must exist
+    (patterns with a * are families, not files)."""
+    have = {p.name for p in (REPO / "profiles").iterdir()}
+    ext = r"(?:jsonl|json|txt|csv|patch)"
+    for doc in ("DESIGN.md", "HISTORY.md", "README.md", "INTEGRATION.md", "tools/README.md", "profiles/README.md"):
+        text = (REPO / doc).read_text()
+        names = set(re.findall(rf"profiles/([A-Za-z0-9_.\-]+\.{ext})\b", text))
+        names |= set(re.findall(rf"`((?:r\d+[a-z]?_)[A-Za-z0-9_.\-]+\.{ext})`", text))
+        missing = sorted(n for n in names if n not in have and not (REPO / "tools" / "experiments" / n).exists())
+        assert not missing, f"{doc} cites profiles that are not in the tree: {missing}"
+    assert len((REPO / "DESIGN.md").read_text().splitlines()) <= 400, "DESIGN.md describes the tree in at most 400 lines; narratives go to HISTORY.md"
 
 
 def test_product_sources_carry_no_laboratory():

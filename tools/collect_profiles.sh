@@ -3,7 +3,7 @@
 #   bash tools/collect_profiles.sh r3
 TAG=${1:-r4}
 cd "$(dirname "$0")/.."
-for N in 2048 4096 1024 8192; do
+for N in 2048 4096 1024 8192 16384 32768; do
   D=gpurun_out/prof_${TAG}_n$N
   [ -d $D ] || { echo "no $D"; continue; }
   cp $D/summary.txt profiles/${TAG}_n${N}_summary.json

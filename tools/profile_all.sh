@@ -3,8 +3,10 @@
 # default bench line with both CPU baselines, every size un-profiled, the in-kernel clock.
 #   bash tools/profile_all.sh r3     -> gpurun_out/prof_r3_n*/, gpurun_out/r3_*.json*
 TAG=${1:-r4}
-for N in 2048 4096 1024 8192; do
-  bash tools/profile.sh ${TAG}_n$N --frame-size $N > gpurun_out/${TAG}_n${N}_profile.log 2>&1 || { echo "profile N=$N failed"; tail -5 gpurun_out/${TAG}_n${N}_profile.log; exit 1; }
+for N in 2048 4096 1024 8192 16384 32768; do
+  FR=4096; [ $N -eq 16384 ] && FR=512; [ $N -eq 32768 ] && FR=256
+  export AMCX_PROFILE_FRAMES=$((6 * 26 * FR))
+  bash tools/profile.sh ${TAG}_n$N --frame-size $N --frames $FR > gpurun_out/${TAG}_n${N}_profile.log 2>&1 || { echo "profile N=$N failed"; tail -5 gpurun_out/${TAG}_n${N}_profile.log; exit 1; }
   echo "profiled N=$N: $(python3 -c "
 import json; d=json.load(open('gpurun_out/prof_${TAG}_n$N/summary.txt')); b=json.load(open('gpurun_out/prof_${TAG}_n$N/bench_trace.json'))
 k=[v for n,v in d['dispatch_ns'].items() if 'features18' in n][0]; r=([v for n,v in d['dispatch_ns'].items() if 'range' in n] or [{'mean_of_the_timed_launches': 0.0}])[0]
