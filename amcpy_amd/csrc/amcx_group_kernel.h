@@ -24,8 +24,10 @@
 // (one ds_read_b128 per round) and is squared / cubed on the spot -- holding the factors of both stages in registers
 // instead (8 VGPRs, all frame long) cost the 128-register W = 16 kernel scratch traffic.  The units W_rho^(r j) are
 // 0 / +-1 in scalar registers (radix_round below: branch-free).
-// As in the quad, a stage goes in two rounds of eight rows (a wave's region of the exchange area holds eight rows of
-// 1 KiB in a round and is its FFT scratch afterwards): four barriers per stage, the same in every wave.
+// W = 16: as in the quad, a stage goes in two rounds of eight rows (a wave's region of the exchange area holds eight rows of
+// 1 KiB in a round and is its FFT scratch afterwards): four barriers per stage, the same in every wave.  W = 8: the LDS
+// holds eight regions of 16 KiB, a stage is ONE round of sixteen rows: two barriers per stage, and a block's registers are
+// all free between its sweep and the first stage.
 //
 // Frames outside the fp32 sums' range are found by the finaliser, recorded in a BIT MASK IN LDS (one bit per frame of
 // the workgroup's current epoch of <= 2048 frames) and re-run by the whole group at the end of the epoch, multiplied by an
@@ -34,7 +36,7 @@
 // own rows: ADVICE round 4).
 //
 // LDS per workgroup, W = 16: FFT tables 16 256 + W_256 table 2 048 + lane factors 2 048 + 16 regions of 8 672 + stash 2 x 2 112
-// (two frames) + partial sums / mask 384 = 163 712 bytes; W = 8: 16 256 + 2 048 + 2 048 + 8 x 8 704 + stash 8 x 1 056 + 320.
+// (two frames) + partial sums / mask 384 = 163 712 bytes; W = 8: 16 256 + 2 048 + 2 048 + 8 x 16 384 + stash 8 x 1 056 + 320 = 160 192.
 // Algorithmic HBM bytes per frame: 8 N read + 72 written.
 #pragma once
 
@@ -47,7 +49,7 @@ using namespace wave;
 using quad::Recentred;
 using quad::reduce_store;
 
-constexpr int kBlock = 2048, kRowsB = 16, kRoundRows = 8;
+constexpr int kBlock = 2048, kRowsB = 16;
 using C2 = Cfg<2048>;                                        // the register FFT every wave runs
 constexpr int kTabBytes = C2::kT2Bytes + C2::kT3Bytes;
 constexpr int kTw256Bytes = 256 * 8;
@@ -62,8 +64,18 @@ struct G {
   static constexpr int kStride0 = W / kRadix0;              // = 4: the second stage is the quad's radix 4 over neighbours
   static_assert(kStride0 == 4, "two stages, the second of radix 4");
   static constexpr int kBatch = W == 16 ? 2 : 8;            // frames finalised together (W = 16: what the LDS left over holds)
-  static constexpr bool kPrefetch = W <= 8;                 // the next frame's block in a second register set (128 VGPRs: no room)
-  static constexpr int kRegionBytes = W == 16 ? 8672 : 8704;
+  // W = 8: the first HALF of the next frame's block is requested before this frame's FFT and lands behind it (eight rows =
+  // 32 registers: all sixteen did not fit next to the FFT's own and were stored to scratch straight from the load, behind a
+  // wait); the second half is requested at the head of the next sweep and arrives while the first is swept.  W = 16 (128
+  // registers): nothing ahead of the frame; rows 12-15 are requested when rows 0-3 have been swept.
+  static constexpr bool kPrefetch = W <= 8;
+  static constexpr int kLateRow = W == 8 ? 8 : 12;          // rows from here on are requested inside the sweep ...
+  static constexpr int kLateAt = W == 8 ? 0 : 4;            // ... before row kLateAt is swept
+  // rows of a block exchanged per round of a stage: all sixteen where the LDS holds W regions of 16 KiB (W = 8: two barriers
+  // per stage), eight otherwise (W = 16: the region is the FFT exchange buffer's 8 672 bytes, four barriers per stage)
+  static constexpr int kRoundRows = W == 8 ? 16 : 8;
+  static constexpr int kRounds = kRowsB / kRoundRows;
+  static constexpr int kRegionBytes = W == 16 ? 8672 : 16384;
   static constexpr int kStashRow = kStashStride;
   static constexpr int kStashFloats = kBatch * W * kStashRow;         // one buffer
   static constexpr int kOffTw = kTabBytes;
@@ -80,7 +92,7 @@ struct G {
   static_assert(kEpochFrames % kBatch == 0, "an epoch is whole batches");
 };
 
-// One round (rows [ROW0, ROW0 + 8)) of a radix-RHO stage for the wave whose residue is r (= its own position among the RHO
+// One round (rows [ROW0, ROW0 + NROWS)) of a radix-RHO stage for the wave whose residue is r (= its own position among the RHO
 // partners; wave-uniform).  Every term comes from LDS, the wave's own included (`first`: the region of partner j' = 0,
 // `step`: bytes from one partner's region to the next); the results -- block p of z_r -- go to xr / xi.  Row factor:
 // tw256[(k0 + i dk) & 255]; lane factor: (lane_tw[2 l + b])^r.
@@ -90,7 +102,7 @@ struct G {
 // -- 32 or 64 of them -- were given stack slots, ~90 scratch stores per frame and wave.
 // PACED: two rows' reads in flight at a time (left alone the compiler issues all of a round's ds_read_b128 -- 128
 // registers of results -- at its head and parks them in scratch).
-template <int RHO, int ROW0, bool PACED>
+template <int RHO, int ROW0, int NROWS, bool PACED>
 __device__ __forceinline__ void radix_round(int r, float (&xr)[2 * kRowsB], float (&xi)[2 * kRowsB], const char* first, int step,
                                             int lane, const char* lane_tw, const float2* tw256, int k0, int dk) {
   float ur[RHO], ui[RHO];                                   // W_RHO^(r j') = ur + i ui
@@ -115,7 +127,7 @@ __device__ __forceinline__ void radix_round(int r, float (&xr)[2 * kRowsB], floa
                                   __builtin_fmaf(sq.z, b.z, -(sq.w * b.w)), __builtin_fmaf(sq.z, b.w, sq.w * b.z));
     lw = r == 0 ? make_float4(1.f, 0.f, 1.f, 0.f) : r == 1 ? b : r == 2 ? sq : cu;
   }
-  static_for<kRoundRows>([&](auto ii) {
+  static_for<NROWS>([&](auto ii) {
     constexpr int i = ROW0 + decltype(ii)::value;
     float a0r = 0.f, a0i = 0.f, a1r = 0.f, a1i = 0.f;
     static_for<RHO>([&](auto jj) {
@@ -312,7 +324,8 @@ __global__ __launch_bounds__(64 * W, 1) void amcx_features18_group_kernel(
       v[i] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src + 128 * i));
     });
   };
-  // rows [ROW0, ROW0 + 8) of the block -> this wave's region of the exchange area
+  constexpr int kRoundRows = Cg::kRoundRows, kRounds = Cg::kRounds;
+  // rows [ROW0, ROW0 + kRoundRows) of the block -> this wave's region of the exchange area
   auto publish_rows = [&](const float (&xr)[2 * kRowsB], const float (&xi)[2 * kRowsB], auto row0) {
     constexpr int ROW0 = decltype(row0)::value;
     static_for<kRoundRows>([&](auto ii) {
@@ -322,12 +335,12 @@ __global__ __launch_bounds__(64 * W, 1) void amcx_features18_group_kernel(
     });
   };
   using Row0 = std::integral_constant<int, 0>;
-  using Row8 = std::integral_constant<int, kRoundRows>;
-  constexpr int kLateRow = 12;                              // W = 16: rows 12-15 are requested only when rows 0-3 have been swept
+  using Row8 = std::integral_constant<int, 8>;
+  constexpr int kLateRow = Cg::kLateRow, kLateAt = Cg::kLateAt;
 
   // ---- a frame, phases A and B: statistics sweep of this wave's block (v: its 16 rows as loaded; nx = the first sample
   // of the next block), envelope about the exact mean, sums -> stash row (g, q), the two stages: xr / xi leave as this
-  // wave's 2048-point sequence.  Eight workgroup barriers, the same in every wave.
+  // wave's 2048-point sequence.  Eight workgroup barriers (W = 16; four at W = 8), the same in every wave.
   // Register economy (what the 128-register W = 16 kernel lives on; a spilled register is a 256-byte transaction per wave
   // that goes all the way to HBM -- the first version moved 4x the frame's bytes that way): a row of the first half is
   // written to the wave's region as soon as it has been swept and its registers are free from then on -- the envelope's
@@ -341,7 +354,7 @@ __global__ __launch_bounds__(64 * W, 1) void amcx_features18_group_kernel(
     AMCX_GROUP_PRIO(0);
     static_for<kRowsB>([&](auto ii) {
       constexpr int i = decltype(ii)::value;
-      if constexpr (LATE && i == kRowsB - kLateRow) {
+      if constexpr (LATE && i == kLateAt) {
         __builtin_amdgcn_sched_barrier(0);
         static_for<kRowsB - kLateRow>([&](auto kk) {
           constexpr int k = kLateRow + decltype(kk)::value;
@@ -390,13 +403,13 @@ __global__ __launch_bounds__(64 * W, 1) void amcx_features18_group_kernel(
 #pragma unroll
       for (int h = 0; h < W; h += 4) mu += (mu_part[h] + mu_part[h + 1]) + (mu_part[h + 2] + mu_part[h + 3]);
       mu *= (1.0f / (float)kN);
-      static_for<kRoundRows>([&](auto ii) {               // rows 0-7: back from the wave's region
+      static_for<kRoundRows>([&](auto ii) {               // the published rows: back from the wave's region
         constexpr int i = decltype(ii)::value;
         const v4f r = *reinterpret_cast<const v4f*>(ex + i * 1024 + lane * 16);
         S.envelope(__builtin_amdgcn_sqrtf(__builtin_fmaf(r.x, r.x, __builtin_fmaf(r.y, r.y, kTinyPower))), mu);
         S.envelope(__builtin_amdgcn_sqrtf(__builtin_fmaf(r.z, r.z, __builtin_fmaf(r.w, r.w, kTinyPower))), mu);
       });
-      static_for<2 * kRoundRows>([&](auto ee) {           // rows 8-15: registers
+      static_for<2 * (kRowsB - kRoundRows)>([&](auto ee) {   // the others (W = 16: rows 8-15): registers
         constexpr int e = 2 * kRoundRows + decltype(ee)::value;
         // |x| is taken AGAIN.  Left to itself the compiler recognises the sweep's square roots and keeps them alive across
         // the barrier; the empty asm makes the two operands opaque, so the second square root is really taken.
@@ -420,25 +433,29 @@ __global__ __launch_bounds__(64 * W, 1) void amcx_features18_group_kernel(
     asm volatile("; MARK gS0");
     AMCX_GROUP_PRIO(2);
     // stage 0 (every term from LDS, the wave's own included: a published row's registers are free)
-    radix_round<Cg::kRadix0, 0, true>(j0, xr, xi, first0, kStep0, lane, lw0, tw256, k00, dk0);
+    radix_round<Cg::kRadix0, 0, kRoundRows, true>(j0, xr, xi, first0, kStep0, lane, lw0, tw256, k00, dk0);
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();                                      // (2) round 1 has been read
-    publish_rows(xr, xi, Row8{});
-    __syncthreads();                                      // (3) rows 8-15 of every block are in LDS
-    radix_round<Cg::kRadix0, kRoundRows, true>(j0, xr, xi, first0, kStep0, lane, lw0, tw256, k00, dk0);
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();                                      // (4) round 2 has been read
+    if constexpr (kRounds == 2) {
+      publish_rows(xr, xi, Row8{});
+      __syncthreads();                                    // (3) rows 8-15 of every block are in LDS
+      radix_round<Cg::kRadix0, 8, 8, true>(j0, xr, xi, first0, kStep0, lane, lw0, tw256, k00, dk0);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();                                    // (4) round 2 has been read
+    }
     // stage 1: the wave's block of z_(j0)
     asm volatile("; MARK gS1");
     publish_rows(xr, xi, Row0{});
     __syncthreads();                                      // (5)
-    radix_round<4, 0, true>(j1, xr, xi, first1, kStep1, lane, lw1, tw256, k01, dk1);
+    radix_round<4, 0, kRoundRows, true>(j1, xr, xi, first1, kStep1, lane, lw1, tw256, k01, dk1);
     __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();                                      // (6)
-    publish_rows(xr, xi, Row8{});
-    __syncthreads();                                      // (7)
-    radix_round<4, kRoundRows, true>(j1, xr, xi, first1, kStep1, lane, lw1, tw256, k01, dk1);
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (kRounds == 2) {
+      __syncthreads();                                    // (6)
+      publish_rows(xr, xi, Row8{});
+      __syncthreads();                                    // (7)
+      radix_round<4, 8, 8, true>(j1, xr, xi, first1, kStep1, lane, lw1, tw256, k01, dk1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     __syncthreads();                                      // (8) a wave's region is its FFT scratch now
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -461,10 +478,17 @@ __global__ __launch_bounds__(64 * W, 1) void amcx_features18_group_kernel(
       f = (eb0 + it) * kBatch + g;
       return it < n_iters && f < n_frames;
     };
-    [[maybe_unused]] v4f nxt[Cg::kPrefetch ? kRowsB : 1];
+    v4f nxt[kRowsB];                                        // W = 8: rows 0 .. kLateRow-1 hold the NEXT frame's, requested a frame ago
+    auto request_head = [&](long long f) {
+      const float2* src = iq + f * row_stride + q * kBlock + 2 * lane;
+      static_for<kLateRow>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        nxt[i] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src + 128 * i));
+      });
+    };
     if constexpr (Cg::kPrefetch) {
       long long f_first;
-      if (frame_at(0, 0, f_first)) load_block(nxt, f_first);
+      if (frame_at(0, 0, f_first)) request_head(f_first);
     }
     for (int it = 0; it < n_iters; ++it) {
       const long long f0 = (eb0 + it) * kBatch;
@@ -476,22 +500,14 @@ __global__ __launch_bounds__(64 * W, 1) void amcx_features18_group_kernel(
         // the first sample of the next block: the phase step that crosses the block boundary
         float2 nx = make_float2(1.f, 0.f);
         if (q < W - 1) nx = iq[(f0 + g) * row_stride + (q + 1) * kBlock];
-        if constexpr (Cg::kPrefetch) {
-          phases_ab(std::false_type{}, nxt, nullptr, nx, stash, g, xr, xi);        // requested a frame ago
-        } else {
-          v4f v[kRowsB];
-          const float2* src = iq + (f0 + g) * row_stride + q * kBlock + 2 * lane;
-          static_for<kLateRow>([&](auto ii) {
-            constexpr int i = decltype(ii)::value;
-            v[i] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src + 128 * i));
-          });
-          phases_ab(std::true_type{}, v, src, nx, stash, g, xr, xi);
-        }
-        // the next frame's block is requested here, before the FFT, and lands behind it
+        const float2* src = iq + (f0 + g) * row_stride + q * kBlock + 2 * lane;
+        if constexpr (!Cg::kPrefetch) request_head(f0 + g);
+        phases_ab(std::true_type{}, nxt, src, nx, stash, g, xr, xi);
+        // the head of the next frame's block is requested here, before the FFT, and lands behind it
         if constexpr (Cg::kPrefetch) {
           long long f_next = 0;                             // (it, g + 1), or the first frame of the next round
           const bool more = g + 1 < n_here ? frame_at(it, g + 1, f_next) : frame_at(it + 1, 0, f_next);
-          if (more) load_block(nxt, f_next);
+          if (more) request_head(f_next);
         }
         __builtin_amdgcn_sched_barrier(0);
         phase_c(xr, xi, stash, g);
