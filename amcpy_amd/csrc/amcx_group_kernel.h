@@ -185,19 +185,26 @@ __device__ __attribute__((noinline)) void group_finalise(const float2* __restric
   float kw0 = 0.f;
   if (lane < count) {
     const float* rows = stash + lane * W * kStashRow;
-    auto sm = [&](int k) -> double {                        // shift-free sums: the W blocks added in fp64
+    // The sums are fetched GROUP BY GROUP, each right before the features that need it (amcx_math.h: phase_features,
+    // envelope_features, moment_features = finalize_features in pieces): all thirty at once, next to the re-centring
+    // accumulators, do not fit 128 registers.  z collects 0 * x of every sum: NaN as soon as one is not finite
+    // (is_outside_fp32_range's test).
+    double z = 0.0;
+    auto sm = [&](int k) -> double {                        // a shift-free sum: the W blocks added in fp64
       double t = 0.0;
 #pragma unroll
       for (int h = 0; h < W; h += 2) t += (double)rows[h * kStashRow + k] + (double)rows[(h + 1) * kStashRow + k];
+      z = __builtin_fma(t, 0.0, z);
       return t;
     };
-    FrameSums F;
-    F.sA = sm(0); F.sBh = sm(1); F.sP = sm(2); F.sAA = sm(3); F.sX4 = sm(4); F.sAB = sm(5);
-    F.sAP = sm(6); F.sBP = sm(7); F.sAAA = sm(8); F.sABB = sm(9); F.sAAB = sm(10);
-    F.sBBB = sm(11); F.sAAP = sm(12); F.sX4P = sm(13); F.sABP = sm(14);
-    F.sa = sm(15); F.sad1 = sm(16); F.sad2 = sm(17); F.sad4 = sm(18);
-    // shifted sums: re-centred about block 0's shifts
-    F.Kt = rows[28]; F.Kw = rows[29]; F.Ka = rows[30];
+    [[maybe_unused]] const int hx = ex_pow / 2;             // ex is even: 2^(hx * twice_order) is exact
+    auto put = [&](int j, int twice_order, double v) {
+      if constexpr (RG) v = __builtin_ldexp(v, hx * twice_order);
+      feat[j] = (float)v;
+    };
+    const double n = (double)kN;
+    // ---- shifted sums, re-centred about block 0's shifts; the peak; the tie flag
+    const double Kt = rows[28], Kw = rows[29], Ka = rows[30];
     kw0 = rows[29];
     Recentred th, ab, ws;
     float pk = 0.f;
@@ -205,22 +212,54 @@ __device__ __attribute__((noinline)) void group_finalise(const float2* __restric
 #pragma unroll 1
     for (int h = 0; h < W; ++h) {
       const float* r = rows + h * kStashRow;
-      th.add((double)kBlock, (double)r[28] - F.Kt, r[19], r[20]);
-      ab.add((double)kBlock, (double)r[30] - F.Ka, r[21], r[22]);
-      ws.add(h == W - 1 ? (double)(kBlock - 1) : (double)kBlock, (double)r[29] - F.Kw, r[23], r[24], r[25], r[26]);
+      th.add((double)kBlock, (double)r[28] - Kt, r[19], r[20]);
+      ab.add((double)kBlock, (double)r[30] - Ka, r[21], r[22]);
+      ws.add(h == W - 1 ? (double)(kBlock - 1) : (double)kBlock, (double)r[29] - Kw, r[23], r[24], r[25], r[26]);
       pk = __builtin_fmaxf(pk, r[27]);
       if (!(r[27] == r[27])) pk = r[27];                    // a NaN peak (non-finite sample) must survive the maximum
       flagged = flagged || r[31] != 0.0f;
     }
-    F.std1 = th.s1; F.std2 = th.s2; F.sab1 = ab.s1; F.sab2 = ab.s2;
-    F.swd1 = ws.s1; F.swd2 = ws.s2; F.swd3 = ws.s3; F.swd4 = ws.s4;
-    F.gmax_raw = pk;
-    F.pi_tie = flagged;
-    if constexpr (RG) {
-      finalize_features<true>(F, kN, feat, ex_pow);
+    z = __builtin_fma((double)pk, 0.0, z);
+    const double sP = sm(2);
+    const bool zero_frame = sP <= 2.0 * n * (double)kTinyPower;
+    const bool all_nan = !(__builtin_fabs(sP) <= 1.79e308) || !(pk == pk);   // non-finite input anywhere: 18 NaNs (finalize_features)
+    if (all_nan) {
+#pragma unroll
+      for (int j = 0; j < 18; ++j) feat[j] = __builtin_nanf("");
     } else {
-      finalize_features(F, kN, feat);
-      if (is_outside_fp32_range(F, kN)) {                   // re-run by the whole group at the end of the epoch; not stored now
+      put(0, 4, (double)pk * (1.0 / n));
+      phase_features(th.s1, th.s2, ab.s1, ab.s2, n, put);
+      frequency_features(Kw, ws.s1, ws.s2, ws.s3, ws.s4, kN, feat[4], feat[8]);
+      if (flagged) feat[4] = -feat[4];                      // picked up below (wave_exact_frequency)
+    }
+    {
+      const double sa = sm(15), sad2 = sm(17), sad4 = sm(18);
+      if (!all_nan) {
+        double sad1 = 0.0;                                  // (not part of the finiteness test)
+#pragma unroll
+        for (int h = 0; h < W; h += 2) sad1 += (double)rows[h * kStashRow + 16] + (double)rows[(h + 1) * kStashRow + 16];
+        envelope_features(sa, sad1, sad2, sad4, zero_frame, n, put);
+      }
+    }
+    {
+      const double sA = sm(0), sBh = sm(1), sAA = sm(3), sX4 = sm(4), sAB = sm(5), sAP = sm(6), sBP = sm(7), sAAA = sm(8),
+                   sABB = sm(9), sAAB = sm(10), sBBB = sm(11), sAAP = sm(12), sX4P = sm(13), sABP = sm(14);
+      if (!all_nan) {
+        if (zero_frame) {                                   // the guard's kTinyPower must not leak into |C20| ... |C63| of a zero frame
+#pragma unroll
+          for (int j = 9; j < 18; ++j) feat[j] = 0.f;
+        } else {
+          moment_features(sA, sBh, sP, sAA, sX4, sAB, sAP, sBP, sAAA, sABB, sAAB, sBBB, sAAP, sX4P, sABP, n, put);
+        }
+      }
+    }
+    if constexpr (!RG) {
+      // is_outside_fp32_range, on the sums as they went by: some sum not finite, or the mean power outside the range the fp32
+      // sums are trusted in (an all-zero frame stays) -> re-run by the whole group at the end of the epoch; not stored now
+      const bool zeros = zero_frame && th.s2 == 0.0 && ab.s2 == 0.0 && Kt == 0.0;
+      const double pbar = sP / n;
+      const bool outside = (sP == sP) && ((z != z) || (!zeros && !(pbar >= kRangeLoPower && pbar <= kRangeHiPower)));
+      if (outside) {
         marked = true;
         const unsigned bit = (unsigned)(f_first + lane - epoch_f0);
         __hip_atomic_fetch_or(&redo_mask[bit >> 5], 1u << (bit & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

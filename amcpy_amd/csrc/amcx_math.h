@@ -283,4 +283,98 @@ __device__ inline void finalize_features(const FrameSums& s, int N, float* __res
   }
 }
 
+// finalize_features in PIECES, each from the sums it needs alone, for a caller whose sums come from several places
+// (amcx_group_kernel.h: W stash rows per frame) and who fetches them group by group instead of holding all thirty at once
+// -- at 128 registers the monolithic form spilled ~100 values per call there.  The same formulas, statement for
+// statement; finalize_features itself is left exactly as it is, because re-expressing it through these pieces changes the
+// machine code of every wave kernel (tools/codeobj_gate.py --kernels), and those are tuned to the register.
+// put(j, twice_order, v) stores feature j (0-based); twice_order: see finalize_features<SCALED>.
+//
+// f2 = std1(|theta|), f3 = std1(theta); both from sums about a shift close to the mean (no E[v^2] - E[v]^2 on raw values:
+// |theta| can have a tiny variance around pi/2 while theta itself spans +-pi)
+template <class Put>
+__device__ __forceinline__ void phase_features(double std1, double std2, double sab1, double sab2, double n, Put&& put) {
+  const double inv = 1.0 / n, inv_nm1 = 1.0 / (n - 1.0);
+  const double md = std1 * inv;                         // mean of shifted theta
+  double ct2 = std2 - n * md * md;                      // sum (theta-mean)^2
+  if (ct2 < 0) ct2 = 0;
+  const double ma = sab1 * inv;                         // mean of shifted |theta|
+  double cabs2 = sab2 - n * ma * ma;                    // sum (|theta|-mean)^2
+  if (cabs2 < 0) cabs2 = 0;
+  put(1, 0, q_sqrt(cabs2 * inv_nm1));
+  put(2, 0, q_sqrt(ct2 * inv_nm1));
+}
+
+// envelope: f4, f6, f7, f8.  An all-zero frame reaches here as N samples of power kTinyPower (the angle guard): the exact
+// zeros are restored so that f4 is 0/0 = NaN as in the reference
+template <class Put>
+__device__ __forceinline__ void envelope_features(double sa, double sad1, double sad2, double sad4, bool zero_frame, double n,
+                                                  Put&& put) {
+  const double inv = 1.0 / n, inv_nm1 = 1.0 / (n - 1.0);
+  const double mu = zero_frame ? 0.0 : sa * inv;
+  const double mad = sad1 * inv;                        // mean |a-mu|
+  double v = sad2 - n * mad * mad;                      // sum (|a-mu| - mad)^2
+  if (v < 0) v = 0;
+  put(3, 0, q_div(q_sqrt(v * inv_nm1), mu));            // 0/0 -> NaN for a zero frame
+  put(5, 2, mu);
+  put(6, 1, q_sqrt(zero_frame ? 0.0 : sa) * inv);
+  const double m2 = sad2 * inv, m4 = sad4 * inv;
+  put(7, 0, q_div(m4, m2 * m2));                        // m2 == 0 -> NaN (scipy rule)
+}
+
+// |C20| ... |C63| from the 15 mixed-moment sums (complex as (re, im) pairs).  Formulas: features.py:116-185; C60 uses
+// +3*m20^3 and m62 is real-only, as the reference has them (features.py:147,57).
+template <class Put>
+__device__ __forceinline__ void moment_features(double sA, double sBh, double sP, double sAA, double sX4, double sAB, double sAP,
+                                                double sBP, double sAAA, double sABB, double sAAB, double sBBB, double sAAP,
+                                                double sX4P, double sABP, double n, Put&& put) {
+  const double inv = 1.0 / n;
+  const double m20r = sA * inv, m20i = 2.0 * sBh * inv;
+  const double m21 = sP * inv;
+  const double m40r = sX4 * inv, m40i = 4.0 * sAB * inv;
+  const double m41r = sAP * inv, m41i = 2.0 * sBP * inv;
+  const double m42 = (2.0 * sAA - sX4) * inv;                         // mean P^2 = A^2 + 4 Bh^2
+  const double m60r = (sAAA - 12.0 * sABB) * inv;                     // Re (A+iB)^3, B = 2Bh
+  const double m60i = (6.0 * sAAB - 8.0 * sBBB) * inv;
+  const double m61r = sX4P * inv, m61i = 4.0 * sABP * inv;
+  const double m62 = (sAAA + 4.0 * sABB) * inv;                       // mean A*P^2 (real only)
+  const double m63 = (2.0 * sAAP - sX4P) * inv;                       // mean P^3
+  // m22 = conj(m20), m43 = conj(m41)
+
+  auto cabs = [](double r, double i) { return q_sqrt(r * r + i * i); };
+  const double q20r = m20r * m20r - m20i * m20i, q20i = 2.0 * m20r * m20i;   // m20^2
+  const double n20 = m20r * m20r + m20i * m20i;                              // |m20|^2
+
+  put(9, 4, cabs(m20r, m20i));                                               // C20
+  put(10, 4, __builtin_fabs(m21));                                           // C21
+  put(11, 8, cabs(m40r - 3.0 * q20r, m40i - 3.0 * q20i));                    // C40
+  put(12, 8, cabs(m41r - 3.0 * m20r * m21, m41i - 3.0 * m20i * m21));        // C41
+  put(13, 8, __builtin_fabs(m42 - n20 - 2.0 * m21 * m21));                   // C42
+  {  // C60 = m60 - 15 m20 m40 + 3 m20^3
+    const double pr = m20r * m40r - m20i * m40i, pi = m20r * m40i + m20i * m40r;
+    const double cr = q20r * m20r - q20i * m20i, ci = q20r * m20i + q20i * m20r;
+    put(14, 12, cabs(m60r - 15.0 * pr + 3.0 * cr, m60i - 15.0 * pi + 3.0 * ci));
+  }
+  {  // C61 = m61 - 5 m21 m40 - 10 m20 m41 + 30 m20^2 m21
+    const double pr = m20r * m41r - m20i * m41i, pi = m20r * m41i + m20i * m41r;
+    put(15, 12, cabs(m61r - 5.0 * m21 * m40r - 10.0 * pr + 30.0 * q20r * m21,
+                     m61i - 5.0 * m21 * m40i - 10.0 * pi + 30.0 * q20i * m21));
+  }
+  {  // C62 = m62 - 6 m20 m42 - 8 m21 m41 - m22 m40 + 6 m20^2 m22 + 24 m21^2 m20
+    // m22 m40 = conj(m20) m40 ; m20^2 m22 = m20 |m20|^2
+    const double ar = m20r * m40r + m20i * m40i, ai = m20r * m40i - m20i * m40r;
+    const double re = m62 - 6.0 * m20r * m42 - 8.0 * m21 * m41r - ar + 6.0 * m20r * n20 +
+                      24.0 * m21 * m21 * m20r;
+    const double im = -6.0 * m20i * m42 - 8.0 * m21 * m41i - ai + 6.0 * m20i * n20 +
+                      24.0 * m21 * m21 * m20i;
+    put(16, 12, cabs(re, im));
+  }
+  {  // C63 = m63 - 9 m21 m42 + 12 m21^3 - 3 m20 m43 - 3 m22 m41 + 18 m20 m21 m22
+    // m20 conj(m41) + conj(m20) m41 = 2 Re(m20 conj(m41)), real
+    const double cross = 2.0 * (m20r * m41r + m20i * m41i);
+    put(17, 12, __builtin_fabs(m63 - 9.0 * m21 * m42 + 12.0 * m21 * m21 * m21 -
+                               3.0 * cross + 18.0 * m21 * n20));
+  }
+}
+
 }  // namespace amcx

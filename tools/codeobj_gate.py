@@ -4,6 +4,8 @@
     python tools/codeobj_gate.py A.so B.so          # exit 0 iff the gfx950 code objects are byte-identical
     python tools/codeobj_gate.py --ref REV           # builds REV's sources aside and compares with amcpy_amd/lib/libamcx.so
     python tools/codeobj_gate.py --print [LIB]       # SHA-256 of the code object and of its .text section
+    python tools/codeobj_gate.py --kernels A.so B.so # per KERNEL: which kernels' machine code differs (a change to one kernel,
+                                                     # or to a header several share, must leave the others' bytes alone)
     python tools/codeobj_gate.py --update            # rewrite amcpy_amd/csrc/codeobj.json from the built library
 
 The gfx950 code object is taken out of the library the way tools/resource_usage.py does (.hip_fatbin -> clang-offload-
@@ -34,6 +36,32 @@ def digests(lib) -> dict:
                 "text_sha256": hashlib.sha256(text.read_bytes()).hexdigest(), "text_bytes": text.stat().st_size}
 
 
+def kernel_digests(lib) -> dict:
+    """{demangled kernel / device function name: SHA-256 of its bytes in .text} of the gfx950 code object."""
+    with tempfile.TemporaryDirectory() as d:
+        fat, co = Path(d) / "fat.bin", Path(d) / "gfx950.co"
+        subprocess.run([str(LLVM / "llvm-objcopy"), f"--dump-section=.hip_fatbin={fat}", str(lib)], check=True)
+        subprocess.run([str(LLVM / "clang-offload-bundler"), "--unbundle", "--type=o",
+                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}", f"--output={co}"], check=True)
+        sec = subprocess.run([str(LLVM / "llvm-readelf"), "-S", "-W", str(co)], capture_output=True, text=True, check=True).stdout
+        addr = off = None
+        for line in sec.splitlines():
+            f = line.replace("[", " ").replace("]", " ").split()
+            if len(f) > 5 and f[1] == ".text":
+                addr, off = int(f[3], 16), int(f[4], 16)
+        syms = subprocess.run([str(LLVM / "llvm-readelf"), "-s", "-W", str(co)], capture_output=True, text=True, check=True).stdout
+        blob = co.read_bytes()
+        out = {}
+        for line in syms.splitlines():
+            f = line.split()
+            if len(f) >= 8 and f[3] == "FUNC" and int(f[2]) > 0:
+                a, n, name = int(f[1], 16), int(f[2]), f[7]
+                nice = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip().split("(")[0]
+                nice = nice.replace("void ", "").replace("(anonymous namespace)::", "")
+                out[nice] = hashlib.sha256(blob[off + a - addr: off + a - addr + n]).hexdigest()
+        return out
+
+
 def build_rev(rev: str, out: Path) -> None:
     with tempfile.TemporaryDirectory() as d:
         tar = subprocess.run(["git", "-C", str(REPO), "archive", rev, "amcpy_amd", "include"], check=True, capture_output=True).stdout
@@ -50,6 +78,17 @@ def main(argv) -> int:
         TABLE.write_text(json.dumps(digests(LIB), indent=1) + "\n")
         print(f"wrote {TABLE}")
         return 0
+    if argv and argv[0] == "--kernels" and len(argv) == 3:
+        a, b = kernel_digests(argv[1]), kernel_digests(argv[2])
+        changed = sorted(k for k in a.keys() & b.keys() if a[k] != b[k])
+        print(f"{len(a.keys() & b.keys()) - len(changed)} kernels / device functions identical")
+        for k in changed:
+            print("DIFFERENT ", k)
+        for k in sorted(a.keys() - b.keys()):
+            print("ONLY IN A ", k)
+        for k in sorted(b.keys() - a.keys()):
+            print("ONLY IN B ", k)
+        return 0 if not changed else 1
     if argv and argv[0] == "--ref":
         with tempfile.TemporaryDirectory() as d:
             other = Path(d) / "ref.so"
