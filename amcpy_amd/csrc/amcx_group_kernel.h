@@ -64,13 +64,15 @@ struct G {
   static constexpr int kStride0 = W / kRadix0;              // = 4: the second stage is the quad's radix 4 over neighbours
   static_assert(kStride0 == 4, "two stages, the second of radix 4");
   static constexpr int kBatch = W == 16 ? 2 : 8;            // frames finalised together (W = 16: what the LDS left over holds)
-  // W = 8: the first HALF of the next frame's block is requested before this frame's FFT and lands behind it (eight rows =
-  // 32 registers: all sixteen did not fit next to the FFT's own and were stored to scratch straight from the load, behind a
-  // wait); the second half is requested at the head of the next sweep and arrives while the first is swept.  W = 16 (128
-  // registers): nothing ahead of the frame; rows 12-15 are requested when rows 0-3 have been swept.
-  static constexpr bool kPrefetch = W <= 8;
-  static constexpr int kLateRow = W == 8 ? 8 : 12;          // rows from here on are requested inside the sweep ...
-  static constexpr int kLateAt = W == 8 ? 0 : 4;            // ... before row kLateAt is swept
+  // W = 8: the first HALF of the next frame's block (rows 0-7, 32 registers) is requested before this frame's FFT and lands
+  // behind it (all sixteen rows did not fit next to the FFT's own registers and were stored to scratch straight from the
+  // load, behind a wait); the second half is requested at the head of the next sweep and arrives while the first is swept.
+  // W = 16 (128 registers): nothing ahead of the frame -- a head of eight or of four rows requested between the FFT's two
+  // halves (a hook in fft_peak: built, measured at the ISA) costs 90 - 126 spilled values per frame --; rows 0-11 are
+  // requested at the head of the sweep, rows 12-15 when rows 0-3 have been swept and released.
+  static constexpr int kHeadRows = W == 8 ? 8 : 0;          // rows requested a frame ahead
+  static constexpr int kLateSplit = W == 8 ? kRowsB : 12;    // rows [kHeadRows, kLateSplit) are requested before row 0 is swept,
+  static constexpr int kLateAt = 4;                          // rows [kLateSplit, 16) before row kLateAt
   // rows of a block exchanged per round of a stage: all sixteen where the LDS holds W regions of 16 KiB (W = 8: two barriers
   // per stage), eight otherwise (W = 16: the region is the FFT exchange buffer's 8 672 bytes, four barriers per stage)
   static constexpr int kRoundRows = W == 8 ? 16 : 8;
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(64 * W, 1) void amcx_features18_group_kernel(
   };
   using Row0 = std::integral_constant<int, 0>;
   using Row8 = std::integral_constant<int, 8>;
-  constexpr int kLateRow = Cg::kLateRow, kLateAt = Cg::kLateAt;
+  constexpr int kHeadRows = Cg::kHeadRows, kLateSplit = Cg::kLateSplit, kLateAt = Cg::kLateAt;
 
   // ---- a frame, phases A and B: statistics sweep of this wave's block (v: its 16 rows as loaded; nx = the first sample
   // of the next block), envelope about the exact mean, sums -> stash row (g, q), the two stages: xr / xi leave as this
@@ -393,10 +395,17 @@ __global__ __launch_bounds__(64 * W, 1) void amcx_features18_group_kernel(
     AMCX_GROUP_PRIO(0);
     static_for<kRowsB>([&](auto ii) {
       constexpr int i = decltype(ii)::value;
-      if constexpr (LATE && i == kLateAt) {
+      if constexpr (LATE && i == 0) {
+        static_for<kLateSplit - kHeadRows>([&](auto kk) {
+          constexpr int k = kHeadRows + decltype(kk)::value;
+          v[k] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(late_src + 128 * k));
+        });
         __builtin_amdgcn_sched_barrier(0);
-        static_for<kRowsB - kLateRow>([&](auto kk) {
-          constexpr int k = kLateRow + decltype(kk)::value;
+      }
+      if constexpr (LATE && i == kLateAt && kLateSplit < kRowsB) {
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<kRowsB - kLateSplit>([&](auto kk) {
+          constexpr int k = kLateSplit + decltype(kk)::value;
           v[k] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(late_src + 128 * k));
         });
         __builtin_amdgcn_sched_barrier(0);
@@ -517,15 +526,15 @@ __global__ __launch_bounds__(64 * W, 1) void amcx_features18_group_kernel(
       f = (eb0 + it) * kBatch + g;
       return it < n_iters && f < n_frames;
     };
-    v4f nxt[kRowsB];                                        // W = 8: rows 0 .. kLateRow-1 hold the NEXT frame's, requested a frame ago
+    v4f nxt[kRowsB];                                        // rows 0 .. kHeadRows-1 hold the NEXT frame's, requested a frame ago
     auto request_head = [&](long long f) {
       const float2* src = iq + f * row_stride + q * kBlock + 2 * lane;
-      static_for<kLateRow>([&](auto ii) {
+      static_for<kHeadRows>([&](auto ii) {
         constexpr int i = decltype(ii)::value;
         nxt[i] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src + 128 * i));
       });
     };
-    if constexpr (Cg::kPrefetch) {
+    if constexpr (kHeadRows > 0) {
       long long f_first;
       if (frame_at(0, 0, f_first)) request_head(f_first);
     }
@@ -540,10 +549,9 @@ __global__ __launch_bounds__(64 * W, 1) void amcx_features18_group_kernel(
         float2 nx = make_float2(1.f, 0.f);
         if (q < W - 1) nx = iq[(f0 + g) * row_stride + (q + 1) * kBlock];
         const float2* src = iq + (f0 + g) * row_stride + q * kBlock + 2 * lane;
-        if constexpr (!Cg::kPrefetch) request_head(f0 + g);
         phases_ab(std::true_type{}, nxt, src, nx, stash, g, xr, xi);
-        // the head of the next frame's block is requested here, before the FFT, and lands behind it
-        if constexpr (Cg::kPrefetch) {
+        // W = 8: the head of the next frame's block is requested here, before the FFT, and lands behind it
+        if constexpr (kHeadRows > 0) {
           long long f_next = 0;                             // (it, g + 1), or the first frame of the next round
           const bool more = g + 1 < n_here ? frame_at(it, g + 1, f_next) : frame_at(it + 1, 0, f_next);
           if (more) request_head(f_next);
