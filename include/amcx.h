@@ -32,11 +32,12 @@
  *     a frame outside that (or any of whose sums overflows: a single 1e7 sample among unit
  *     ones) is re-run on a copy multiplied by an exact power of two by the throughput kernel itself
  *     -- at the frame sizes 128 ... 4096 right behind the batch it was found in, at 8192 in a pass of
- *     the quad at the end of the launch (a data set that is out of range throughout, e.g. raw 24-bit
- *     ADC counts, runs at half the normal rate) -- so
+ *     the quad at the end of the launch, at 16384 / 32768 at the end of every epoch of 2048 frames of a
+ *     workgroup (a data set that is out of range throughout, e.g. raw 24-bit ADC counts, runs at half
+ *     the normal rate) -- so
  *     results match the reference, which evaluates in complex128 (features.py:46-58), including
  *     the inf / 0 / denormals its float32 store produces (feature_extraction.py:35,56).
- *   - AMCX_VARIANT_WAVE / AUTO at a power-of-two frame size 128 ... 8192 is ONE launch on the stream; when
+ *   - AMCX_VARIANT_WAVE / AUTO at a power-of-two frame size 128 ... 32768 is ONE launch on the stream; when
  *     it has completed every row is final (ABI 3 as built in rounds 2-3 took two launches and left out-of-range
  *     frames marked in band in between, and so did N = 8192 until late in round 4).  Frames with a phase step
  *     within an fp32 ulp of +-pi are finished exactly inside every throughput kernel.
