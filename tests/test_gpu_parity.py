@@ -326,6 +326,64 @@ def test_group_kernels_16384_and_32768(N, W):
     assert (np.isinf(want) == np.isinf(b)).all()
 
 
+@pytest.mark.parametrize("N,W,extra", [(16384, 8, 1024), (32768, 16, 512)])
+def test_group_kernels_across_epoch_boundaries(N, W, extra):
+    """The group kernels keep their re-run list as a bit mask in LDS that covers one EPOCH of 2048 frames of a workgroup;
+    a launch in which every workgroup owns more than 2048 frames (256 workgroups x 2048 frames and some: 69 GB at N = 16384,
+    137 GB at N = 32768 -- a fraction of the card's 288 GB) crosses epoch boundaries everywhere.  A block of ordinary frames is
+    tiled over the arena; frames out of the fp32 sums' range are planted in the last frames of a first epoch, the first of a
+    second one, mid-epoch, and at the very end.  Every row must equal the row of the same frame computed in a small launch
+    (bit for bit: results do not depend on the position), so a mark set in one epoch and re-run in another, a mark lost at a
+    boundary, or a re-run of the wrong frame shows."""
+    torch = _torch()
+    from amcpy_amd import synth
+    from amcpy_amd.features import features18
+    free, _ = torch.cuda.mem_get_info()
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    F = cus * 2048 + extra * (cus // 256 or 1)
+    need = F * N * 8 + (4 << 30)
+    if free < need:
+        pytest.skip(f"needs {need >> 30} GiB of free device memory")
+    T = 512                                                              # the tile: 512 ordinary frames
+    tile = torch.from_numpy(np.concatenate([synth.host_block(m, 8.0, T // 4, N, seed=N + i)
+                                            for i, m in enumerate(("BPSK", "QPSK", "64QAM", "WGN"))])).cuda()
+    arena = torch.empty((F, N), dtype=torch.complex64, device="cuda")
+    for a in range(0, F, T):
+        b = min(F, a + T)
+        arena[a:b] = tile[: b - a]
+    batch = 8 if W == 8 else 2
+    per_wg = -(-(-(-F // batch)) // cus) * batch                         # frames a workgroup owns (ceil over batches)
+    assert per_wg > 2048                                                 # every workgroup crosses an epoch boundary
+    planted = sorted({2046, 2047, 2048, 2049, 3, per_wg + 2047, per_wg + 2048, 5 * per_wg + 1000, F - 1, F - 2,
+                      (cus - 1) * per_wg + 2048})
+    planted = [f for f in planted if f < F]
+    scales = [2.0 ** (26 + 2 * (k % 4)) if k % 2 == 0 else 2.0 ** (-(30 + 2 * (k % 3))) for k in range(len(planted))]
+    for f, sc in zip(planted, scales):
+        arena[f] *= sc
+    out = features18(arena)
+    torch.cuda.synchronize()
+    base = features18(tile)                                              # the tile alone: one small launch
+    small = features18(arena[torch.tensor(planted, device="cuda")].contiguous())
+    torch.cuda.synchronize()
+    got = out.view(torch.int32)
+    idx = torch.arange(F, device="cuda") % T
+    want = base.view(torch.int32)[idx]
+    pl = torch.tensor(planted, device="cuda")
+    want[pl] = small.view(torch.int32)
+    bad = (got != want).any(dim=1).nonzero().flatten()
+    assert bad.numel() == 0, (N, bad[:10].tolist(), per_wg)
+    # and the planted frames really took the re-run path: their scale-free features equal the ordinary frame's closely,
+    # their scaled ones follow the scaling laws (exactly, as powers of two)
+    order = torch.tensor([2, 0, 0, 0, 0, 1, 0.5, 0, 0, 2, 2, 4, 4, 4, 6, 6, 6, 6], dtype=torch.float64, device="cuda")
+    ref = base.double()[pl % T] * torch.tensor(scales, dtype=torch.float64, device="cuda")[:, None] ** order[None, :]
+    fin = torch.isfinite(ref.float()) & (ref.float() != 0)
+    rel = ((small.double() - ref).abs() / ref.abs())
+    rel[~fin] = 0.0
+    strict = [0, 1, 2, 3, 4, 5, 6, 7, 8, 10]                          # ids 1-9 and 11: not cancellation-dominated
+    assert rel[:, strict].max() < 1e-5 and rel.max() < 1e-3, (rel[:, strict].max(), rel.max())
+    del arena, out
+
+
 def test_bad_frames_do_not_leak_into_neighbours():
     """Grouped short frames share FFT passes 2-3 and a finaliser batch; the ping-pong variants
     share registers across frames: a NaN / Inf / all-zero frame in the middle of a batch must
