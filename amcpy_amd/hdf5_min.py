@@ -134,6 +134,12 @@ def _declare(lib):
         "H5Aget_type": (hid_t, [hid_t]),
         "H5Aread": (herr_t, [hid_t, hid_t, ctypes.c_void_p]),
         "H5Aclose": (herr_t, [hid_t]),
+        "H5Tcopy": (hid_t, [hid_t]),
+        "H5Tset_size": (herr_t, [hid_t, ctypes.c_size_t]),
+        "H5Acreate2": (hid_t, [hid_t, ctypes.c_char_p, hid_t, hid_t, hid_t, hid_t]),
+        "H5Awrite": (herr_t, [hid_t, hid_t, ctypes.c_void_p]),
+        "H5Screate": (hid_t, [ctypes.c_int]),
+        "H5Pset_userblock": (herr_t, [hid_t, hsize_t]),
         "H5Pcreate": (hid_t, [hid_t]),
         "H5Pclose": (herr_t, [hid_t]),
         "H5Pset_chunk": (herr_t, [hid_t, ctypes.c_int, P(hsize_t)]),
@@ -154,6 +160,16 @@ def _declare(lib):
             lib._amcx_raw_chunks = False
         else:
             fn.restype, fn.argtypes = res, args
+
+
+def write_matlab_header(path, text: str = "MATLAB 7.3 MAT-file, Platform: GLNXA64, Created by amcpy_amd.hdf5_min HDF5 schema 1.00 .") -> None:
+    """Fill the 512-byte user block of a file created with ``File(path, "w", userblock=512)`` with MATLAB's -v7.3 header:
+    116 bytes of text, 8 of subsystem offset, version 0x0200 and the endian indicator "IM"."""
+    block = bytearray(b" " * 116 + b"\0" * 8 + bytes([0x00, 0x02]) + b"IM" + b"\0" * 384)
+    head = text.encode("ascii")[:116]
+    block[:len(head)] = head
+    with open(path, "r+b") as fh:
+        fh.write(bytes(block))
 
 
 def available() -> bool:
@@ -455,7 +471,9 @@ class Dataset:
 class File:
     """An HDF5 file: read-only by default (``mode="w"`` truncates; the tests write the file they read)."""
 
-    def __init__(self, path, mode: str = "r"):
+    def __init__(self, path, mode: str = "r", userblock: int = 0):
+        """``userblock`` (mode "w"): bytes reserved in front of the HDF5 superblock (512, 1024, ...: MATLAB's -v7.3 header
+        lives there; :func:`write_matlab_header` fills it after ``close()``)."""
         lib = _lib()
         self.path = str(path)
         self._sets = []
@@ -465,7 +483,13 @@ class File:
                     raise FileNotFoundError(self.path)
                 self._id = lib.H5Fopen(self.path.encode(), H5F_ACC_RDONLY, H5P_DEFAULT)
             elif mode == "w":
-                self._id = lib.H5Fcreate(self.path.encode(), H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT)
+                fcpl = H5P_DEFAULT
+                if userblock:
+                    fcpl = lib.H5Pcreate(hid_t.in_dll(lib, "H5P_CLS_FILE_CREATE_ID_g").value)
+                    lib.H5Pset_userblock(fcpl, int(userblock))
+                self._id = lib.H5Fcreate(self.path.encode(), H5F_ACC_TRUNC, fcpl, H5P_DEFAULT)
+                if fcpl != H5P_DEFAULT:
+                    lib.H5Pclose(fcpl)
             else:
                 raise ValueError("mode is 'r' or 'w'")
             if self._id < 0:
@@ -483,8 +507,11 @@ class File:
         return ds
 
     def create_dataset(self, name: str, data: np.ndarray, chunks: Optional[Tuple[int, ...]] = None,
-                       deflate: Optional[int] = None) -> None:
-        """Write ``data`` as dataset ``name`` -- contiguous, or chunked (and deflate-compressed) when ``chunks`` is given."""
+                       deflate: Optional[int] = None, matlab_class: Optional[str] = None) -> None:
+        """Write ``data`` as dataset ``name`` -- contiguous, or chunked (and deflate-compressed) when ``chunks`` is given.
+        complex64 / complex128 data goes out as the compound ``{real, imag}`` MATLAB's -v7.3 files use; ``matlab_class``
+        adds the ``MATLAB_class`` string attribute.  (``data`` is written in ITS shape: a MATLAB (S, K, L) variable is the
+        dataset of ``np.asfortranarray(x).T``'s shape -- :func:`write_mat73_variable` does that.)"""
         lib = _lib()
         data = np.ascontiguousarray(data)
         with _LOCK:
@@ -495,17 +522,48 @@ class File:
                 lib.H5Pset_chunk(dcpl, data.ndim, _dims(chunks))
                 if deflate is not None:
                     lib.H5Pset_deflate(dcpl, int(deflate))
-            tid = _native_type(lib, data.dtype)
+            close_tid = False
+            if data.dtype.kind == "c":
+                part = np.dtype(f"f{data.dtype.itemsize // 2}")
+                tid = lib.H5Tcreate(H5T_COMPOUND, data.dtype.itemsize)
+                lib.H5Tinsert(tid, b"real", 0, _native_type(lib, part))
+                lib.H5Tinsert(tid, b"imag", part.itemsize, _native_type(lib, part))
+                close_tid = True
+            else:
+                tid = _native_type(lib, data.dtype)
             dset = lib.H5Dcreate2(self._id, name.encode(), tid, space, H5P_DEFAULT, dcpl, H5P_DEFAULT)
             try:
                 if dset < 0 or lib.H5Dwrite(dset, tid, H5S_ALL, H5S_ALL, H5P_DEFAULT, data.ctypes.data_as(ctypes.c_void_p)) < 0:
                     raise OSError(f"{self.path}: writing {name!r} failed")
+                if matlab_class is not None:
+                    text = matlab_class.encode("ascii")
+                    st = lib.H5Tcopy(hid_t.in_dll(lib, "H5T_C_S1_g").value)
+                    lib.H5Tset_size(st, len(text))
+                    sp = lib.H5Screate(0)                       # H5S_SCALAR
+                    at = lib.H5Acreate2(dset, b"MATLAB_class", st, sp, H5P_DEFAULT, H5P_DEFAULT)
+                    try:
+                        if at < 0 or lib.H5Awrite(at, st, ctypes.c_char_p(text)) < 0:
+                            raise OSError(f"{self.path}: writing the MATLAB_class attribute of {name!r} failed")
+                    finally:
+                        if at >= 0:
+                            lib.H5Aclose(at)
+                        lib.H5Sclose(sp)
+                        lib.H5Tclose(st)
             finally:
                 if dset >= 0:
                     lib.H5Dclose(dset)
+                if close_tid:
+                    lib.H5Tclose(tid)
                 if dcpl != H5P_DEFAULT:
                     lib.H5Pclose(dcpl)
                 lib.H5Sclose(space)
+
+    def write_mat73_variable(self, name: str, x: np.ndarray, chunks: Optional[Tuple[int, ...]] = None,
+                             deflate: Optional[int] = None) -> None:
+        """A MATLAB variable the way ``save -v7.3`` lays it out: the dataset has the REVERSED shape (its bytes are the
+        column-major variable), complex as ``{real, imag}``, ``MATLAB_class`` double / single."""
+        cls = {"f8": "double", "c16": "double", "f4": "single", "c8": "single"}[np.dtype(x.dtype).str[1:]]
+        self.create_dataset(name, np.ascontiguousarray(np.asarray(x).T), chunks=chunks, deflate=deflate, matlab_class=cls)
 
     def close(self):
         with _LOCK:

@@ -580,6 +580,43 @@ def test_mat73_container_reads_bit_for_bit(tmp_path):
         assert fh["signal_bpsk"][37:222].shape == (185, 5, 2) and np.array_equal(fh["signal_bpsk"][37:222], fh["signal_bpsk"][:][37:222])
 
 
+def test_hdf5_min_writes_the_mat73_layout_it_reads(tmp_path):
+    """hdf5_min's own writer of MATLAB's -v7.3 layout (user block with the MATLAB header, reversed dimensions, {real, imag}
+    compounds, MATLAB_class) -- what tools/mat73_ingest_probe.py writes a configs[1]-sized container with -- read back
+    through matfile.load_variable both ways, contiguous and chunked + deflate, double and single, complex and real; and
+    refused by scipy.io.loadmat the way a real -v7.3 file is."""
+    import scipy.io
+    from amcpy_amd import hdf5_min, matfile
+    from amcpy_amd.feature_extraction import FileComplex
+    if not hdf5_min.available():
+        pytest.skip("no HDF5 C library on this machine")
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((3, 7, 40)) + 1j * rng.standard_normal((3, 7, 40))
+    path = tmp_path / "own.mat"
+    with hdf5_min.File(path, "w", userblock=512) as fh:
+        fh.write_mat73_variable("a", x)
+        fh.write_mat73_variable("b", x.astype(np.complex64), chunks=(10, 7, 3), deflate=3)
+        fh.write_mat73_variable("r", x.real.copy())
+    hdf5_min.write_matlab_header(path)
+    assert matfile.is_v73(path) and path.read_bytes()[:19] == b"MATLAB 7.3 MAT-file" and path.read_bytes()[124:128] == b"\x00\x02IM"
+    for name, ref in (("a", x), ("b", x.astype(np.complex64)), ("r", x.real)):
+        got = matfile.load_variable(path, name)
+        assert got.dtype == ref.dtype and got.flags.f_contiguous and np.array_equal(got, ref), name
+        direct = matfile.load_variable(path, name, None, True)
+        if name == "b":
+            assert isinstance(direct, np.ndarray) and np.array_equal(direct, ref)
+        else:
+            assert isinstance(direct, FileComplex)
+            back = np.asarray(direct[:])
+            assert np.array_equal(back.real if name == "r" else back, ref)
+            direct.release()
+    with hdf5_min.File(path) as fh:
+        assert fh["a"].attr_string("MATLAB_class") == "double" and fh["b"].attr_string("MATLAB_class") == "single"
+        assert fh["a"].shape == (40, 7, 3) and fh["a"].complex_pair and fh["a"].file_offset >= 512
+    with pytest.raises(NotImplementedError):
+        scipy.io.loadmat(str(path))
+
+
 def test_run_extraction_takes_a_mat73_container(tmp_path):
     """run_extraction on the -v7.3 container (stand-in engine, no GPU here) writes the same six feature files as on a
     level-5 container of the same arrays -- contiguous variables as offsets into the file, compressed ones decoded."""
