@@ -395,7 +395,11 @@ class Dataset:
         grid = [range(lo // cshape[0], (hi - 1) // cshape[0] + 1)] + \
                [range((n + c - 1) // c) for n, c in zip(self.shape[1:], cshape[1:])]
         todo = list(itertools.product(*grid))
-        workers = min(len(todo), max(1, min(8, (os.cpu_count() or 2))))
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            cores = os.cpu_count() or 2
+        workers = min(len(todo), max(1, min(16, cores)))      # inflate-bound: zlib releases the GIL
         if workers <= 1:
             for index in todo:
                 one(index)
