@@ -164,7 +164,8 @@ __device__ __forceinline__ void radix_round(int r, float (&xr)[2 * kRowsB], floa
 }
 
 // Wave priority by section, as in the quad kernel (AMCX_QUAD_PRIO_MASK there): bit 0 the statistics sweep, 1 envelope +
-// reduction, 2 the radix rounds, 3 pass 1 of the register FFT (its passes 2-3 drop to 0 in fft_peak).
+// reduction, 2 the radix rounds, 3 pass 1 of the register FFT (its passes 2-3 drop to 0 in fft_peak).  Measured: masks 0, 1, 3
+// and 15 do not differ at either size (profiles/r5_group_prio_ab.txt) -- the one workgroup's waves move in lock step.
 #ifndef AMCX_GROUP_PRIO_MASK
 #define AMCX_GROUP_PRIO_MASK 1
 #endif

@@ -386,6 +386,31 @@ def test_group_kernels_across_epoch_boundaries(N, W, extra):
     torch.cuda.empty_cache()
 
 
+def test_run_extraction_at_frame_size_16384(tmp_path):
+    """The whole drop-in at a frame size the reference accepts (config.py:96 is a free integer) and rounds 1-4 refused: a
+    column-major container of doubles with rows longer than the frame, `run_extraction(cfg)` with frame_size = 16384 -- the
+    staging threads, the device transposition and the eight-waves-per-frame kernel -- six files, against the oracle."""
+    import scipy.io
+    from amcpy_amd import synth
+    from amcpy_amd.config import Config, Paths, SignalConfig
+    from amcpy_amd.feature_extraction import release_engines, run_extraction
+    N, n_frames = 16384, 3
+    cfg = Config(paths=Paths(root=tmp_path), signals=SignalConfig(snr_values={0: "0", 1: "10"}, num_frames=n_frames, frame_size=N))
+    cfg.paths.ensure_dirs()
+    blocks = {}
+    for mi, m in enumerate(cfg.signals.modulations_with_noise):
+        x = np.stack([synth.host_block(m, snr, n_frames, N + 100, seed=160 + 10 * mi + si) for si, snr in enumerate((0.0, 10.0))])
+        blocks[m] = x.astype(np.complex128) * (1.0 + 1e-9)
+    scipy.io.savemat(str(cfg.paths.mat_data / cfg.paths.mat_filename), {cfg.signals.mat_info[m]: v for m, v in blocks.items()})
+    run_extraction(cfg, verbose=False)
+    release_engines()
+    for m, v in blocks.items():
+        got = scipy.io.loadmat(str(cfg.paths.calculated_features / f"{m}_features.mat"))[cfg.signals.mat_info[m]]
+        assert got.shape == (2, n_frames, 18) and got.dtype == np.float32
+        x = v[:, :, :N].reshape(-1, N)
+        _assert_parity(got.reshape(-1, 18), orc.features18_batch(x), x, f"run_extraction N=16384 {m}")
+
+
 def test_bad_frames_do_not_leak_into_neighbours():
     """Grouped short frames share FFT passes 2-3 and a finaliser batch; the ping-pong variants
     share registers across frames: a NaN / Inf / all-zero frame in the middle of a batch must

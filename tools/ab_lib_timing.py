@@ -11,7 +11,7 @@ from amcpy_amd.features import features18
 
 dev = torch.device("cuda", 0)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048          # frame size: python tools/ab_lib_timing.py [N]
-S, K, M = 26, 4096, 6
+S, K, M = 26, (4096 if N <= 8192 else 512 if N == 16384 else 256), 6       # (the two arenas stay below ~85 GB)
 arena = torch.empty((M, S, K, N), dtype=torch.complex64, device=dev)
 for mi in range(M):
     synth.device_frames(synth.MODS6[mi], S, K, N, device=dev, rank=0, mod_idx=mi, out=arena[mi])
