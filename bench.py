@@ -30,7 +30,7 @@ One JSON line on stdout (rank 0).  Extra objects:
                roofline.secondary.measured: the board's instruction-issue ceiling under its power cap, run
                live after the timed region (amcx_probe_fma_rate, ~1 s of independent v_fma_f32), and this
                kernel's own instruction rate against it; roofline.frac_of_measured_read_peak.
-  per_rank     (N > 1) one entry per rank: rank, device, PCI bus id, mean / min / max launch ms, frames per
+  per_rank     (N > 1) one entry per rank: rank, device, PCI bus id, ms = [mean, min, max] launch, frames per
                launch, its own wall seconds, its device's FMA ceiling -- if the aggregate is short of N x, the
                line says which rank, device or clock was slow; scaling_efficiency = value / (N x the best rank's
                own kernel-only rate), rank_balance = slowest / fastest rank's kernel-only rate.
@@ -244,8 +244,7 @@ def _parity_block():
     """Where parity is established -- not a replay of numbers: the live gate is `pytest -m gpu` (the driver runs it), whose
     test_full_snr_grid_against_oracle covers 6 modulations x 26 SNRs x 8 frames at N = 1024 / 2048 / 4096 with zero frames
     beyond the unfloored criterion."""
-    return {"source": "pytest -m gpu (tests/test_gpu_parity.py: golden fixtures, full SNR grid, 1 024-frame samples of the "
-                      "full-size shards); no parity number is replayed into this line"}
+    return {"source": "pytest -m gpu (golden fixtures, 26-SNR grid, 1 024-frame full-shard samples); nothing replayed here"}
 
 
 def _committed_json(name: str):
@@ -362,11 +361,11 @@ def fanout_child(n_devices: int, share_gpu: bool, frame_size: int, n_frames: int
                "per_device_seconds": [e.stats.get("seconds") for e in fan.engines],
                "per_device_frames": fan.stats.get("frames_per_device"),
                "pcie_GBps": fan.stats.get("bytes_uploaded", 0) / wall / 1e9,
-               "placement": [{k: pl[k] for k in ("pci_bus_id", "numa_node", "n_cpus", "n_cpus_allowed")}
-                             for pl in fan.placement()],
-               "what": f"one process, {len(devices)} engines: ({N_SNR}, {n_frames}, {frame_size}) complex128 "
-                       f"Fortran-ordered = {F * frame_size * 16 / 1e9:.2f} GB cut along the frame axis; GBps = "
-                       f"container bytes / wall"}
+               # placement, one entry per engine: PCI bus id, NUMA node, CPUs bound (of those this process may use)
+               "bus": [pl["pci_bus_id"] for pl in fan.placement()], "numa": [pl["numa_node"] for pl in fan.placement()],
+               "cpus": [pl["n_cpus_allowed"] for pl in fan.placement()],
+               "what": f"1 process, {len(devices)} engines, ({N_SNR},{n_frames},{frame_size}) c128 F-order "
+                       f"{F * frame_size * 16 / 1e9:.2f} GB; GBps = container bytes / wall"}
     finally:
         fan.close()
     print(json.dumps(_rounded(rec)), flush=True)
@@ -790,8 +789,10 @@ def main():
             bus = _lib.device_pci_bus_id(dev_index)
         except Exception:
             bus = None
-        mine = {"rank": rank, "dev": dev_index, "bus": bus, "ms_mean": sum(launch_ms) / len(launch_ms),
-                "ms_min": min(launch_ms), "ms_max": max(launch_ms), "frames": frames_per_launch, "wall_s": wall_own,
+        # compact: eight of these and the fan-out block must leave the line under 4 KB (the driver keeps its tail only)
+        mine = {"rank": rank, "dev": dev_index, "bus": bus,
+                "ms": [sum(launch_ms) / len(launch_ms), min(launch_ms), max(launch_ms)],          # launch mean / min / max
+                "frames": frames_per_launch, "wall_s": wall_own,
                 "fma_G": None if not fma or "error" in fma else fma["wave_instr_per_s"] / 1e9,
                 "fma_GHz": None if not fma or "error" in fma else fma["clock_GHz"]}
         per_rank = [None] * world
@@ -837,7 +838,7 @@ def main():
             "frac_at_min": alg_bytes / (srt[0] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             "measured_read_peak_GBps": read_peak,
             "frac_of_measured_read_peak": None if not read_peak else achieved / read_peak,
-            "secondary": _secondary(value / world, fma) if FS == FRAME_SIZE else None,
+            "secondary": _secondary(value / world, fma, brief=world > 1) if FS == FRAME_SIZE else None,
         },
         "wall_incl_d2h_ms": wall_d2h_ms,
         "h2d": h2d,
@@ -853,11 +854,13 @@ def main():
     print(json.dumps(_rounded(rec)), flush=True)
 
 
-def _secondary(frames_per_s_per_gpu: float, fma):
+def _secondary(frames_per_s_per_gpu: float, fma, brief: bool = False):
     """The replayed budget of the N = 2048 kernel (profiles/r*_wave_budget.json) plus what THIS run measured: the
     device's FMA ceiling under the power cap and the kernel's instruction rate (committed VALU instructions per frame x
     the measured frames/s) against it."""
     out = _valu_note(frames_per_s_per_gpu)
+    if out is not None and brief:                  # a multi-rank line carries per_rank and h2d_fanout instead of the replayed budget
+        out = {k: out[k] for k in ("valu_instr_per_frame", "source") if k in out}
     if out is None or fma is None:
         return out
     if "error" in fma:
@@ -867,16 +870,22 @@ def _secondary(frames_per_s_per_gpu: float, fma):
     ceil = fma["wave_instr_per_s"] / 1e9
     out["measured"] = {"fma_Gwaveinstr_per_s": ceil, "fma_clock_GHz": fma["clock_GHz"],
                        "kernel_Gwaveinstr_per_s": kern, "ratio": kern / ceil if ceil else None,
-                       "what": "amcx_probe_fma_rate in this run: 4 waves/SIMD of independent v_fma_f32, no memory traffic, "
-                               "~0.5 s settle + 0.5 s timed; kernel = valu_instr_per_frame x this run's frames/s/GPU"}
+                       "what": "amcx_probe_fma_rate, this run: 4 waves/SIMD of v_fma_f32, 0.5 s settle + 0.5 s timed; "
+                               "kernel = valu_instr_per_frame x frames/s/GPU"}
     return out
 
 
 def _scaling_block(per_rank, value, world):
     """Which rank was slow?  Every rank's own kernel-only rate (frames per launch / mean launch time); the aggregate
     against N x the best of them; the spread."""
-    rates = [r["frames"] / (r["ms_mean"] * 1e-3) for r in per_rank if r and r.get("ms_mean")]
-    out = {"per_rank": [{k: (float(f"{v:.6g}") if isinstance(v, float) else v) for k, v in r.items()} for r in per_rank]}
+    def short(v):
+        if isinstance(v, float):
+            return float(f"{v:.5g}")
+        if isinstance(v, list):
+            return [short(x) for x in v]
+        return v
+    rates = [r["frames"] / (r["ms"][0] * 1e-3) for r in per_rank if r and r.get("ms") and r["ms"][0]]
+    out = {"per_rank": [{k: short(v) for k, v in r.items()} for r in per_rank]}
     if rates:
         out["scaling_efficiency"] = value / (world * max(rates))
         out["rank_balance"] = min(rates) / max(rates)

@@ -1367,6 +1367,35 @@ def test_device_fan_out_reports_every_failing_device():
         fe.DeviceFanOut(8, [-1])
 
 
+def test_bench_scaling_block_at_eight_ranks():
+    """What a multi-rank bench line adds (bench._scaling_block) at the driver's largest N, on made-up ranks of which one is
+    slow: `per_rank` names it, `scaling_efficiency` = aggregate / (8 x the best rank's own kernel-only rate), `rank_balance`
+    = slowest / fastest; the block stays small enough for the whole line to fit the driver's 4 KB tail; and the measured
+    FMA ceiling lands in roofline.secondary.measured with the kernel's own rate against it (bench._secondary)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", REPO / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    frames = 6 * 26 * 4096
+    per_rank = [{"rank": r, "dev": r, "bus": f"0000:{0x05 + 0x10 * r:02x}:00.0",
+                 "ms": [3.1234567 if r != 5 else 3.9, 3.05, 3.3 if r != 5 else 4.2], "frames": frames,
+                 "wall_s": 0.0631 if r != 5 else 0.0785, "fma_G": 851.234567, "fma_GHz": 2.1234567} for r in range(8)]
+    value = 8 * frames * 20 / (0.0785)                      # 20 steps, the slowest rank's wall
+    blk = bench._scaling_block(per_rank, value, 8)
+    best = frames / 3.1234567e-3
+    assert abs(blk["scaling_efficiency"] - value / (8 * best)) < 1e-12
+    assert abs(blk["rank_balance"] - 3.1234567 / 3.9) < 1e-9 and abs(blk["sum_of_rank_rates"] - (7 * best + frames / 3.9e-3)) < 1
+    assert [r["rank"] for r in blk["per_rank"]] == list(range(8)) and blk["per_rank"][5]["ms"][0] == 3.9
+    text = json.dumps(bench._rounded(blk))
+    assert len(text) < 1300, len(text)                      # + ~1.7 KB of an N > 1 line without it + ~0.65 KB of h2d_fanout: under 4 096
+    sec = bench._secondary(200e6, {"wave_instr_per_s": 850e9, "clock_GHz": 2.1})
+    assert sec is not None and abs(sec["measured"]["ratio"] - sec["valu_instr_per_frame"] * 200e6 / 850e9) < 1e-12
+    assert bench._secondary(200e6, {"error": "boom"})["measured"] == {"error": "boom"}
+    assert bench._secondary(200e6, None) == bench._valu_note(200e6)
+    brief = bench._secondary(200e6, {"wave_instr_per_s": 850e9, "clock_GHz": 2.1}, brief=True)
+    assert set(brief) == {"valu_instr_per_frame", "source", "measured"} and brief["measured"]["ratio"] == sec["measured"]["ratio"]
+
+
 def test_numa_mapper_on_a_fake_sysfs_tree(tmp_path):
     """Host placement (include/amcx.h, ABI 4): amcx_numa_place reads <sysfs>/bus/pci/devices/<bdf>/{numa_node,
     local_cpulist}.  A fake tree of two nodes and four devices (two per socket, the SMT siblings in the second range
