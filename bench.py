@@ -364,8 +364,7 @@ def fanout_child(n_devices: int, share_gpu: bool, frame_size: int, n_frames: int
                # placement, one entry per engine: PCI bus id, NUMA node, CPUs bound (of those this process may use)
                "bus": [pl["pci_bus_id"] for pl in fan.placement()], "numa": [pl["numa_node"] for pl in fan.placement()],
                "cpus": [pl["n_cpus_allowed"] for pl in fan.placement()],
-               "what": f"1 process, {len(devices)} engines, ({N_SNR},{n_frames},{frame_size}) c128 F-order "
-                       f"{F * frame_size * 16 / 1e9:.2f} GB; GBps = container bytes / wall"}
+               "what": f"1 process, ({N_SNR},{n_frames},{frame_size}) c128 F-order, {F * frame_size * 16 / 1e9:.2f} GB"}
     finally:
         fan.close()
     print(json.dumps(_rounded(rec)), flush=True)
@@ -782,7 +781,7 @@ def main():
             dist.barrier()
             gather = {"ms": (time.perf_counter() - t_g) * 1e3, "bytes_per_rank": int(local.nbytes),
                       "rows_on_rank0": None if full is None else int(full.shape[0]),
-                      "what": "sharding.gather_rows, one step's result, all ranks -> rank 0"}
+                      "what": "gather_rows of one step's result"}
     per_rank = None
     if use_dist:
         try:
