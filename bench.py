@@ -394,7 +394,7 @@ def _valu_note(frames_per_s: float):
     """Secondary bounds of the N = 2048 kernel from this round's committed budget
     (profiles/r2_wave_budget.json: in-kernel clock, issue slots, ablations -- DESIGN.md 4.6, HISTORY.md 4.3)."""
     b, name = None, None
-    for name in ("r4_wave_budget.json", "r3_wave_budget.json", "r2_wave_budget.json"):
+    for name in ("r5_wave_budget.json", "r4_wave_budget.json", "r3_wave_budget.json", "r2_wave_budget.json"):
         b = _committed_json(name)
         if b is not None:
             break
