@@ -32,8 +32,8 @@
 // Frames outside the fp32 sums' range are found by the finaliser, recorded in a BIT MASK IN LDS (one bit per frame of
 // the workgroup's current epoch of <= 2048 frames) and re-run by the whole group at the end of the epoch, multiplied by an
 // exact power of two first (the wave kernels' scheme, finalize_features<true>); a row is stored once, final, and
-// nothing is ever read back from the caller's result matrix (the quad kernel marks such frames in band and re-reads its
-// own rows: ADVICE round 4).
+// nothing is ever read back from the caller's result matrix (the quad kernel, N = 8192, has the same kind of mask for
+// its workgroup's whole run of frames since late in round 5; before that it marked such frames in band).
 //
 // LDS per workgroup, W = 16: FFT tables 16 256 + W_256 table 2 048 + lane factors 2 048 + 16 regions of 8 672 + stash 2 x 2 112
 // (two frames) + partial sums / mask 384 = 163 712 bytes; W = 8: 16 256 + 2 048 + 2 048 + 8 x 16 384 + stash 8 x 1 056 + 320 = 160 192.

@@ -52,8 +52,16 @@ constexpr int kOffFrames = kTabBytes;
 constexpr int kOffStash = kOffFrames + kFrameBytes;
 constexpr int kOffMu = kOffStash + 2 * kStashFloats * 4;
 constexpr int kOffMx = kOffMu + kWavesPerQuad * 4;          // [wave] largest |component| of its quarter (re-run of an out-of-range frame)
-constexpr int kOffFlag = kOffMx + kWavesPerQuad * 4;         // != 0: this workgroup has marked a frame for its re-run pass
-constexpr int kLdsBytes = kOffFlag + 4;
+constexpr int kOffFlag = kOffMx + kWavesPerQuad * 4;         // != 0: this workgroup has a frame in its re-run mask
+// Re-run mask: bit k = frame k of the workgroup's own contiguous run is outside the fp32 sums' range.  Set by the wave
+// with quarter 0 (the only finaliser), read by all four waves behind a barrier: the list is the same in every wave by
+// construction, and nothing is read back from the caller's result matrix.  2 KiB cover 16 384 frames per workgroup =
+// 8.4 M frames (550 GB) per launch of 512 workgroups; launch_quad cuts longer inputs into several launches.
+constexpr int kMaskWords = 512;
+constexpr long long kMaskFrames = 32LL * kMaskWords;
+constexpr int kOffMask = kOffFlag + 4;
+constexpr int kLdsBytes = kOffMask + kMaskWords * 4;
+static_assert(kMaskFrames % kBatch == 0 && 32 % kBatch == 0, "a batch's bits never straddle a mask word");
 static_assert(kWGsPerCU * kLdsBytes <= 163840, "two workgroups per CU");
 static_assert(kExchangeBytes <= kRegionBytes && kRoundRows * 1024 <= kRegionBytes, "a wave's region holds a round's rows and its FFT exchange buffer");
 
@@ -201,7 +209,9 @@ __global__ __launch_bounds__(kThreads, 2) void amcx_features18_quad_kernel(
   float* mu_part = reinterpret_cast<float*>(smem + kOffMu);
   float* mx_part = reinterpret_cast<float*>(smem + kOffMx);
   unsigned* const redo_flag = reinterpret_cast<unsigned*>(smem + kOffFlag);
+  unsigned* const redo_mask = reinterpret_cast<unsigned*>(smem + kOffMask);
   if (tid == 0) *redo_flag = 0;
+  for (int w = tid; w < kMaskWords; w += kThreads) redo_mask[w] = 0;
 
   // ---- tables of the 2048-point register FFT ----
   constexpr int R = C2::kFftRows;                           // 16
@@ -278,15 +288,19 @@ __global__ __launch_bounds__(kThreads, 2) void amcx_features18_quad_kernel(
         finalize_features<true>(F, kN, feat, ex);
       } else {
         finalize_features(F, kN, feat);
-        // outside the fp32 sums' range: marked here (f5 = -inf: a standard deviation is >= 0 or NaN) in the workgroup's
-        // OWN row, found again and re-run by the whole quad in the pass at the end of this kernel -- the row is final
-        // when the launch is
-        if (is_outside_fp32_range(F, kN)) { feat[4] = -__builtin_inff(); marked = true; }
+        // outside the fp32 sums' range: noted in the workgroup's re-run mask (below) and run again by the whole quad
+        // in the pass at the end of this kernel, which overwrites the row -- the row is final when the launch is
+        marked = is_outside_fp32_range(F, kN);
       }
-      tie = __builtin_signbitf(feat[4]) && feat[4] == feat[4] && feat[4] != -__builtin_inff();
+      tie = !marked && __builtin_signbitf(feat[4]) && feat[4] == feat[4] && feat[4] != -__builtin_inff();
     }
     if constexpr (!RG) {
-      if (__builtin_amdgcn_ballot_w64(marked) != 0 && lane == 0) *redo_flag = 1;
+      const unsigned long long mk = __builtin_amdgcn_ballot_w64(marked);       // bits 0 .. count-1
+      if (mk != 0 && lane == 0) {
+        const unsigned rel = (unsigned)(f_first - b0 * kBatch);                // a multiple of kBatch
+        redo_mask[rel >> 5] |= (unsigned)mk << (rel & 31);                     // this wave is the mask's only writer
+        *redo_flag = 1;
+      }
     }
     unsigned long long ties = __builtin_amdgcn_ballot_w64(tie);
     const float sct = RG ? __builtin_bit_cast(float, (127 - ex) << 23) : 1.0f;   // the 2^-ex the frame was multiplied by
@@ -454,31 +468,28 @@ __global__ __launch_bounds__(kThreads, 2) void amcx_features18_quad_kernel(
   __syncthreads();                                          // the last batch's FFT peaks are in the stash
   if (q == 0) {
     if (pend_n > 0) finalise(std::false_type{}, pend_f0, pend_n, stash_q + pend_buf * kStashFloats, 0);
-    __threadfence();                                        // this wave's rows (and marks) are visible to the quad's other waves
+    __threadfence();                                        // this wave's rows are out before the re-run pass writes some of them again
   }
   __syncthreads();
 
   // ---- re-run pass: frames outside the fp32 sums' range (never on ordinary data: one LDS word says so) ----
-  // The finaliser marked them in the workgroup's own rows (f5 = -inf).  All four waves scan those rows -- the same
-  // memory, so the same list in every wave, and the barriers stay common -- and run each marked frame again, multiplied
-  // by 2^-ex first (ex the even-rounded exponent of the frame's largest component: every component below 4, no
-  // sixth-order product can overflow); the scaled finaliser undoes it through the features' scaling laws
+  // The finaliser noted them in the workgroup's LDS mask.  All four waves walk that mask -- the same LDS words behind
+  // the barrier above, so the same list in every wave, and the barriers stay common -- and run each noted frame again,
+  // multiplied by 2^-ex first (ex the even-rounded exponent of the frame's largest component: every component below 4,
+  // no sixth-order product can overflow); the scaled finaliser undoes it through the features' scaling laws
   // (finalize_features<true>), as the wave kernels do (amcx_wave_kernel.h, rerun_scaled).  A launch leaves every row
-  // final; rounds 2-3 left the marks to a second launch of the block kernel's fp64 routine (amcx_range_fixup_kernel).
+  // final; nothing is read back from the result matrix (until round 5 the note was f5 = -inf in the row itself).
   if (__builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile unsigned*>(redo_flag)) != 0) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     const long long fa = b0 * kBatch;
     long long fz = b1 * kBatch;
     if (fz > n_frames) fz = n_frames;
     float* const stash = stash_q;
-    for (long long base = fa; base < fz; base += 64) {
-      unsigned bits = 0;
-      if (base + lane < fz)
-        bits = __hip_atomic_load(reinterpret_cast<const unsigned*>(out + (base + lane) * out_stride + 4), __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_AGENT);
-      unsigned long long todo = __builtin_amdgcn_ballot_w64(bits == 0xff800000u);      // -inf
+    const int n_words = (int)((fz - fa + 31) >> 5);
+    for (int w = 0; w < n_words; ++w) {
+      unsigned todo = __builtin_amdgcn_readfirstlane(reinterpret_cast<volatile unsigned*>(redo_mask)[w]);
+      const long long base = fa + 32LL * w;
       while (todo != 0) {
-        const int idx = __builtin_ctzll(todo);
+        const int idx = __builtin_ctz(todo);
         todo &= todo - 1;
         const long long f = base + idx;
         float xr[2 * kRowsQ], xi[2 * kRowsQ];
@@ -523,13 +534,23 @@ __global__ __launch_bounds__(kThreads, 2) void amcx_features18_quad_kernel(
 
 inline hipError_t launch_quad(const float2* iq, int64_t n_frames, int64_t row_stride, float* out,
                               int64_t out_stride, hipStream_t stream, int cus) {
-  const int64_t n_batches = (n_frames + kBatch - 1) / kBatch;
-  int64_t grid = (int64_t)cus * kWGsPerCU;                   // persistent: two resident workgroups per CU
-  if (grid > n_batches) grid = n_batches;
-  if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(amcx_features18_quad_kernel, dim3((unsigned)grid), dim3(kThreads), kLdsBytes, stream, iq,
-                     (long long)n_frames, (long long)row_stride, out, (long long)out_stride);
-  return hipGetLastError();
+  const int64_t full_grid = (int64_t)cus * kWGsPerCU;        // persistent: two resident workgroups per CU
+  // a workgroup's re-run mask covers kMaskFrames frames of its own run: longer inputs (more than 8.4 M frames of
+  // 64 KiB at 512 workgroups -- beyond one device's memory unless rows overlap) go as several launches
+  const int64_t per_launch = full_grid * kMaskFrames;
+  for (int64_t f0 = 0; f0 < n_frames; f0 += per_launch) {
+    const int64_t n_here = n_frames - f0 < per_launch ? n_frames - f0 : per_launch;
+    const int64_t n_batches = (n_here + kBatch - 1) / kBatch;
+    int64_t grid = full_grid;
+    if (grid > n_batches) grid = n_batches;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(amcx_features18_quad_kernel, dim3((unsigned)grid), dim3(kThreads), kLdsBytes, stream,
+                       iq + f0 * row_stride, (long long)n_here, (long long)row_stride, out + f0 * out_stride,
+                       (long long)out_stride);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 }  // namespace quad
