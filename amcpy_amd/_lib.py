@@ -12,7 +12,7 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("AMCX_LIB", _HERE / "lib" / "libamcx.so"))
 
-ABI_VERSION = 5          # the version this binding was written against; any library >= it will do (include/amcx.h)
+ABI_VERSION = 6          # the version this binding was written against; any library >= it will do (include/amcx.h)
 NUM_FEATURES = 18
 VARIANT_AUTO, VARIANT_BLOCK, VARIANT_WAVE = 0, 1, 2
 VARIANTS = {"auto": VARIANT_AUTO, "block": VARIANT_BLOCK, "wave": VARIANT_WAVE}

@@ -10,6 +10,7 @@
 #include <new>
 
 #include "amcx_block_kernel.h"
+#include "amcx_stream_kernel.h"
 #include "amcx_wave_kernel.h"
 #include "amcx_quad_kernel.h"
 #include "amcx_group_kernel.h"
@@ -36,7 +37,7 @@ bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
 int resolve_variant(int32_t frame_size, int32_t variant) {
   if (frame_size < AMCX_MIN_FRAME_SIZE || frame_size > AMCX_MAX_FRAME_SIZE) return AMCX_EINVAL;
-  const bool block_ok = frame_size <= AMCX_MAX_BLOCK_FRAME_SIZE;      // above it only the powers of two have a kernel
+  const bool block_ok = frame_size <= AMCX_MAX_BLOCK_FRAME_SIZE;      // every size in range since ABI 6
   switch (variant) {
     case AMCX_VARIANT_AUTO:
       return amcx::wave_supports(frame_size) ? AMCX_VARIANT_WAVE : block_ok ? AMCX_VARIANT_BLOCK : AMCX_ENOTSUP;
@@ -81,8 +82,31 @@ int block_mode(int N) {
   return N > amcx::kBluesteinMaxN ? amcx::kBlockBluesteinBig : amcx::kBlockDirect;
 }
 
+// 8192 < N <= 32768: one 1024-thread workgroup per frame, the frame read where it lies (amcx_stream_kernel.h)
+int launch_stream(const float2* iq, int64_t n_frames, int32_t N, int64_t row_stride, float* out,
+                  int64_t out_stride, hipStream_t stream) {
+  auto kern = amcx::stream::amcx_features18_stream_kernel;
+  {
+    static bool attr_set[64] = {};                       // once per device, to the most any frame size asks for
+    int dev = 0;
+    AMCX_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+      AMCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)amcx::stream::lds_bytes(amcx::stream::kMaxN)));
+      if (dev >= 0 && dev < 64) attr_set[dev] = true;    // benign race: idempotent
+    }
+  }
+  int64_t grid = cu_count();                             // one resident workgroup per CU, grid-stride beyond
+  if (grid > n_frames) grid = n_frames;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(amcx::stream::kThreads), amcx::stream::lds_bytes(N), stream, iq,
+                     (long long)n_frames, (int)N, (long long)row_stride, out, (long long)out_stride);
+  AMCX_HIP(hipGetLastError());
+  return AMCX_OK;
+}
+
 int launch_block(const float2* iq, int64_t n_frames, int32_t N, int64_t row_stride, float* out,
                  int64_t out_stride, hipStream_t stream) {
+  if (N > amcx::kBlockMaxN) return launch_stream(iq, n_frames, N, row_stride, out, out_stride, stream);
   const int mode = block_mode(N);
   const size_t lds = (mode == amcx::kBlockBluestein      ? (size_t)16 * amcx::bluestein_length(N)
                       : mode == amcx::kBlockBluesteinBig ? (size_t)8 * amcx::kBluesteinBigM
@@ -97,7 +121,7 @@ int launch_block(const float2* iq, int64_t n_frames, int32_t N, int64_t row_stri
   // race between one's attribute and the other's launch.
   {
     static bool attr_set[4][64] = {};
-    constexpr int kMaxLds = 16 * AMCX_MAX_BLOCK_FRAME_SIZE + amcx::kBlockScratchBytes + amcx::kBlockTwiddleBytes;
+    constexpr int kMaxLds = 16 * amcx::kBlockMaxN + amcx::kBlockScratchBytes + amcx::kBlockTwiddleBytes;
     int dev = 0;
     AMCX_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64 || !attr_set[mode][dev]) {
@@ -893,6 +917,7 @@ int amcx_kernel_name(int32_t frame_size, int32_t variant, char* buf, int32_t buf
   const int v = resolve_variant(frame_size, variant);
   if (v < 0) return v;
   const char* name = (v == AMCX_VARIANT_WAVE) ? amcx::wave_kernel_name(frame_size)
+                     : frame_size > amcx::kBlockMaxN                   ? "amcx_features18_stream_kernel"
                      : block_mode(frame_size) == amcx::kBlockPow2      ? "amcx_features18_block_kernel<1>"
                      : block_mode(frame_size) == amcx::kBlockBluestein ? "amcx_features18_block_kernel<2>"
                      : block_mode(frame_size) == amcx::kBlockBluesteinBig ? "amcx_features18_block_kernel<3>"

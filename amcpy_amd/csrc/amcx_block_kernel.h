@@ -26,6 +26,7 @@
 namespace amcx {
 
 constexpr int kBlockThreads = 256;
+constexpr int kBlockMaxN = 8192;                 // a staged frame + its (|x|, angle) stash: 16 N bytes of LDS; larger: amcx_stream_kernel.h
 constexpr int kBlockWaves = kBlockThreads / 64;
 constexpr int kMaxReduce = 16;
 

@@ -81,8 +81,9 @@ extern "C" {
  * 4 = host placement (amcx_numa_place, amcx_device_pci_bus_id, amcx_ctx_bind_cpus, amcx_ctx_placement: a context's
  * staging threads and pinned slots on the CPUs local to its device) and the instruction-issue ceiling probe
  * (amcx_probe_fma_rate);
- * 5 = frame sizes 16384 and 32768 (AMCX_MAX_FRAME_SIZE 32768, AMCX_MAX_BLOCK_FRAME_SIZE). */
-#define AMCX_ABI_VERSION 5
+ * 5 = frame sizes 16384 and 32768 (AMCX_MAX_FRAME_SIZE 32768, AMCX_MAX_BLOCK_FRAME_SIZE);
+ * 6 = EVERY frame size 2 ... 32768: AMCX_MAX_BLOCK_FRAME_SIZE 32768 (8193 ... 32767 were AMCX_ENOTSUP but for 16384). */
+#define AMCX_ABI_VERSION 6
 #define AMCX_NUM_FEATURES 18
 
 /* error codes */
@@ -102,7 +103,12 @@ extern "C" {
                                    other N >= 65: both spectra in LDS up to 4096; 4097..8191 a
                                    16384-point convolution with the chirp's spectrum held in
                                    registers) or direct O(N^2) fp64 DFT (N <= 64); fp64
-                                   accumulation; 2 <= frame_size <= AMCX_MAX_BLOCK_FRAME_SIZE */
+                                   accumulation.  Above 8192 samples (ABI 6) one 1024-thread
+                                   workgroup per frame, the frame read where it lies, the phase in
+                                   LDS, the spectral peak as the DFT by its definition with exact
+                                   twiddle indices -- O(N^2), the fallback that makes the domain
+                                   whole (6 k frames/s at 32768, 65 k at 10000), not a throughput
+                                   path; 2 <= frame_size <= AMCX_MAX_BLOCK_FRAME_SIZE */
 #define AMCX_VARIANT_WAVE 2     /* one wavefront per frame, frame held in registers,
                                    register radix-16/8 FFT with LDS exchanges, followed by the
                                    range-pass launch for frames outside the fp32 range;
@@ -111,9 +117,9 @@ extern "C" {
 
 #define AMCX_MIN_FRAME_SIZE 2
 #define AMCX_MAX_FRAME_SIZE 32768       /* the reference takes any frame_size (config.py:96; np.fft.fft, features.py:68); this
-                                           library: every size 2 ... 8192, and the powers of two 16384 and 32768 (ABI 5).
-                                           Larger: AMCX_EINVAL.  8193 ... 32767 other than 16384: AMCX_ENOTSUP. */
-#define AMCX_MAX_BLOCK_FRAME_SIZE 8192  /* AMCX_VARIANT_BLOCK (and with it every size that is not a power of two) ends here */
+                                           library: every size 2 ... 32768 (ABI 6; ABI 5: 2 ... 8192 and the powers of two
+                                           16384, 32768).  Larger: AMCX_EINVAL. */
+#define AMCX_MAX_BLOCK_FRAME_SIZE 32768 /* AMCX_VARIANT_BLOCK (and with it every size that is not a power of two) ends here */
 
 int amcx_abi_version(void);
 const char* amcx_strerror(int code);

@@ -104,7 +104,7 @@ def capture_kat(rfeat):
     (OUT / "kat_n10.json").write_text(json.dumps(doc, indent=1))
 
 
-SEEDED_FROM = 16384       # fixtures of frames this long hold no inputs: their SHA-256 and the recipe below rebuild them
+SEEDED_FROM = 8193        # fixtures of frames this long hold no inputs: their SHA-256 and the recipe below rebuild them
 
 
 def frames_inputs(N):
@@ -413,11 +413,11 @@ def main():
             print(f"{name:28s} {(OUT / name).stat().st_size:9d} B")
         return
     capture_kat(rfeat)
-    for N in (128, 256, 512, 1000, 1024, 2048, 4096, 5000, 8192, 16384, 32768):
+    for N in (128, 256, 512, 1000, 1024, 2048, 4096, 5000, 8192, 10000, 12289, 16384, 32767, 32768):
         capture_frames(rfeat, N)
-    for N in (1000, 1024, 2048, 4096, 8192, 16384, 32768):
+    for N in (1000, 1024, 2048, 4096, 8192, 10000, 16384, 32767, 32768):
         capture_edges(rfeat, N)
-    for N in (2048, 4096, 8192, 16384, 32768):
+    for N in (2048, 4096, 8192, 10000, 16384, 32768):
         capture_range(rfeat, N)
     capture_roundtrip(rfe, rcfg)
     capture_roundtrip_f64(rfe, rcfg)

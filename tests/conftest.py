@@ -35,7 +35,7 @@ def kat():
 
 
 def load_npz(name):
-    """A fixture as a dict.  The large ones (frame sizes from 16384: oracle/capture_golden.py SEEDED_FROM) hold the
+    """A fixture as a dict.  The large ones (frame sizes above 8192: oracle/capture_golden.py SEEDED_FROM) hold the
     SHA-256 of their inputs and the name of the numpy-only recipe that rebuilds them instead of megabytes of samples:
     the inputs are rebuilt here and checked against the digest."""
     import hashlib
@@ -51,11 +51,11 @@ def load_npz(name):
     return d
 
 
-@pytest.fixture(scope="session", params=[128, 256, 512, 1000, 1024, 2048, 4096, 5000, 8192, 16384, 32768])
+@pytest.fixture(scope="session", params=[128, 256, 512, 1000, 1024, 2048, 4096, 5000, 8192, 10000, 12289, 16384, 32767, 32768])
 def golden_frames(request):
     return request.param, load_npz(f"frames_n{request.param}.npz")
 
 
-@pytest.fixture(scope="session", params=[1000, 1024, 2048, 4096, 8192, 16384, 32768])
+@pytest.fixture(scope="session", params=[1000, 1024, 2048, 4096, 8192, 10000, 16384, 32767, 32768])
 def golden_edges(request):
     return request.param, load_npz(f"edges_n{request.param}.npz")

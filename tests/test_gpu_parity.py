@@ -45,7 +45,7 @@ def _run(frames, variant, frame_size=None):
 
 def _variants_for(N):
     from amcpy_amd import _lib
-    out = ["block"] if N <= 8192 else []             # AMCX_MAX_BLOCK_FRAME_SIZE: above it only the powers of two, one kernel each
+    out = ["block"]                                  # every size up to AMCX_MAX_BLOCK_FRAME_SIZE = 32768 (above 8192: amcx_stream_kernel.h)
     try:
         _lib.kernel_name(N, _lib.VARIANT_WAVE)
         out.append("wave")
@@ -535,10 +535,15 @@ def test_argument_errors():
     assert f(x.data_ptr(), 2, 1 << 20, 1 << 20, o.data_ptr(), 18, None) == _lib.EINVAL
     assert f(x.data_ptr(), 2, 65536, 65536, o.data_ptr(), 18, None) == _lib.EINVAL          # AMCX_MAX_FRAME_SIZE is 32768
     assert f(x.data_ptr(), 2, 32769, 32769, o.data_ptr(), 18, None) == _lib.EINVAL
-    # 8193 ... 32767 other than 16384: in range, but no kernel (the block kernel ends at AMCX_MAX_BLOCK_FRAME_SIZE)
-    assert f(x.data_ptr(), 2, 10000, 10000, o.data_ptr(), 18, None) == _lib.ENOTSUP
-    assert f(x.data_ptr(), 2, 8193, 8193, o.data_ptr(), 18, None) == _lib.ENOTSUP
-    assert lib.amcx_features18_c64_ex(x.data_ptr(), 2, 16384, 16384, o.data_ptr(), 18, None, _lib.VARIANT_BLOCK) == _lib.ENOTSUP
+    # 8193 ... 32767: every size has a kernel since ABI 6 (amcx_stream_kernel.h); the one-wave / multi-wave kernels only the powers of two
+    big = torch.zeros((2, 16384), dtype=torch.complex64, device="cuda")
+    assert f(big.data_ptr(), 2, 10000, 16384, o.data_ptr(), 18, None) == _lib.OK
+    assert f(big.data_ptr(), 2, 8193, 8193, o.data_ptr(), 18, None) == _lib.OK
+    assert lib.amcx_features18_c64_ex(big.data_ptr(), 2, 16384, 16384, o.data_ptr(), 18, None, _lib.VARIANT_BLOCK) == _lib.OK
+    assert lib.amcx_features18_c64_ex(big.data_ptr(), 2, 10000, 10000, o.data_ptr(), 18, None, _lib.VARIANT_WAVE) == _lib.ENOTSUP
+    assert _lib.kernel_name(10000, _lib.VARIANT_AUTO) == "amcx_features18_stream_kernel"
+    assert _lib.kernel_name(16384, _lib.VARIANT_BLOCK) == "amcx_features18_stream_kernel"
+    torch.cuda.synchronize()
     assert f(None, 0, 64, 64, None, 18, None) == _lib.OK                          # empty batch
     assert lib.amcx_features18_c64_ex(x.data_ptr(), 2, 100, 100, o.data_ptr(), 18, None,
                                       _lib.VARIANT_WAVE) == _lib.ENOTSUP
@@ -897,7 +902,7 @@ def test_launch_is_graph_capturable():
     assert torch.equal(out, want)
 
 
-@pytest.mark.parametrize("N", [2048, 4096, 8192, 16384, 32768])
+@pytest.mark.parametrize("N", [2048, 4096, 8192, 10000, 16384, 32768])
 def test_dynamic_range_matches_the_float32_stored_reference(N):
     """Frames of ordinary shape at scales 1e-12 ... 1e12, one whose halves differ by ten orders
     of magnitude and one with a single 5e7 sample (tests/golden/range_n{N}.npz, captured from
@@ -914,7 +919,7 @@ def test_dynamic_range_matches_the_float32_stored_reference(N):
         stored = gold64.astype(np.float32)
     assert np.array_equal(stored, gold32, equal_nan=True)
     strict = [i for i in range(18) if i < 9 or i == 10]
-    for variant in (VARIANTS_POW2 if N <= 8192 else ["wave"]):
+    for variant in _variants_for(N):
         got = _run(x, variant)
         special = ~np.isfinite(gold32) | (gold32 == 0)
         bad = np.argwhere(special & (got != gold32))
@@ -1393,7 +1398,7 @@ def test_out_of_range_frames_scattered_over_a_full_grid(N):
     assert np.array_equal(got[kinds == 0], ref[pick][kinds == 0].astype(np.float32), equal_nan=True)
 
 
-@pytest.mark.parametrize("N", [2048, 4096, 8192, 16384, 32768])
+@pytest.mark.parametrize("N", [2048, 4096, 8192, 10000, 16384, 32768])
 def test_ends_of_float32_through_the_range_pass(N):
     """range_extreme_n{N}.npz (captured from the reference): the range fixture's frames at 1e-30, 1e-20,
     1e20 and 1e30 -- |x|^2 itself leaves float32.  The reference, evaluating in complex128, still returns
@@ -1404,8 +1409,8 @@ def test_ends_of_float32_through_the_range_pass(N):
     g = load_npz(f"range_extreme_n{N}.npz")
     x, names, gold32 = g["iq"], [str(n) for n in g["names"]], g["golden64"]
     S = orc.conditioning_scales(x.astype(np.complex128))
-    variants = VARIANTS_POW2 if N <= 8192 else ["wave"]
-    for variant in variants:                 # the block kernel stages every frame times a power of two as well
+    variants = _variants_for(N)
+    for variant in variants:                 # the block kernels take every frame times a power of two as well
         _check_ends_of_float32(_run(x, variant), gold32, S, names, variant)
     # non-power-of-two frame sizes (block kernel, Bluestein): the first 1000 samples of the same frames vs the oracle
     x1000 = np.ascontiguousarray(x[:, :1000])
@@ -1786,3 +1791,52 @@ def test_small_host_calls_replay_a_graph():
     assert np.array_equal(out, want[(1, 2048, np.complex64)], equal_nan=True)
     assert with_graph < without
     ctx.close()
+
+
+# ----------------------------------------------------------------------------
+# round 5, third session: every frame size up to 32768 (ABI 6, amcx_stream_kernel.h)
+# ----------------------------------------------------------------------------
+@pytest.mark.parametrize("N", [8193, 9999, 16385, 20000, 30011])
+def test_any_frame_size_above_8192_against_oracle(N):
+    """frame_size is a free integer in the reference (config.py:96; np.fft.fft takes any N, features.py:68).  Sizes above
+    8192 that are not powers of two -- 8193 (just past the LDS-staged block kernel), an odd composite, 16385 (the first size
+    whose samples are staged in two chunks), 20000, a prime -- through the device entry (AUTO = the stream kernel) and through
+    the host engine on a complex128 container with a row stride above N (run_extraction's [0:frame_size] slice,
+    feature_extraction.py:68), against the oracle in complex128; more frames than one workgroup round of a small grid
+    would need is not required: the kernel strides a grid of one workgroup per CU over them."""
+    from amcpy_amd import _lib, synth
+    from amcpy_amd.feature_extraction import HipEngine
+    assert _lib.kernel_name(N, _lib.VARIANT_AUTO) == "amcx_features18_stream_kernel"
+    L = N + 37
+    frames = np.concatenate([synth.host_block(mod, snr, 1, L, seed=7000 + N % 1000 + i)
+                             for i, (mod, snr) in enumerate([("BPSK", 4.0), ("16QAM", 12.0), ("WGN", 0.0), ("8PSK", -6.0)])])
+    x128 = frames.astype(np.complex128) * (1.0 + 1e-9)                  # genuine doubles: the engine rounds them on the way
+    want = orc.features18_batch(np.ascontiguousarray(x128[:, :N]).astype(np.complex64).astype(np.complex128))
+    got = _run(frames.astype(np.complex64), "auto", frame_size=N)
+    _assert_parity(got, want, frames[:, :N].astype(np.complex64), f"any-size N={N} device")
+    host = HipEngine(N)(x128)
+    assert np.array_equal(host, got), "the host engine and the device entry disagree"
+
+
+def test_stream_kernel_strides_its_grid_and_keeps_frames_apart():
+    """More frames than CUs (the grid is one workgroup per CU, striding), a NaN frame, an all-zero frame and an
+    out-of-fp32-range frame in between: every row equals the row the same frame gets alone."""
+    torch = _torch()
+    from amcpy_amd import synth
+    N, F = 8200, 300
+    x = np.concatenate([synth.host_block("QPSK", 6.0, F // 2, N, seed=91), synth.host_block("64QAM", 15.0, F - F // 2, N, seed=92)])
+    x = x.astype(np.complex64)
+    x[17] = 0
+    x[130, 5] = np.nan
+    x[277] *= np.float32(1e15)
+    got = _run(x, "auto")
+    pick = [0, 17, 130, 131, 256, 277, 299]
+    alone = np.concatenate([_run(x[i:i + 1], "block") for i in pick])
+    assert np.array_equal(got[pick], alone, equal_nan=True)
+    assert np.isnan(got[130]).all() and not np.isnan(got[131]).any()
+    assert np.isnan(got[17][[3, 7, 8]]).all() and np.all(got[17][[0, 1, 2, 4, 5, 6] + list(range(9, 18))] == 0)
+    want = orc.features18_batch(x[[0, 256, 299]].astype(np.complex128))
+    _assert_parity(got[[0, 256, 299]], want, x[[0, 256, 299]], "stream kernel, batch of 300")
+    with np.errstate(all="ignore"):
+        w277 = orc.features18_batch(x[277:278].astype(np.complex128)).astype(np.float32)
+    assert np.array_equal(np.isinf(got[277]), np.isinf(w277[0])) and np.isinf(got[277]).any()

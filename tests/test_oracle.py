@@ -131,7 +131,7 @@ def test_extract_roundtrip_fixture_is_reference_rows():
         assert str(g[f"label_{mod}"]) == mod
 
 
-@pytest.mark.parametrize("N", [2048, 4096, 8192, 16384, 32768])
+@pytest.mark.parametrize("N", [2048, 4096, 8192, 10000, 16384, 32768])
 def test_oracle_at_extreme_scales_matches_reference(N):
     """range_n{N}.npz (captured from the reference): frames at scales 1e-12 ... 1e12, a mixed-scale
     frame and a single 5e7 spike.  Both oracle evaluators on the complex128 cast reproduce the
@@ -162,7 +162,7 @@ def test_oracle_on_genuine_doubles_matches_reference_run():
         assert np.allclose(got, want, rtol=2e-6, atol=0, equal_nan=True), m
 
 
-@pytest.mark.parametrize("N", [2048, 4096, 8192, 16384, 32768])
+@pytest.mark.parametrize("N", [2048, 4096, 8192, 10000, 16384, 32768])
 def test_oracle_at_the_ends_of_float32_matches_reference(N):
     g = load_npz(f"range_extreme_n{N}.npz")
     x, gold = g["iq"].astype(np.complex128), g["golden64_f64"]
