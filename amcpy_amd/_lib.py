@@ -43,6 +43,8 @@ SIGNATURES = {
     "amcx_device_count": (C.c_int, []),
     "amcx_features18_c64": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i64, _vp]),
     "amcx_features18_c64_ex": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i64, _vp, _i32]),
+    "amcx_features18_workspace_bytes": (_i64, [_i32, _i64, _i32]),
+    "amcx_features18_c64_ws": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i64, _vp, _i32, _vp, _i64]),
     "amcx_features18_c64_host": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i64, _i32, _i32]),
     "amcx_features18_c128_host": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i64, _i32, _i32]),
     "amcx_ctx_create": (C.c_int, [_i32, C.POINTER(_vp)]),

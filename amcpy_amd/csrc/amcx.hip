@@ -82,31 +82,80 @@ int block_mode(int N) {
   return N > amcx::kBluesteinMaxN ? amcx::kBlockBluesteinBig : amcx::kBlockDirect;
 }
 
-// 8192 < N <= 32768: one 1024-thread workgroup per frame, the frame read where it lies (amcx_stream_kernel.h)
-int launch_stream(const float2* iq, int64_t n_frames, int32_t N, int64_t row_stride, float* out,
-                  int64_t out_stride, hipStream_t stream) {
-  auto kern = amcx::stream::amcx_features18_stream_kernel;
-  {
-    static bool attr_set[64] = {};                       // once per device, to the most any frame size asks for
-    int dev = 0;
-    AMCX_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-      AMCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)amcx::stream::lds_bytes(amcx::stream::kMaxN)));
-      if (dev >= 0 && dev < 64) attr_set[dev] = true;    // benign race: idempotent
-    }
+// 8192 < N <= 32768: one 1024-thread workgroup per frame, the frame read where it lies (amcx_stream_kernel.h).  With a
+// workspace of at least one workgroup's share the spectral term is an FFT through it (Bluestein for the sizes that are
+// not powers of two), otherwise the DFT by its definition.
+struct StreamPlan {
+  int M;            // transform length of the FFT form
+  bool chirped;     // not a power of two: one more buffer of M for the chirp's spectrum
+  int64_t grid;     // workgroups = frames in flight
+};
+
+StreamPlan stream_plan(int32_t N, int64_t n_frames) {
+  StreamPlan p;
+  p.M = amcx::stream::conv_length(N);
+  p.chirped = !is_pow2(N);
+  p.grid = cu_count();                                   // one resident workgroup per CU, grid-stride beyond
+  if (p.grid > n_frames) p.grid = n_frames;
+  if (p.grid < 1) p.grid = 1;
+  return p;
+}
+
+int set_stream_lds_once(const void* kern, int which) {
+  static bool attr_set[3][64] = {};                      // once per (kernel, device), to the most any frame size asks for
+  int dev = 0;
+  AMCX_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !attr_set[which][dev]) {
+    const size_t most = which == 0 ? amcx::stream::lds_bytes(amcx::stream::kMaxN)
+                        : which == 1 ? amcx::stream::lds_bytes_fft(amcx::stream::kMaxN)
+                                     : (size_t)amcx::stream::kTileBytes + amcx::stream::kFftTabBytes;
+    AMCX_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)most));
+    if (dev >= 0 && dev < 64) attr_set[which][dev] = true;   // benign race: idempotent
   }
-  int64_t grid = cu_count();                             // one resident workgroup per CU, grid-stride beyond
-  if (grid > n_frames) grid = n_frames;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(amcx::stream::kThreads), amcx::stream::lds_bytes(N), stream, iq,
-                     (long long)n_frames, (int)N, (long long)row_stride, out, (long long)out_stride);
+  return AMCX_OK;
+}
+
+int launch_stream(const float2* iq, int64_t n_frames, int32_t N, int64_t row_stride, float* out,
+                  int64_t out_stride, hipStream_t stream, void* ws, int64_t ws_bytes) {
+  StreamPlan p = stream_plan(N, n_frames);
+  const int64_t per = (int64_t)p.M * (int64_t)sizeof(float2);
+  int64_t fit = ws != nullptr && ws_bytes > 0 ? ws_bytes / per - (p.chirped ? 1 : 0) : 0;   // workgroups the workspace has room for
+  if (fit >= 1 && (reinterpret_cast<uintptr_t>(ws) & 7u) == 0) {
+    if (p.grid > fit) p.grid = fit;
+    float2* const base = static_cast<float2*>(ws);
+    const float2* bspec = nullptr;
+    float2* bufs = base;
+    if (p.chirped) {
+      auto chirp = amcx::stream::amcx_stream_chirp_kernel;
+      const int rc = set_stream_lds_once(reinterpret_cast<const void*>(chirp), 2);
+      if (rc != AMCX_OK) return rc;
+      hipLaunchKernelGGL(chirp, dim3(1), dim3(amcx::stream::kThreads),
+                         (size_t)amcx::stream::kTileBytes + amcx::stream::kFftTabBytes, stream, base, (int)N, p.M);
+      AMCX_HIP(hipGetLastError());
+      bspec = base;
+      bufs = base + p.M;
+    }
+    auto kern = amcx::stream::amcx_features18_stream_kernel<true>;
+    const int rc = set_stream_lds_once(reinterpret_cast<const void*>(kern), 1);
+    if (rc != AMCX_OK) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)p.grid), dim3(amcx::stream::kThreads), amcx::stream::lds_bytes_fft(N), stream,
+                       iq, (long long)n_frames, (int)N, (long long)row_stride, out, (long long)out_stride, bspec, bufs, p.M);
+    AMCX_HIP(hipGetLastError());
+    return AMCX_OK;
+  }
+  auto kern = amcx::stream::amcx_features18_stream_kernel<false>;
+  const int rc = set_stream_lds_once(reinterpret_cast<const void*>(kern), 0);
+  if (rc != AMCX_OK) return rc;
+  hipLaunchKernelGGL(kern, dim3((unsigned)p.grid), dim3(amcx::stream::kThreads), amcx::stream::lds_bytes(N), stream, iq,
+                     (long long)n_frames, (int)N, (long long)row_stride, out, (long long)out_stride,
+                     static_cast<const float2*>(nullptr), static_cast<float2*>(nullptr), 0);
   AMCX_HIP(hipGetLastError());
   return AMCX_OK;
 }
 
 int launch_block(const float2* iq, int64_t n_frames, int32_t N, int64_t row_stride, float* out,
-                 int64_t out_stride, hipStream_t stream) {
-  if (N > amcx::kBlockMaxN) return launch_stream(iq, n_frames, N, row_stride, out, out_stride, stream);
+                 int64_t out_stride, hipStream_t stream, void* ws = nullptr, int64_t ws_bytes = 0) {
+  if (N > amcx::kBlockMaxN) return launch_stream(iq, n_frames, N, row_stride, out, out_stride, stream, ws, ws_bytes);
   const int mode = block_mode(N);
   const size_t lds = (mode == amcx::kBlockBluestein      ? (size_t)16 * amcx::bluestein_length(N)
                       : mode == amcx::kBlockBluesteinBig ? (size_t)8 * amcx::kBluesteinBigM
@@ -229,9 +278,18 @@ int amcx_device_count(void) {
   return ok;
 }
 
-int amcx_features18_c64_ex(const void* iq_dev, int64_t n_frames, int32_t frame_size,
+int64_t amcx_features18_workspace_bytes(int32_t frame_size, int64_t n_frames, int32_t variant) {
+  if (n_frames < 0) return -1;
+  const int v = resolve_variant(frame_size, variant);
+  if (v < 0) return -1;
+  if (v != AMCX_VARIANT_BLOCK || frame_size <= amcx::kBlockMaxN || n_frames == 0) return 0;
+  const StreamPlan p = stream_plan(frame_size, n_frames);
+  return (p.grid + (p.chirped ? 1 : 0)) * (int64_t)p.M * (int64_t)sizeof(float2);
+}
+
+int amcx_features18_c64_ws(const void* iq_dev, int64_t n_frames, int32_t frame_size,
                            int64_t row_stride_elems, float* out_dev, int64_t out_row_stride,
-                           void* hip_stream, int32_t variant) {
+                           void* hip_stream, int32_t variant, void* workspace_dev, int64_t workspace_bytes) {
   if (n_frames < 0 || row_stride_elems < frame_size || out_row_stride < AMCX_NUM_FEATURES)
     return AMCX_EINVAL;
   const int v = resolve_variant(frame_size, variant);
@@ -261,7 +319,38 @@ int amcx_features18_c64_ex(const void* iq_dev, int64_t n_frames, int32_t frame_s
     // of +-pi in its finaliser.
     return AMCX_OK;
   }
-  return launch_block(iq, n_frames, frame_size, row_stride_elems, out_dev, out_row_stride, stream);
+  if (workspace_dev != nullptr && on_another_device(workspace_dev)) return AMCX_EINVAL;
+  return launch_block(iq, n_frames, frame_size, row_stride_elems, out_dev, out_row_stride, stream, workspace_dev,
+                      workspace_bytes < 0 ? 0 : workspace_bytes);
+}
+
+int amcx_features18_c64_ex(const void* iq_dev, int64_t n_frames, int32_t frame_size,
+                           int64_t row_stride_elems, float* out_dev, int64_t out_row_stride,
+                           void* hip_stream, int32_t variant) {
+  // The any-size path above 8192 samples runs its FFT form through a workspace from the stream-ordered allocator
+  // (as amcx_group_stats_f32 does) -- unless the stream is being captured into a graph, or the allocator has nothing:
+  // then the DFT by its definition, which needs none (amcx_stream_kernel.h).  Everything else allocates nothing.
+  const int64_t want = n_frames > 0 && iq_dev != nullptr && out_dev != nullptr && row_stride_elems >= frame_size &&
+                               out_row_stride >= AMCX_NUM_FEATURES
+                           ? amcx_features18_workspace_bytes(frame_size, n_frames, variant) : 0;
+  if (want <= 0)
+    return amcx_features18_c64_ws(iq_dev, n_frames, frame_size, row_stride_elems, out_dev, out_row_stride, hip_stream,
+                                  variant, nullptr, 0);
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+  void* ws = nullptr;
+  if (cap == hipStreamCaptureStatusNone && hipMallocAsync(&ws, (size_t)want, st) != hipSuccess) {
+    (void)hipGetLastError();
+    ws = nullptr;
+  }
+  const int rc = amcx_features18_c64_ws(iq_dev, n_frames, frame_size, row_stride_elems, out_dev, out_row_stride,
+                                        hip_stream, variant, ws, ws != nullptr ? want : 0);
+  if (ws != nullptr) {
+    const hipError_t fe = hipFreeAsync(ws, st);
+    if (rc == AMCX_OK) AMCX_HIP(fe);
+  }
+  return rc;
 }
 
 int amcx_features18_c64(const void* iq_dev, int64_t n_frames, int32_t frame_size,
@@ -289,6 +378,7 @@ struct amcx_ctx {
   char* pin = nullptr;     size_t pin_cap = 0;   // kPinSlots x slot
   void* d_slab = nullptr;  size_t slab_cap = 0;  // 2 x slot: uploaded chunks
   void* d_frames = nullptr; size_t frames_cap = 0;   // plane-major sources: the frame-major complex64 image
+  void* d_ws = nullptr; size_t ws_cap = 0;           // the any-size path's FFT workspace (frame sizes above 8192, amcx_features18_c64_ws)
   hipEvent_t up_done[3] = {nullptr, nullptr, nullptr};
   hipEvent_t slab_free[2] = {nullptr, nullptr};
   float* out_pin = nullptr; size_t out_pin_cap = 0;   // the result lands in pinned memory first
@@ -304,6 +394,7 @@ struct amcx_ctx {
     hipGraphExec_t exec = nullptr;
     int64_t frames = 0; int32_t frame_size = 0, variant = 0; bool c128 = false, zero_copy = false;
     const void* pin = nullptr; const void* slab = nullptr; const void* out = nullptr; const void* out_pin = nullptr;
+    const void* ws = nullptr;      // the workspace the captured kernel node points into
     size_t slot = 0;
   };
   SmallGraph graphs[4];
@@ -328,6 +419,21 @@ int ctx_reserve(void** p, size_t* cap, size_t bytes) {
   }
   *cap = want;
   return AMCX_OK;
+}
+
+// The context's own workspace for a call of `frames` frames (nothing for the frame sizes that need none).  Reserved
+// BEFORE any capture begins: a captured kernel node points into it, and an allocation inside a capture is not allowed.
+// A context that cannot have it runs the workspace-free form.
+void ctx_reserve_ws(amcx_ctx* c, int32_t N, int64_t frames, int32_t variant) {
+  const int64_t want = amcx_features18_workspace_bytes(N, frames, variant);
+  if (want > 0 && ctx_reserve(&c->d_ws, &c->ws_cap, (size_t)want) != AMCX_OK) { c->d_ws = nullptr; c->ws_cap = 0; }
+}
+
+int ctx_features(amcx_ctx* c, const void* rows, int64_t frames, int32_t N, float* out, int32_t variant) {
+  const int64_t want = amcx_features18_workspace_bytes(N, frames, variant);
+  const bool have = want > 0 && c->d_ws != nullptr && c->ws_cap >= (size_t)want;
+  return amcx_features18_c64_ws(rows, frames, N, N, out, AMCX_NUM_FEATURES, c->stream, variant, have ? c->d_ws : nullptr,
+                                have ? want : 0);
 }
 
 struct DeviceGuard {
@@ -431,6 +537,7 @@ int ctx_run_strided(amcx_ctx* c, amcx::Source src, int64_t S, int64_t K,
   int rc = strided_prepare(c, slot, dslot, rows ? 0 : (size_t)F * N * 8, sizeof(float) * AMCX_NUM_FEATURES * (size_t)F,
                            threaded);
   if (rc != AMCX_OK) return rc;
+  ctx_reserve_ws(c, N, F, v);                                      // (frame sizes above 8192 only) before any capture below
   amcx::Pool inline_pool;                                          // size 1: stage_runs runs on the caller
   amcx_upload_stats st = {};
   amcx::Pool& pool = threaded ? c->pool : inline_pool;
@@ -464,7 +571,8 @@ int ctx_run_strided(amcx_ctx* c, amcx::Source src, int64_t S, int64_t K,
     for (auto& cand : c->graphs)
       if (cand.exec && cand.frames == F && cand.frame_size == N && cand.variant == v && cand.c128 == as_c128 &&
           cand.zero_copy == zero_copy &&
-          cand.pin == pinned && cand.slab == dev && cand.out == c->d_out && cand.out_pin == c->out_pin && cand.slot == slot)
+          cand.pin == pinned && cand.slab == dev && cand.out == c->d_out && cand.out_pin == c->out_pin && cand.slot == slot &&
+          cand.ws == c->d_ws)
         g = &cand;
     if (g != nullptr) {
       ++c->graph_hits;
@@ -477,7 +585,7 @@ int ctx_run_strided(amcx_ctx* c, amcx::Source src, int64_t S, int64_t K,
       int crc = AMCX_OK;
       hipError_t ce = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
       if (ce == hipSuccess && zero_copy) {
-        crc = amcx_features18_c64_ex(pinned, F, N, N, c->out_pin, AMCX_NUM_FEATURES, c->stream, v);
+        crc = ctx_features(c, pinned, F, N, c->out_pin, v);
         const hipError_t ee = hipStreamEndCapture(c->stream, &graph);
         ce = ee;
       } else if (ce == hipSuccess) {
@@ -490,7 +598,7 @@ int ctx_run_strided(amcx_ctx* c, amcx::Source src, int64_t S, int64_t K,
           ce = hipGetLastError();
           d_rows = rounded;
         }
-        if (ce == hipSuccess) crc = amcx_features18_c64_ex(d_rows, F, N, N, c->d_out, AMCX_NUM_FEATURES, c->stream, v);
+        if (ce == hipSuccess) crc = ctx_features(c, d_rows, F, N, c->d_out, v);
         if (ce == hipSuccess && crc == AMCX_OK)
           ce = hipMemcpyAsync(c->out_pin, c->d_out, out_bytes, hipMemcpyDeviceToHost, c->stream);
         const hipError_t ee = hipStreamEndCapture(c->stream, &graph);      // always ends the capture
@@ -506,6 +614,7 @@ int ctx_run_strided(amcx_ctx* c, amcx::Source src, int64_t S, int64_t K,
         slot_g.exec = exec; slot_g.frames = F; slot_g.frame_size = N; slot_g.variant = v; slot_g.c128 = as_c128;
         slot_g.zero_copy = zero_copy;
         slot_g.pin = pinned; slot_g.slab = dev; slot_g.out = c->d_out; slot_g.out_pin = c->out_pin; slot_g.slot = slot;
+        slot_g.ws = c->d_ws;
         c->graph_next = (c->graph_next + 1) % 4;
         g = &slot_g;
       }
@@ -582,8 +691,7 @@ int ctx_run_strided(amcx_ctx* c, amcx::Source src, int64_t S, int64_t K,
         if (e != hipSuccess) break;
         d_rows = rounded;
       }
-      rc = amcx_features18_c64_ex(d_rows, take, N, N, c->d_out + (size_t)u * AMCX_NUM_FEATURES, AMCX_NUM_FEATURES,
-                                  c->stream, v);
+      rc = ctx_features(c, d_rows, take, N, c->d_out + (size_t)u * AMCX_NUM_FEATURES, v);
     } else {
       float2* frames = static_cast<float2*>(c->d_frames);
       e = as_c128 ? amcx::launch_pack_planes(reinterpret_cast<const double2*>(dev), (int)take, (long long)F, (long long)F,
@@ -599,7 +707,7 @@ int ctx_run_strided(amcx_ctx* c, amcx::Source src, int64_t S, int64_t K,
     st.chunks = ch + 1;
   }
   if (rc == AMCX_OK && e == hipSuccess && !rows)
-    rc = amcx_features18_c64_ex(c->d_frames, F, N, N, c->d_out, AMCX_NUM_FEATURES, c->stream, v);
+    rc = ctx_features(c, c->d_frames, F, N, c->d_out, v);
   const double t_tail = wall_now();
   st.seconds_prepare = t_loop - t_start;
   // the result comes back into pinned memory (a copy into the caller's pageable rows would be staged by the
@@ -740,6 +848,7 @@ int amcx_ctx_destroy(amcx_ctx* c) {
   if (c->d_out) (void)hipFree(c->d_out);
   if (c->d_slab) (void)hipFree(c->d_slab);
   if (c->d_frames) (void)hipFree(c->d_frames);
+  if (c->d_ws) (void)hipFree(c->d_ws);
   if (c->pin) (void)hipHostFree(c->pin);
   if (c->out_pin) (void)hipHostFree(c->out_pin);
   for (auto& g : c->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
@@ -917,7 +1026,7 @@ int amcx_kernel_name(int32_t frame_size, int32_t variant, char* buf, int32_t buf
   const int v = resolve_variant(frame_size, variant);
   if (v < 0) return v;
   const char* name = (v == AMCX_VARIANT_WAVE) ? amcx::wave_kernel_name(frame_size)
-                     : frame_size > amcx::kBlockMaxN                   ? "amcx_features18_stream_kernel"
+                     : frame_size > amcx::kBlockMaxN                   ? "amcx_features18_stream_kernel"     /* <true> with a workspace, <false> without */
                      : block_mode(frame_size) == amcx::kBlockPow2      ? "amcx_features18_block_kernel<1>"
                      : block_mode(frame_size) == amcx::kBlockBluestein ? "amcx_features18_block_kernel<2>"
                      : block_mode(frame_size) == amcx::kBlockBluesteinBig ? "amcx_features18_block_kernel<3>"

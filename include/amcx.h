@@ -82,7 +82,8 @@ extern "C" {
  * staging threads and pinned slots on the CPUs local to its device) and the instruction-issue ceiling probe
  * (amcx_probe_fma_rate);
  * 5 = frame sizes 16384 and 32768 (AMCX_MAX_FRAME_SIZE 32768, AMCX_MAX_BLOCK_FRAME_SIZE);
- * 6 = EVERY frame size 2 ... 32768: AMCX_MAX_BLOCK_FRAME_SIZE 32768 (8193 ... 32767 were AMCX_ENOTSUP but for 16384). */
+ * 6 = EVERY frame size 2 ... 32768: AMCX_MAX_BLOCK_FRAME_SIZE 32768 (8193 ... 32767 were AMCX_ENOTSUP but for 16384);
+ * amcx_features18_c64_ws / amcx_features18_workspace_bytes. */
 #define AMCX_ABI_VERSION 6
 #define AMCX_NUM_FEATURES 18
 
@@ -105,10 +106,10 @@ extern "C" {
                                    registers) or direct O(N^2) fp64 DFT (N <= 64); fp64
                                    accumulation.  Above 8192 samples (ABI 6) one 1024-thread
                                    workgroup per frame, the frame read where it lies, the phase in
-                                   LDS, the spectral peak as the DFT by its definition with exact
-                                   twiddle indices -- O(N^2), the fallback that makes the domain
-                                   whole (6 k frames/s at 32768, 65 k at 10000), not a throughput
-                                   path; 2 <= frame_size <= AMCX_MAX_BLOCK_FRAME_SIZE */
+                                   LDS, the spectral peak by a chirp-z / plain FFT run in place on a
+                                   global workspace (amcx_features18_c64_ws below) or, without one,
+                                   as the DFT by its definition with exact twiddle indices, O(N^2);
+                                   2 <= frame_size <= AMCX_MAX_BLOCK_FRAME_SIZE */
 #define AMCX_VARIANT_WAVE 2     /* one wavefront per frame, frame held in registers,
                                    register radix-16/8 FFT with LDS exchanges, followed by the
                                    range-pass launch for frames outside the fp32 range;
@@ -147,6 +148,25 @@ int amcx_features18_c64(const void* iq_dev, int64_t n_frames, int32_t frame_size
 int amcx_features18_c64_ex(const void* iq_dev, int64_t n_frames, int32_t frame_size,
                            int64_t row_stride_elems, float* out_dev, int64_t out_row_stride,
                            void* hip_stream, int32_t variant);
+
+/*
+ * ABI 6.  The any-size path above 8192 samples (AMCX_VARIANT_BLOCK there; AUTO where frame_size is not a power of
+ * two) has two forms of its spectral term: an FFT through a device workspace -- Bluestein's chirp-z as a 32768- /
+ * 65536-point circular convolution run in place on one private buffer per workgroup, the plain transform at 16384 /
+ * 32768 -- and, without one, the DFT by its definition (O(N^2), ~100x slower at 32767; same results within the parity
+ * contract).  amcx_features18_c64 / _ex take the workspace from the stream-ordered allocator (hipMallocAsync /
+ * hipFreeAsync on hip_stream), except while the stream is being captured into a graph or when the allocator fails:
+ * then they run the form that needs none.  amcx_features18_c64_ws takes the caller's: at least
+ * amcx_features18_workspace_bytes(frame_size, n_frames, variant) bytes of device memory (contents undefined before,
+ * garbage after; 8-byte aligned; on the current device) for the full number of frames in flight, fewer bytes mean fewer
+ * workgroups, less than one workgroup's share (or NULL) the workspace-free form.  _workspace_bytes is 0 for every
+ * frame size and variant that needs none (all of 2 ... 8192, and the WAVE kernels), -1 for arguments the call itself
+ * would refuse.  Every other frame size: _ws behaves exactly as _ex and ignores the workspace.
+ */
+int64_t amcx_features18_workspace_bytes(int32_t frame_size, int64_t n_frames, int32_t variant);
+int amcx_features18_c64_ws(const void* iq_dev, int64_t n_frames, int32_t frame_size,
+                           int64_t row_stride_elems, float* out_dev, int64_t out_row_stride,
+                           void* hip_stream, int32_t variant, void* workspace_dev, int64_t workspace_bytes);
 
 /*
  * Same computation for HOST buffers (numpy arrays): allocates device scratch,

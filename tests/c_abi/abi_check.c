@@ -34,6 +34,14 @@ int main(int argc, char** argv) {
   CHECK(strstr(name, "wave_kernel<2048>") != NULL);
   CHECK(amcx_kernel_name(1000, AMCX_VARIANT_AUTO, name, (int32_t)sizeof name) == AMCX_OK);
   CHECK(strstr(name, "block_kernel") != NULL);
+  /* ABI 6: every frame size up to 32768; the workspace the any-size path's FFT form wants */
+  CHECK(amcx_kernel_name(12345, AMCX_VARIANT_AUTO, name, (int32_t)sizeof name) == AMCX_OK);
+  CHECK(strstr(name, "stream_kernel") != NULL);
+  CHECK(amcx_features18_workspace_bytes(2048, 1000, AMCX_VARIANT_AUTO) == 0);
+  CHECK(amcx_features18_workspace_bytes(12345, 2, AMCX_VARIANT_AUTO) == 3 * 32768 * 8);
+  CHECK(amcx_features18_workspace_bytes(32769, 2, AMCX_VARIANT_AUTO) == -1);
+  CHECK(amcx_features18_c64_ws(NULL, 0, 12345, 12345, NULL, 18, NULL, AMCX_VARIANT_AUTO, NULL, 0) == AMCX_OK);
+  CHECK(amcx_features18_c64_ws(NULL, 2, 12345, 12345, NULL, 18, NULL, AMCX_VARIANT_AUTO, NULL, 0) == AMCX_EINVAL);
   /* version-2 additions: the strided-container entries validate before touching a device, and the staging half
    * works without one */
   CHECK(amcx_ctx_features18_strided_host(NULL, NULL, NULL, AMCX_SRC_C64, 1, 1, 64, 64, 64, 1, NULL, 18, AMCX_VARIANT_AUTO) == AMCX_EINVAL);

@@ -1814,7 +1814,7 @@ def test_any_frame_size_above_8192_against_oracle(N):
     want = orc.features18_batch(np.ascontiguousarray(x128[:, :N]).astype(np.complex64).astype(np.complex128))
     got = _run(frames.astype(np.complex64), "auto", frame_size=N)
     _assert_parity(got, want, frames[:, :N].astype(np.complex64), f"any-size N={N} device")
-    host = HipEngine(N)(x128)
+    host = HipEngine(N)(x128)                                            # its context owns a workspace: the FFT form here too
     assert np.array_equal(host, got), "the host engine and the device entry disagree"
 
 
@@ -1840,3 +1840,74 @@ def test_stream_kernel_strides_its_grid_and_keeps_frames_apart():
     with np.errstate(all="ignore"):
         w277 = orc.features18_batch(x[277:278].astype(np.complex128)).astype(np.float32)
     assert np.array_equal(np.isinf(got[277]), np.isinf(w277[0])) and np.isinf(got[277]).any()
+
+
+def _run_ws(frames, frame_size, ws_bytes, variant="auto"):
+    """features through amcx_features18_c64_ws with a workspace of exactly ws_bytes (0: none) -> numpy (F, 18)."""
+    torch = _torch()
+    from amcpy_amd import _lib
+    lib = _lib.load()
+    x = torch.from_numpy(np.ascontiguousarray(frames)).cuda()
+    out = torch.full((x.shape[0], 18), float("nan"), dtype=torch.float32, device="cuda")
+    ws = torch.empty(max(ws_bytes, 8) // 8, dtype=torch.complex64, device="cuda").fill_(complex(float("nan"), float("nan")))
+    _lib.check(lib.amcx_features18_c64_ws(x.data_ptr(), x.shape[0], frame_size, x.shape[1], out.data_ptr(), 18,
+                                          torch.cuda.current_stream().cuda_stream, _lib.VARIANTS[variant],
+                                          ws.data_ptr() if ws_bytes else None, ws_bytes))
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("N,variant", [(8193, "auto"), (12289, "auto"), (16384, "block"), (16385, "auto"), (32767, "auto"), (32768, "block")])
+def test_the_two_forms_of_the_any_size_path_agree(N, variant):
+    """Above 8192 samples the spectral term is an FFT through a workspace (Bluestein's chirp-z, M = 32768 / 65536; the plain
+    transform at the two powers of two) or, without one, the DFT by its definition.  Both against the oracle, and against
+    each other: features 2-18 do not involve the spectral term and are bit-identical, f1 agrees to 2e-6.  A workspace with
+    room for fewer workgroups than frames in flight, a workspace one byte short of one workgroup's share (-> the
+    workspace-free form) and one polluted with NaNs give the same rows."""
+    from amcpy_amd import _lib, synth
+    lib = _lib.load()
+    F = 7
+    x = np.concatenate([synth.host_block(mod, snr, 1, N, seed=8100 + i)
+                        for i, (mod, snr) in enumerate([("BPSK", 0.0), ("QPSK", 8.0), ("8PSK", 14.0), ("16QAM", 20.0),
+                                                        ("64QAM", 30.0), ("WGN", 0.0), ("BPSK", -12.0)])]).astype(np.complex64)
+    x[3] *= np.float32(3e-9)                                      # a frame that is scaled by a power of two on the way
+    want = orc.features18_batch(x.astype(np.complex128))
+    full = lib.amcx_features18_workspace_bytes(N, F, _lib.VARIANTS[variant])
+    M = 1 << int(np.ceil(np.log2(2 * N - 1))) if N & (N - 1) else N
+    assert full == (F + (1 if N & (N - 1) else 0)) * M * 8
+    fft = _run_ws(x, N, full, variant)
+    direct = _run_ws(x, N, 0, variant)
+    _assert_parity(fft, want, x, f"any-size N={N} FFT form")
+    _assert_parity(direct, want, x, f"any-size N={N} by the definition")
+    assert np.array_equal(fft[:, 1:], direct[:, 1:], equal_nan=True)
+    assert np.allclose(fft[:, 0], direct[:, 0], rtol=2e-6, atol=0)
+    two = (2 + (1 if N & (N - 1) else 0)) * M * 8                 # room for two frames in flight
+    assert np.array_equal(_run_ws(x, N, two, variant), fft)
+    short = (1 + (1 if N & (N - 1) else 0)) * M * 8 - 1           # not even one: the form that needs none
+    assert np.array_equal(_run_ws(x, N, short, variant), direct)
+    assert np.array_equal(_run(x, variant), fft), "amcx_features18_c64_ex takes its workspace from the stream-ordered allocator"
+
+
+def test_any_size_path_inside_a_graph_capture():
+    """While its stream is being captured amcx_features18_c64_ex allocates nothing: the captured node is the
+    workspace-free form, and replaying the graph gives that form's rows."""
+    torch = _torch()
+    from amcpy_amd import synth
+    from amcpy_amd.features import features18
+    N = 9000
+    x = torch.from_numpy(synth.host_block("QPSK", 10.0, 5, N, seed=77).astype(np.complex64)).cuda()
+    out = torch.zeros((5, 18), dtype=torch.float32, device="cuda")
+    features18(x, out=out)                                        # warm (attributes, allocator)
+    torch.cuda.synchronize()
+    eager = out.clone()
+    out.zero_()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        features18(x, out=out)
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    direct = _run_ws(x.cpu().numpy(), N, 0)
+    assert np.array_equal(out.cpu().numpy(), direct)
+    assert np.array_equal(out.cpu().numpy()[:, 1:], eager.cpu().numpy()[:, 1:])
+    assert np.allclose(out.cpu().numpy()[:, 0], eager.cpu().numpy()[:, 0], rtol=2e-6, atol=0)

@@ -50,6 +50,19 @@ def test_argument_validation_needs_no_gpu():
     assert lib.amcx_features18_c64_ex(None, 0, 2048, 2048, None, 18, None, 7) == _lib.EINVAL
     assert _lib.kernel_name(2048).startswith("amcx_features18_wave_kernel")
     assert _lib.kernel_name(1000) == "amcx_features18_block_kernel<2>"
+    # ABI 6: every size up to 32768 has a kernel; the any-size path above 8192 samples says what workspace its FFT form wants
+    assert _lib.kernel_name(10000).startswith("amcx_features18_stream_kernel")
+    wsb = lib.amcx_features18_workspace_bytes
+    assert wsb(2048, 100, _lib.VARIANT_AUTO) == 0 and wsb(8191, 100, _lib.VARIANT_BLOCK) == 0
+    assert wsb(16384, 4, _lib.VARIANT_AUTO) == 0                       # the group kernel needs none
+    assert wsb(16384, 4, _lib.VARIANT_BLOCK) == 4 * 16384 * 8          # the plain transform: one buffer per frame in flight
+    assert wsb(10000, 4, _lib.VARIANT_AUTO) == (4 + 1) * 32768 * 8     # Bluestein: M = 32768, + the chirp's spectrum
+    assert wsb(20000, 3, _lib.VARIANT_AUTO) == (3 + 1) * 65536 * 8
+    assert wsb(10000, 0, _lib.VARIANT_AUTO) == 0
+    assert wsb(40000, 4, _lib.VARIANT_AUTO) == -1 and wsb(10000, -1, _lib.VARIANT_AUTO) == -1
+    assert wsb(10000, 4, _lib.VARIANT_WAVE) == -1                      # no such kernel: the call itself would refuse
+    assert lib.amcx_features18_c64_ws(None, 4, 10000, 10000, None, 18, None, _lib.VARIANT_AUTO, None, 0) == _lib.EINVAL
+    assert lib.amcx_features18_c64_ws(None, 0, 10000, 10000, None, 18, None, _lib.VARIANT_AUTO, None, 0) == _lib.OK
     with pytest.raises(ValueError):
         _lib.check(_lib.EINVAL)
     with pytest.raises(_lib.AmcxError):
