@@ -220,14 +220,19 @@ def test_variants_agree():
 
 
 def test_wave_kernel_short_power_of_two_frames():
-    """N = 128, 256, 512: the register-FFT wave kernel with fewer rows per lane (for R < 8 only
-    lanes with lane>>3 < R hold bins) and 16/32-frame finaliser batches; frame counts chosen to
-    leave ragged batches and tail chunks.  Checked against the oracle and the block kernel."""
+    """N = 128, 256: four frames per wave, sixteen lanes per frame (amcx_short_kernel.h: row reductions, a 4 x 8 x 4 /
+    8 x 8 x 4 register FFT with two LDS transposes, every frame scaled by a power of two); N = 512: the one-wave kernel with
+    fewer rows per lane (two frames sharing one run of FFT passes 2-3).  Frame counts chosen to leave ragged passes, batches and
+    tail chunks; pure tones on bins of every residue of the short kernel's index split X[kj + R (kc + 8 ka)] (each residue takes
+    another lane and register through the transposes).  Checked against the oracle and the block kernel."""
     from amcpy_amd import synth, _lib
     for N, F in ((128, 1531), (256, 777), (512, 403)):
-        assert "wave_kernel" in _lib.kernel_name(N, _lib.VARIANT_AUTO)
+        assert ("short_kernel" if N <= 256 else "wave_kernel") in _lib.kernel_name(N, _lib.VARIANT_AUTO)
         x = np.concatenate([synth.host_block(m, snr, F // 3 + 1, N, seed=N + i)
                             for i, (m, snr) in enumerate((("BPSK", 0.0), ("16QAM", 12.0), ("WGN", -10.0)))])[:F]
+        n = np.arange(N)
+        for i, k in enumerate((1, 2, 3, 5, 6, 7, 37, 41, N // 2, N // 2 + 3, N - 10, N - 1)):
+            x[5 + 7 * i] = (0.7 * np.exp(2j * np.pi * (k * n / N + 0.1 * i))).astype(np.complex64) + x[5 + 7 * i] * np.float32(0.1)
         gold = orc.features18_batch(x)
         got = _run(x, "wave")
         _assert_parity(got, gold, x, f"wave N={N}")
