@@ -424,11 +424,26 @@ __global__ __launch_bounds__(kThreads, 2) void amcx_features18_quad_kernel(
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  // The next frame's quarter is requested before this frame's FFT and lands behind it.
-  v4f nxt[kRowsQ];
+  // Rows 0-7 of the next frame's quarter are requested before this frame's FFT and land behind it; rows 8-15 at the head of
+  // the frame itself, and arrive while rows 0-7 are swept.  (Until late in round 5 all sixteen rows were requested before the
+  // FFT: with 64 more registers live across it the allocator parked lane addresses in scratch and reloaded them INSIDE the
+  // FFT -- and a scratch reload waits on vmcnt(0), i.e. for the sixteen loads in front of it: the prefetch was waited for a
+  // few hundred instructions after it had been issued.)
+  constexpr int kHead = kRowsQ / 2;
+  auto load_rows = [&](auto first, v4f (&v)[kHead], long long f) {
+    constexpr int FIRST = decltype(first)::value;
+    const float2* src = iq + f * row_stride + q * kQuarter + 2 * lane;
+    static_for<kHead>([&](auto ii) {
+      constexpr int i = decltype(ii)::value;
+      v[i] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src + 128 * (FIRST + i)));
+    });
+  };
+  using Head = std::integral_constant<int, 0>;
+  using Tail = std::integral_constant<int, kHead>;
+  v4f nxt[kHead];
   {
     long long f_first;
-    if (frame_at(0, 0, f_first)) load_quarter(nxt, f_first);
+    if (frame_at(0, 0, f_first)) load_rows(Head{}, nxt, f_first);
   }
 
   for (int it = 0; it < n_iters; ++it) {
@@ -438,11 +453,17 @@ __global__ __launch_bounds__(kThreads, 2) void amcx_features18_quad_kernel(
     float* const stash = stash_q + (it & 1) * kStashFloats;
     for (int g = 0; g < n_here; ++g) {                      // n_here is the same for the quad's four waves: so are the barriers
       float xr[2 * kRowsQ], xi[2 * kRowsQ];
-      // this wave's quarter (requested a frame ago)
-      static_for<kRowsQ>([&](auto ii) {
-        constexpr int i = decltype(ii)::value;
-        xr[2 * i] = nxt[i].x; xi[2 * i] = nxt[i].y; xr[2 * i + 1] = nxt[i].z; xi[2 * i + 1] = nxt[i].w;
-      });
+      // this wave's quarter: rows 0-7 were requested a frame ago, rows 8-15 are requested now
+      {
+        v4f late[kHead];
+        load_rows(Tail{}, late, f0 + g);
+        static_for<kHead>([&](auto ii) {
+          constexpr int i = decltype(ii)::value;
+          xr[2 * i] = nxt[i].x; xi[2 * i] = nxt[i].y; xr[2 * i + 1] = nxt[i].z; xi[2 * i + 1] = nxt[i].w;
+          xr[2 * (kHead + i)] = late[i].x; xi[2 * (kHead + i)] = late[i].y;
+          xr[2 * (kHead + i) + 1] = late[i].z; xi[2 * (kHead + i) + 1] = late[i].w;
+        });
+      }
       // the first sample of the next quarter: the phase step that crosses the quarter boundary
       float2 nx = make_float2(1.f, 0.f);
       if (q < 3) nx = iq[(f0 + g) * row_stride + (q + 1) * kQuarter];
@@ -453,14 +474,14 @@ __global__ __launch_bounds__(kThreads, 2) void amcx_features18_quad_kernel(
       const bool finalise_now = q == 0 && g == 0 && pend_n > 0;
       long long f_next;                                     // (it, g + 1), or the first frame of the next round
       const bool more = g + 1 < n_here ? frame_at(it, g + 1, f_next) : frame_at(it + 1, 0, f_next);
-      if (more && !finalise_now) load_quarter(nxt, f_next);
+      if (more && !finalise_now) load_rows(Head{}, nxt, f_next);
       __builtin_amdgcn_sched_barrier(0);
       phase_c(xr, xi, stash, g);
       if (finalise_now) {                                   // the previous batch: every wave is past its last FFT (barrier 1 of this frame)
         finalise(std::false_type{}, pend_f0, pend_n, stash_q + pend_buf * kStashFloats, 0);
         pend_n = 0;
         __builtin_amdgcn_sched_barrier(0);
-        if (more) load_quarter(nxt, f_next);
+        if (more) load_rows(Head{}, nxt, f_next);
       }
     }
     if (q == 0) { pend_f0 = f0; pend_n = n_here; pend_buf = it & 1; }
