@@ -1,12 +1,12 @@
 #!/bin/bash
-# counters of the N = 128 kernels (old: one wave per frame; AMCX_SHORT=1: four frames per wave)
+# counters of a frame size's throughput kernel (NN=128 by default): VALU / LDS / VMEM instructions per frame, wait shares per wave-cycle
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-for tag in old short; do
-  if [ $tag = short ]; then export AMCX_SHORT=1; else unset AMCX_SHORT; fi
-  OUT=gpurun_out/s3_short/pmc_$tag
+for tag in ${TAGS:-product}; do
+  : # (while both N = 128 kernels existed, AMCX_SHORT=1 selected the new one: profiles/r5_short_kernel_ab.txt)
+  OUT=gpurun_out/pmc_n${NN:-128}_$tag
   mkdir -p $OUT
-  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/a -- python3 bench.py --no-cpu-baseline --no-h2d --no-d2h --no-fma-probe --steps 20 --warmup 5 --frame-size 128 > $OUT/a.json 2> $OUT/a.err
-  rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/b -- python3 bench.py --no-cpu-baseline --no-h2d --no-d2h --no-fma-probe --steps 20 --warmup 5 --frame-size 128 > /dev/null 2> $OUT/b.err
+  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/a -- python3 bench.py --no-cpu-baseline --no-h2d --no-d2h --no-fma-probe --steps 20 --warmup 5 --frame-size ${NN:-128} > $OUT/a.json 2> $OUT/a.err
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/b -- python3 bench.py --no-cpu-baseline --no-h2d --no-d2h --no-fma-probe --steps 20 --warmup 5 --frame-size ${NN:-128} > /dev/null 2> $OUT/b.err
   python3 - $OUT $tag <<'PY'
 import csv, glob, sys, collections
 acc = collections.defaultdict(float); n=collections.defaultdict(set)
