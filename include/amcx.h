@@ -31,7 +31,8 @@
  *     un-scales in fp64.  The throughput kernel's fp32 sums hold inside 1e-5 <~ rms|x| <~ 1e5;
  *     a frame outside that (or any of whose sums overflows: a single 1e7 sample among unit
  *     ones) is re-run on a copy multiplied by an exact power of two by the throughput kernel itself
- *     -- at the frame sizes 128 ... 4096 right behind the batch it was found in, at 8192 in a pass of
+ *     -- at the frame sizes 512 ... 4096 right behind the batch it was found in (128 and 256 take EVERY frame times a
+ *     power of two, as the block kernel does: nothing to re-run), at 8192 in a pass of
  *     the quad at the end of the launch, at 16384 / 32768 at the end of every epoch of 2048 frames of a
  *     workgroup (a data set that is out of range throughout, e.g. raw 24-bit ADC counts, runs at half
  *     the normal rate) -- so
@@ -110,11 +111,12 @@ extern "C" {
                                    global workspace (amcx_features18_c64_ws below) or, without one,
                                    as the DFT by its definition with exact twiddle indices, O(N^2);
                                    2 <= frame_size <= AMCX_MAX_BLOCK_FRAME_SIZE */
-#define AMCX_VARIANT_WAVE 2     /* one wavefront per frame, frame held in registers,
-                                   register radix-16/8 FFT with LDS exchanges, followed by the
-                                   range-pass launch for frames outside the fp32 range;
-                                   frame_size a power of two, 128 ... 32768 (8192: four waves per
-                                   frame, 16384 / 32768: eight / sixteen) */
+#define AMCX_VARIANT_WAVE 2     /* the throughput kernels: the frame held in registers, register
+                                   FFT with LDS exchanges, fp32 sums with an fp64 finaliser, frames
+                                   outside the fp32 range re-run inside the launch; frame_size a
+                                   power of two, 128 ... 32768 (512 ... 4096: one wavefront per
+                                   frame; 128 / 256: four frames per wavefront; 8192: four waves
+                                   per frame, 16384 / 32768: eight / sixteen) */
 
 #define AMCX_MIN_FRAME_SIZE 2
 #define AMCX_MAX_FRAME_SIZE 32768       /* the reference takes any frame_size (config.py:96; np.fft.fft, features.py:68); this
