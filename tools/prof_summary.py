@@ -51,7 +51,7 @@ frames = int(os.environ.get("AMCX_PROFILE_FRAMES", 6 * 26 * 4096))
 for n, cs in summary["counters_mean_per_dispatch"].items():
     if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
         rd, wr = cs["FETCH_SIZE"] * 1024 * 2, cs["WRITE_SIZE"] * 1024
-        m = re.search(r"wave_kernel<(\d+)>", n)
+        m = re.search(r"(?:wave|short)_kernel<(\d+)>", n)
         g = re.search(r"group_kernel<(\d+)>", n)               # N = 2048 x the number of waves per frame
         fs = int(m.group(1)) if m else 2048 * int(g.group(1)) if g else 8192 if "quad_kernel" in n else \
             int(os.environ.get("AMCX_PROFILE_FRAME_SIZE", 2048))
