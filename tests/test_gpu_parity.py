@@ -452,7 +452,7 @@ def test_bad_frames_do_not_leak_into_neighbours():
 def test_results_do_not_depend_on_batch_position():
     """Same property for the long-frame variants and the block kernel."""
     from amcpy_amd import synth
-    for N, F in ((128, 517), (512, 333), (1024, 301), (2048, 203), (4096, 101), (8192, 67), (16384, 37), (32768, 21), (100, 57)):
+    for N, F in ((128, 517), (256, 401), (512, 333), (1024, 301), (2048, 203), (4096, 101), (8192, 67), (16384, 37), (32768, 21), (100, 57)):
         x = synth.host_block("64QAM", 8.0, F, N, seed=N)
         perm = np.random.default_rng(N).permutation(F)
         for variant in _variants_for(N):
@@ -1890,6 +1890,14 @@ def test_the_two_forms_of_the_any_size_path_agree(N, variant):
     assert np.array_equal(_run_ws(x, N, two, variant), fft)
     short = (1 + (1 if N & (N - 1) else 0)) * M * 8 - 1           # not even one: the form that needs none
     assert np.array_equal(_run_ws(x, N, short, variant), direct)
+    torch = _torch()                                              # a workspace that is not 8-byte aligned is not used either
+    from amcpy_amd import _lib as L
+    xs = torch.from_numpy(x).cuda()
+    o = torch.zeros((F, 18), dtype=torch.float32, device="cuda")
+    w = torch.zeros(full + 16, dtype=torch.uint8, device="cuda")
+    L.check(lib.amcx_features18_c64_ws(xs.data_ptr(), F, N, N, o.data_ptr(), 18, None, L.VARIANTS[variant], w.data_ptr() + 4, full))
+    torch.cuda.synchronize()
+    assert np.array_equal(o.cpu().numpy(), direct)
     assert np.array_equal(_run(x, variant), fft), "amcx_features18_c64_ex takes its workspace from the stream-ordered allocator"
 
 
