@@ -1,9 +1,10 @@
 // N = 128 and 256 (RadioML-2016-style short frames): FOUR frames per wavefront, sixteen lanes per frame.
 //
 // The one-wave-per-frame kernel (amcx_wave_kernel.h) spreads a 128-sample frame over 64 lanes, two samples each: every
-// frame then pays a full 64-lane reduction of its 27 sums (~120 instructions), another for the envelope's mean (~70),
-// and shares a 1024-point-shaped FFT back half with seven other frames (~170 per frame) -- ~490 instructions per frame
-// where the per-sample work is ~210 (profiles/r5_short_kernel_isa.txt).  Here a frame lives in ONE 16-lane DPP row:
+// frame then pays a full 64-lane reduction of its 27 sums, another for the envelope's mean, and shares a 1024-point-shaped
+// FFT back half with seven other frames -- 327 VALU instructions per frame where the per-sample work is ~210, and at FULL
+// clock (not the board's power cap) a quarter of its wave-cycles in s_waitcnt (profiles/r5_short_kernel_ab.txt).  Here a
+// frame lives in ONE 16-lane DPP row (247 instructions per frame at N = 128):
 //   * lane l of a row holds samples 32 j + 2 l + b, j < 4, b < 2 (four global_load_dwordx4, 256 contiguous bytes per row
 //     and load); the statistics sweep is the wave kernel's, with the neighbour's angle from a row rotate (row_ror:15) and
 //     the shifts from the row's first 16 samples;
