@@ -188,7 +188,7 @@ def test_random_frames_against_oracle():
             _assert_parity(_run(x, variant), gold, x, f"synthetic N={N} {variant}")
 
 
-@pytest.mark.parametrize("N", [1024, 2048, 4096])
+@pytest.mark.parametrize("N", [128, 256, 1024, 2048, 4096])
 def test_full_snr_grid_against_oracle(N):
     """The whole SNR grid of the BASELINE configs -- 6 modulations x 26 SNRs (-20 ... +30 dB, step 2) x 8 frames = 1 248
     frames per frame size, the host generator with SURVEY 8d's seeds (1000 + 10 mod + snr index) -- against the oracle,
