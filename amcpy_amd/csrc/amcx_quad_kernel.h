@@ -468,20 +468,19 @@ __global__ __launch_bounds__(kThreads, 2) void amcx_features18_quad_kernel(
       float2 nx = make_float2(1.f, 0.f);
       if (q < 3) nx = iq[(f0 + g) * row_stride + (q + 1) * kQuarter];
       phases_ab(xr, xi, nx, stash, g);
-      // The next frame's quarter is requested here, before the FFT, and lands behind it -- except when this wave has a
-      // batch to finalise: the fp64 algebra wants ~200 registers, so it runs after the FFT, when y_q is dead, and the
-      // request follows it (one exposed round trip per batch, on one wave; the CU's other workgroup covers it).
+      // The head of the next frame's quarter is requested here, before the FFT, and lands behind it.  A batch to finalise
+      // (the wave with quarter 0, once per batch) runs after the FFT, when y_q is dead: its ~200 registers and the eight
+      // requested rows fit side by side (with all sixteen rows a frame ahead the request had to wait for it).
       const bool finalise_now = q == 0 && g == 0 && pend_n > 0;
       long long f_next;                                     // (it, g + 1), or the first frame of the next round
       const bool more = g + 1 < n_here ? frame_at(it, g + 1, f_next) : frame_at(it + 1, 0, f_next);
-      if (more && !finalise_now) load_rows(Head{}, nxt, f_next);
+      if (more) load_rows(Head{}, nxt, f_next);
       __builtin_amdgcn_sched_barrier(0);
       phase_c(xr, xi, stash, g);
       if (finalise_now) {                                   // the previous batch: every wave is past its last FFT (barrier 1 of this frame)
         finalise(std::false_type{}, pend_f0, pend_n, stash_q + pend_buf * kStashFloats, 0);
         pend_n = 0;
         __builtin_amdgcn_sched_barrier(0);
-        if (more) load_rows(Head{}, nxt, f_next);
       }
     }
     if (q == 0) { pend_f0 = f0; pend_n = n_here; pend_buf = it & 1; }
