@@ -557,7 +557,11 @@ inline hipError_t launch_quad(const float2* iq, int64_t n_frames, int64_t row_st
   const int64_t full_grid = (int64_t)cus * kWGsPerCU;        // persistent: two resident workgroups per CU
   // a workgroup's re-run mask covers kMaskFrames frames of its own run: longer inputs (more than 8.4 M frames of
   // 64 KiB at 512 workgroups -- beyond one device's memory unless rows overlap) go as several launches
-  const int64_t per_launch = full_grid * kMaskFrames;
+  int64_t per_launch = full_grid * kMaskFrames;
+  if (const char* t = getenv("AMCX_TEST_QUAD_SPLIT")) {       // tests only: cut at this many frames (any cut is valid; the
+    const long long v = atoll(t);                            // real one needs more frames than a device holds)
+    if (v >= kBatch && v < per_launch) per_launch = v / kBatch * kBatch;
+  }
   for (int64_t f0 = 0; f0 < n_frames; f0 += per_launch) {
     const int64_t n_here = n_frames - f0 < per_launch ? n_frames - f0 : per_launch;
     const int64_t n_batches = (n_here + kBatch - 1) / kBatch;

@@ -1924,3 +1924,20 @@ def test_any_size_path_inside_a_graph_capture():
     assert np.array_equal(out.cpu().numpy(), direct)
     assert np.array_equal(out.cpu().numpy()[:, 1:], eager.cpu().numpy()[:, 1:])
     assert np.allclose(out.cpu().numpy()[:, 0], eager.cpu().numpy()[:, 0], rtol=2e-6, atol=0)
+
+
+def test_quad_launch_cut_into_several(monkeypatch):
+    """launch_quad cuts an input longer than its workgroups' re-run masks cover (8.4 M frames of 64 KiB: more than a device
+    holds) into several launches.  With the cut forced at 52 frames (AMCX_TEST_QUAD_SPLIT) 211 frames go as five launches:
+    same rows as one launch, an out-of-range frame on either side of a cut included."""
+    from amcpy_amd import synth
+    N, F = 8192, 211
+    x = synth.host_block("16QAM", 9.0, F, N, seed=4242).astype(np.complex64)
+    x[51] *= np.float32(1e14)
+    x[52] *= np.float32(1e-14)
+    x[207] *= np.float32(3e12)
+    whole = _run(x, "wave")
+    monkeypatch.setenv("AMCX_TEST_QUAD_SPLIT", "52")
+    cut = _run(x, "wave")
+    assert np.array_equal(cut, whole, equal_nan=True)
+    assert np.isinf(whole[51]).any() and np.isfinite(whole[50]).all()
