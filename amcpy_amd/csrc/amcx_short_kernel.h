@@ -71,96 +71,16 @@ __device__ __forceinline__ float row_max(float v) {
   return v;
 }
 
-// The statistics sweep of amcx_wave_kernel.h (Stats::row) for a frame that lives in one 16-lane row: the right neighbour
-// of (j, b = 1) is (j, b = 0) of lane l + 1, or (j + 1, b = 0) of lane 0 for lane 15; the shifts are the means of the
-// row's first 16 values.
-struct RowStats {
-  float sA = 0, sBh = 0, sP = 0, sAA = 0, sX4 = 0, sAB = 0, sAP = 0, sBP = 0;
-  float sAAA = 0, sABB = 0, sAAB = 0, sBBB = 0, sAAP = 0, sX4P = 0, sABP = 0;
-  float sa = 0, st1 = 0, st2 = 0, sab1 = 0, sab2 = 0, sw1 = 0, sw2 = 0, sw3 = 0, sw4 = 0;
-  float sad1 = 0, sad2 = 0, sad4 = 0;
-  float Kt = 0, Kw = 0, Ka = 0;
-  float th_b1_prev = 0, rot_prev = 0, wmax = 0;
-
-  __device__ __forceinline__ void step(float w) {
-    const float d = w - Kw, d2 = d * d;
-    sw1 += d; sw2 += d2;
-    sw3 = __builtin_fmaf(d2, d, sw3);
-    sw4 = __builtin_fmaf(d2, d2, sw4);
-  }
-
-  template <bool FIRST, bool LAST>
-  __device__ __forceinline__ void row(float re0, float im0, float re1, float im1, bool last_lane, float& a0, float& a1) {
-    float th[2], av[2];
-    const float res[2] = {re0, re1}, ims[2] = {im0, im1};
-    static_for<2>([&](auto bb) {
-      constexpr int b = decltype(bb)::value;
-      const float re = res[b], im = ims[b];
-      const float q = __builtin_fmaf(im, im, kTinyPower);
-      const float P = __builtin_fmaf(re, re, q);
-      const float A = __builtin_fmaf(re, re, -q);
-      const float Bh = re * im;
-      const float AA = A * A, BB = Bh * Bh, AP = A * P;
-      const float X4 = __builtin_fmaf(-4.0f, BB, AA);
-      sA += A; sBh += Bh; sP += P; sAA += AA; sX4 += X4; sAP += AP;
-      sAB = __builtin_fmaf(A, Bh, sAB);
-      sBP = __builtin_fmaf(Bh, P, sBP);
-      sAAA = __builtin_fmaf(AA, A, sAAA);
-      sABB = __builtin_fmaf(A, BB, sABB);
-      sAAB = __builtin_fmaf(AA, Bh, sAAB);
-      sBBB = __builtin_fmaf(BB, Bh, sBBB);
-      sAAP = __builtin_fmaf(AA, P, sAAP);
-      sX4P = __builtin_fmaf(X4, P, sX4P);
-      sABP = __builtin_fmaf(AP, Bh, sABP);
-      av[b] = __builtin_amdgcn_sqrtf(P);
-      sa += av[b];
-      th[b] = fast_angle(re, im, av[b]);
-    });
-    a0 = av[0]; a1 = av[1];
-    if constexpr (FIRST) {
-      const float w00 = wrapped_step(th[1], th[0]);
-      Kt = row_sum(th[0]) * (1.0f / 16.0f);
-      Kw = row_sum(w00) * (1.0f / 16.0f);
-      Ka = row_sum(__builtin_fabsf(th[0])) * (1.0f / 16.0f);
-    }
-    static_for<2>([&](auto bb) {
-      constexpr int b = decltype(bb)::value;
-      const float d = th[b] - Kt;
-      st1 += d;
-      st2 = __builtin_fmaf(d, d, st2);
-      const float e = __builtin_fabsf(th[b]) - Ka;
-      sab1 += e;
-      sab2 = __builtin_fmaf(e, e, sab2);
-    });
-    const float wa = wrapped_step(th[1], th[0]);
-    step(wa);
-    const float rot = dpp<kRowRor15>(th[0]);              // lane l: angle(j, 0) of lane l + 1 (15 -> lane 0 of the row)
-    if constexpr (!FIRST) {
-      const float nxt = last_lane ? rot : rot_prev;
-      const float wb = wrapped_step(nxt, th_b1_prev);
-      step(wb);
-      wmax = __builtin_fmaxf(__builtin_fmaxf(wmax, __builtin_fabsf(wa)), __builtin_fabsf(wb));
-    } else {
-      wmax = __builtin_fabsf(wa);
-    }
-    if constexpr (LAST) {
-      // (j, b = 1) of this row's lanes 0 .. 14; and, one row late as everywhere, nothing for lane 15: the frame's last sample
-      const float w = wrapped_step(rot, th[1]);
-      const float wc = last_lane ? Kw : w;
-      step(wc);
-      wmax = __builtin_fmaxf(wmax, __builtin_fabsf(wc));
-    }
-    th_b1_prev = th[1];
-    rot_prev = rot;
-  }
-
-  __device__ __forceinline__ void envelope(float a, float mu) {
-    const float d = a - mu, d2 = d * d;
-    sad1 += __builtin_fabsf(d);
-    sad2 += d2;
-    sad4 = __builtin_fmaf(d2, d2, sad4);
-  }
+// The statistics sweep of amcx_wave_kernel.h (StatsT) for a frame that lives in one 16-lane row: the right neighbour of
+// (j, b = 1) is (j, b = 0) of lane l + 1, or (j + 1, b = 0) of lane 0 for lane 15; the shifts are the means of the row's
+// first 16 values.
+struct RowLanes {
+  static constexpr float kInvLanes = 1.0f / 16.0f;
+  static __device__ __forceinline__ float sum_all(float v) { return row_sum(v); }
+  static __device__ __forceinline__ float next_lane(float v) { return dpp<kRowRor15>(v); }
+  static __device__ __forceinline__ bool is_last(int lane) { return (lane & 15) == 15; }
 };
+using RowStats = StatsT<RowLanes>;
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
@@ -177,7 +97,6 @@ __global__ __launch_bounds__(SCfg<N>::kThreads, SCfg<N>::kWavesPerWG / 4) void a
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fq = lane >> 4, l = lane & 15;                   // frame of the pass, lane of the row
-  const bool last_lane = l == 15;
   float2* const ex = reinterpret_cast<float2*>(smem + wave * kExBytes) + fq * kFrameStride;   // this frame's exchange block
   float* const stash = reinterpret_cast<float*>(smem + kWavesPerWG * kExBytes + wave * kStashBytes);
 
@@ -306,7 +225,7 @@ __global__ __launch_bounds__(SCfg<N>::kThreads, SCfg<N>::kWavesPerWG / 4) void a
     float a[2 * kRows];
     static_for<kRows>([&](auto jj) {
       constexpr int j = decltype(jj)::value;
-      S.template row<j == 0, j == kRows - 1>(xr[2 * j], xi[2 * j], xr[2 * j + 1], xi[2 * j + 1], last_lane, a[2 * j], a[2 * j + 1]);
+      S.template row<j == 0, j == kRows - 1>(xr[2 * j], xi[2 * j], xr[2 * j + 1], xi[2 * j + 1], lane, a[2 * j], a[2 * j + 1]);
     });
     // ---- envelope about the exact mean ----
     {

@@ -330,7 +330,17 @@ constexpr int kStampSections = 8;
 // ---------------------------------------------------------------------------
 // Per-lane running sums of the statistics sweep (27 values + the three shifts)
 // ---------------------------------------------------------------------------
-struct Stats {
+// How a frame's lanes see each other, for the sweep: all 64 lanes of the wave (one wave per frame: the kernels below, the
+// quad and group kernels), or one 16-lane DPP row (four frames per wave: amcx_short_kernel.h, RowLanes).
+struct WaveLanes {
+  static constexpr float kInvLanes = 1.0f / 64.0f;
+  static __device__ __forceinline__ float sum_all(float v) { return bcast_l63(wave_sum_l63(v)); }   // the total, in every lane
+  static __device__ __forceinline__ float next_lane(float v) { return dpp<kWaveRol1>(v); }          // lane l reads lane l + 1 (last -> first)
+  static __device__ __forceinline__ bool is_last(int lane) { return lane == 63; }
+};
+
+template <class Lanes>
+struct StatsT {
   float sA = 0, sBh = 0, sP = 0, sAA = 0, sX4 = 0, sAB = 0, sAP = 0, sBP = 0;
   float sAAA = 0, sABB = 0, sAAB = 0, sBBB = 0, sAAP = 0, sX4P = 0, sABP = 0;
   float sa = 0, st1 = 0, st2 = 0, sab1 = 0, sab2 = 0, sw1 = 0, sw2 = 0, sw3 = 0, sw4 = 0;
@@ -381,9 +391,9 @@ struct Stats {
     if constexpr (FIRST) {
       // shifts: mean over the wave of the first angle / first step
       const float w00 = wrapped_step(th[1], th[0]);
-      Kt = bcast_l63(wave_sum_l63(th[0])) * (1.0f / 64.0f);
-      Kw = bcast_l63(wave_sum_l63(w00)) * (1.0f / 64.0f);
-      Ka = bcast_l63(wave_sum_l63(__builtin_fabsf(th[0]))) * (1.0f / 64.0f);
+      Kt = Lanes::sum_all(th[0]) * Lanes::kInvLanes;
+      Kw = Lanes::sum_all(w00) * Lanes::kInvLanes;
+      Ka = Lanes::sum_all(__builtin_fabsf(th[0])) * Lanes::kInvLanes;
     }
     static_for<2>([&](auto bb) {
       constexpr int b = decltype(bb)::value;
@@ -396,10 +406,10 @@ struct Stats {
     });
     const float wa = wrapped_step(th[1], th[0]);          // sample (i,0) -> (i,1), same lane
     step(wa);
-    const float rot = dpp<kWaveRol1>(th[0]);              // lane l: angle(i,0) of lane l+1 (63 -> lane 0)
+    const float rot = Lanes::next_lane(th[0]);            // lane l: angle(i,0) of lane l+1 (63 -> lane 0)
     if constexpr (!FIRST) {
       // right neighbour of (i-1, b=1) is (i-1, b=0) of lane l+1, or (i, b=0) of lane 0 for lane 63
-      const float nxt = (lane == 63) ? rot : rot_prev;
+      const float nxt = Lanes::is_last(lane) ? rot : rot_prev;
       const float wb = wrapped_step(nxt, th_b1_prev);
       step(wb);
       wmax = __builtin_fmaxf(__builtin_fmaxf(wmax, __builtin_fabsf(wa)), __builtin_fabsf(wb));   // one v_max3
@@ -409,7 +419,7 @@ struct Stats {
     if constexpr (LAST) {
       // (last row, b=1): lane 63 holds the frame's last sample, which has no step
       const float w = wrapped_step(rot, th[1]);
-      const float wc = lane == 63 ? Kw : w;
+      const float wc = Lanes::is_last(lane) ? Kw : w;
       step(wc);
       wmax = __builtin_fmaxf(wmax, __builtin_fabsf(wc));
     }
@@ -431,6 +441,8 @@ struct Stats {
     sad4 = __builtin_fmaf(d2, d2, sad4);
   }
 };
+using Stats = StatsT<WaveLanes>;
+
 
 // LDS addresses that depend only on the lane (bytes)
 struct LaneAddr {
