@@ -303,7 +303,7 @@ int amcx_features18_c64_ws(const void* iq_dev, int64_t n_frames, int32_t frame_s
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
   const float2* iq = static_cast<const float2*>(iq_dev);
   if (v == AMCX_VARIANT_WAVE) {
-    // N = 8192: four waves per frame (amcx_quad_kernel.h); 16384 / 32768: eight / sixteen (amcx_group_kernel.h); 128 / 256:
+    // N = 8192: four waves per frame (amcx_quad_kernel.h); 16384 / 32768: eight / sixteen (amcx_group_kernel.h); 128 / 256 / 512:
     // four frames per wave (amcx_short_kernel.h); every other wave size: one wave per frame
     hipError_t e;
     if (frame_size == amcx::quad::kN)
@@ -312,7 +312,7 @@ int amcx_features18_c64_ws(const void* iq_dev, int64_t n_frames, int32_t frame_s
       e = amcx::group::launch_group<8>(iq, n_frames, row_stride_elems, out_dev, out_row_stride, stream, cu_count());
     else if (frame_size == amcx::group::G<16>::kN)
       e = amcx::group::launch_group<16>(iq, n_frames, row_stride_elems, out_dev, out_row_stride, stream, cu_count());
-    else if (amcx::shortk::short_supports(frame_size))       // 128, 256: four frames per wave (amcx_short_kernel.h)
+    else if (amcx::shortk::short_supports(frame_size))       // 128, 256, 512: four frames per wave (amcx_short_kernel.h)
       e = amcx::shortk::launch_short(iq, n_frames, frame_size, row_stride_elems, out_dev, out_row_stride, stream, cu_count());
     else
       e = amcx::launch_wave(iq, n_frames, frame_size, row_stride_elems, out_dev, out_row_stride, stream, cu_count());

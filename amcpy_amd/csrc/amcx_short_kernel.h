@@ -1,4 +1,4 @@
-// N = 128 and 256 (RadioML-2016-style short frames): FOUR frames per wavefront, sixteen lanes per frame.
+// N = 128, 256 and 512 (RadioML-2016-style short frames): FOUR frames per wavefront, sixteen lanes per frame.
 //
 // The one-wave-per-frame kernel (amcx_wave_kernel.h) spreads a 128-sample frame over 64 lanes, two samples each: every
 // frame then pays a full 64-lane reduction of its 27 sums, another for the envelope's mean, and shares a 1024-point-shaped
@@ -20,8 +20,11 @@
 //   * after eight passes (32 frames) lanes 0-31 turn a stash row each into 18 features in fp64; frames with a phase step
 //     within an angle rounding of +-pi get f5 / f9 from the exact fp64 sweep (wave_exact_frequency).
 // N = 256 is the same machine with eight rows per lane: pass 1 is a radix 8 over j, and a lane takes TWO of the eight
-// 32-point transforms of passes 2 and 3 (kj = l / 4 and l / 4 + 4), one after the other.
-// N = 128: 16 waves per CU (116 VGPRs); N = 256: 12 (its 9.5 KB exchange block per wave).  No barrier in the frame loop,
+// 32-point transforms of passes 2 and 3 (kj = l / 4 and l / 4 + 4), one after the other.  N = 512 has sixteen rows per lane:
+// pass 1 is a radix 16 over j, its sixteen 32-point transforms go through the exchange block in two batches of eight, only
+// four of the sixteen rows are requested a pass ahead (the rest at the head of the pass: with eight ahead three of them were
+// stored to scratch straight from their loads), and |x| is parked in the exchange block for the envelope's second sweep.
+// N = 128: 16 waves per CU (116 VGPRs); N = 256 / 512: 12 (143 / 162 VGPRs; a 9.5 KB exchange block per wave).  No barrier in the frame loop,
 // nothing shared between waves but the twiddle tables.  Algorithmic HBM bytes per frame: 8 N + 72.
 #pragma once
 
@@ -40,14 +43,21 @@ constexpr int kTw2Bytes = 4 * 8 * 8;                         // pass 2: [a][kc] 
 
 template <int N>
 struct SCfg {
-  static_assert(N == 128 || N == 256, "sixteen lanes per frame: 8 or 16 samples a lane");
+  static_assert(N == 128 || N == 256 || N == 512, "sixteen lanes per frame: 8, 16 or 32 samples a lane");
   static constexpr int kRows = N / 32;                        // rows of 32 samples (16 lanes x 2) per frame
-  static constexpr int kLogRows = N == 128 ? 2 : 3;
-  static constexpr int kRounds = kRows / 4;                   // 32-point transforms a lane takes in passes 2 and 3
+  static constexpr int kLogRows = N == 128 ? 2 : N == 256 ? 3 : 4;
+  // passes 2 and 3 take the kRows 32-point transforms of a frame in kHalves batches of kBlocks through the exchange block
+  // (N = 512: two batches of eight, so that the block stays at 9.5 KB), a lane kRounds of them per batch
+  static constexpr int kHalves = N == 512 ? 2 : 1, kBlocks = kRows / kHalves, kRounds = kBlocks / 4;
   static constexpr int kWavesPerWG = N == 128 ? 16 : 12, kThreads = 64 * kWavesPerWG;
   static constexpr int kBatchPasses = N == 128 ? 8 : 4, kBatch = kQuad * kBatchPasses;   // frames finalised together, one per lane
-  static constexpr int kFrameStride = kRows * kKjStride + (N == 256 ? 16 : 0);   // the four frames of a pass 128 bytes apart in the banks
-  static constexpr int kExBytes = kQuad * kFrameStride * 8;   // 4 608 / 9 728
+  // rows requested a pass ahead (the rest at the head of the pass itself: N = 512 has 64 registers of samples)
+  static constexpr int kHead = N == 512 ? 4 : kRows;
+  // |x| of the sweep for the envelope's second sweep: in registers, or (N = 512) parked in the exchange block
+  static constexpr bool kParkA = N == 512;
+  static constexpr int kFrameStride = kBlocks * kKjStride + (N == 128 ? 0 : 16);   // the four frames of a pass 128 bytes apart in the banks
+  static constexpr int kExBytes = kQuad * kFrameStride * 8;   // 4 608 / 9 728 / 9 728
+  static_assert(!kParkA || 2 * kRows * 64 * 4 <= kExBytes, "|x| parking fits the wave's exchange area");
   static constexpr int kStashBytes = kBatch * kRow * 4;       // 4 608 / 2 304
   static constexpr int kTw1Bytes = 16 * (kRows - 1) * 16;     // pass 1: [l][kj - 1] (c0, s0, c1, s1)
   static constexpr int kOffTw1 = kWavesPerWG * (kExBytes + kStashBytes), kOffTw2 = kOffTw1 + kTw1Bytes;
@@ -91,7 +101,7 @@ __global__ __launch_bounds__(SCfg<N>::kThreads, SCfg<N>::kWavesPerWG / 4) void a
   using C = SCfg<N>;
   constexpr int kN = N, kRows = C::kRows, kRounds = C::kRounds, kWavesPerWG = C::kWavesPerWG, kExBytes = C::kExBytes;
   constexpr int kStashBytes = C::kStashBytes, kOffTw1 = C::kOffTw1, kOffTw2 = C::kOffTw2, kFrameStride = C::kFrameStride;
-  constexpr int kBatchPasses = C::kBatchPasses;
+  constexpr int kBatchPasses = C::kBatchPasses, kHead = C::kHead, kBlocks = C::kBlocks;
   extern __shared__ float4 amcx_short_smem[];
   char* const smem = reinterpret_cast<char*>(amcx_short_smem);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -138,15 +148,19 @@ __global__ __launch_bounds__(SCfg<N>::kThreads, SCfg<N>::kWavesPerWG / 4) void a
   long long p_hi = p_lo + per;
   if (p_hi > n_pass) p_hi = n_pass;
 
-  auto load_pass = [&](v4f (&v)[kRows], long long p) {
+  // rows [FIRST, FIRST + COUNT) of this lane's frame of pass p
+  auto load_rows = [&](auto first, auto& v, long long p) {
+    constexpr int FIRST = decltype(first)::value;
     long long f = p * kQuad + fq;
     if (f >= n_frames) f = n_frames - 1;                      // a pass past the end reads the last frame again (not stored)
     const float2* src = iq + f * row_stride + 2 * l;
-    static_for<kRows>([&](auto jj) {
+    static_for<sizeof(v) / sizeof(v[0])>([&](auto jj) {
       constexpr int j = decltype(jj)::value;
-      v[j] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src + 32 * j));
+      v[j] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src + 32 * (FIRST + j)));
     });
   };
+  using HeadRows = std::integral_constant<int, 0>;
+  using TailRows = std::integral_constant<int, kHead>;
 
   // ---- batch finalisation: lane g turns stash row g into 18 features (fp64) ----
   auto finalise = [&](long long f0, int count) {
@@ -190,18 +204,26 @@ __global__ __launch_bounds__(SCfg<N>::kThreads, SCfg<N>::kWavesPerWG / 4) void a
     lds_wave_fence();
   };
 
-  v4f nxt[kRows];
-  if (p_lo < p_hi) load_pass(nxt, p_lo);
+  v4f nxt[kHead];
+  if (p_lo < p_hi) load_rows(HeadRows{}, nxt, p_lo);
   int in_batch = 0;                                           // passes whose rows are in the stash
   long long batch_f0 = p_lo * kQuad;
 
   for (long long p = p_lo; p < p_hi; ++p) {
     float xr[2 * kRows], xi[2 * kRows];
-    static_for<kRows>([&](auto jj) {
+    if constexpr (kHead < kRows) {                            // the rows that were not requested a pass ahead
+      v4f late[kRows - kHead];
+      load_rows(TailRows{}, late, p);
+      static_for<kRows - kHead>([&](auto jj) {
+        constexpr int j = kHead + decltype(jj)::value;
+        xr[2 * j] = late[j - kHead].x; xi[2 * j] = late[j - kHead].y; xr[2 * j + 1] = late[j - kHead].z; xi[2 * j + 1] = late[j - kHead].w;
+      });
+    }
+    static_for<kHead>([&](auto jj) {
       constexpr int j = decltype(jj)::value;
       xr[2 * j] = nxt[j].x; xi[2 * j] = nxt[j].y; xr[2 * j + 1] = nxt[j].z; xi[2 * j + 1] = nxt[j].w;
     });
-    if (p + 1 < p_hi) load_pass(nxt, p + 1);                  // lands behind this pass
+    if (p + 1 < p_hi) load_rows(HeadRows{}, nxt, p + 1);      // lands behind this pass
     __builtin_amdgcn_s_setprio(1);
     // ---- the frame times 2^-ex (exact), ex the even-rounded exponent of its largest component: NaNs drop out of the
     // maximum (the sums carry them), an infinite or all-zero frame keeps 0 ----
@@ -222,15 +244,28 @@ __global__ __launch_bounds__(SCfg<N>::kThreads, SCfg<N>::kWavesPerWG / 4) void a
     }
     // ---- statistics sweep ----
     RowStats S;
-    float a[2 * kRows];
+    float a[C::kParkA ? 2 : 2 * kRows];
+    float2* const park = reinterpret_cast<float2*>(smem + wave * kExBytes) + lane;   // (N = 512) |x| of row j at park[64 j]
     static_for<kRows>([&](auto jj) {
       constexpr int j = decltype(jj)::value;
-      S.template row<j == 0, j == kRows - 1>(xr[2 * j], xi[2 * j], xr[2 * j + 1], xi[2 * j + 1], lane, a[2 * j], a[2 * j + 1]);
+      constexpr int k = C::kParkA ? 0 : 2 * j;
+      S.template row<j == 0, j == kRows - 1>(xr[2 * j], xi[2 * j], xr[2 * j + 1], xi[2 * j + 1], lane, a[k], a[k + 1]);
+      if constexpr (C::kParkA) park[64 * j] = make_float2(a[0], a[1]);
     });
     // ---- envelope about the exact mean ----
     {
       const float mu = row_sum(S.sa) * (1.0f / (float)kN);
-      static_for<2 * kRows>([&](auto ee) { S.envelope(a[decltype(ee)::value], mu); });
+      if constexpr (C::kParkA) {
+        lds_wave_fence();
+        static_for<kRows>([&](auto jj) {
+          const float2 aa = park[64 * decltype(jj)::value];
+          S.envelope(aa.x, mu);
+          S.envelope(aa.y, mu);
+        });
+        lds_wave_fence();                                     // the area is the exchange block again
+      } else {
+        static_for<2 * kRows>([&](auto ee) { S.envelope(a[decltype(ee)::value], mu); });
+      }
     }
     // ---- the row's sums -> stash row (pass, frame): every lane of a row ends with the totals, lane 0 stores them ----
     float* const row = stash + (in_batch * kQuad + fq) * kRow;
@@ -261,58 +296,61 @@ __global__ __launch_bounds__(SCfg<N>::kThreads, SCfg<N>::kWavesPerWG / 4) void a
         });
         dif<kRows, 0, kRows>(yr[b], yi[b]);                   // frequency kj at position bitrev(kj)
       });
-      static_for<kRows>([&](auto kk) {
-        constexpr int kj = decltype(kk)::value;
-        constexpr int pos = bitrev(kj, C::kLogRows);
-        float r0 = yr[0][pos], i0 = yi[0][pos], r1 = yr[1][pos], i1 = yi[1][pos];
-        if constexpr (kj != 0) {
-          const float4 t = tw1_l[kj - 1];
-          const float c0 = t.x, s0 = t.y, c1 = t.z, s1 = t.w;
-          const float tr0 = __builtin_fmaf(r0, c0, -(i0 * s0)); i0 = __builtin_fmaf(r0, s0, i0 * c0); r0 = tr0;
-          const float tr1 = __builtin_fmaf(r1, c1, -(i1 * s1)); i1 = __builtin_fmaf(r1, s1, i1 * c1); r1 = tr1;
-        }
-        *reinterpret_cast<float4*>(ex1_w + kj * kKjStride) = make_float4(r0, i0, r1, i1);
-      });
-    }
-    lds_wave_fence();
-    // ---- pass 2: lane (kj, a) takes y[kj][4 c + a], c < 8: radix 8 over c, times W_32^(a kc) -> z[kj][kc][a] ----
-    // (a lane reads and writes the same 8 places of its block: positions = a mod 4 of block kj)
-    static_for<kRounds>([&](auto rr) {
-      constexpr int blk = 4 * decltype(rr)::value * kKjStride;   // round r: kj = l / 4 + 4 r
-      float zr[8], zi[8];
-      static_for<8>([&](auto cc) {
-        constexpr int c = decltype(cc)::value;
-        const float2 v = ex1_r[blk + 4 * c];
-        zr[c] = v.x; zi[c] = v.y;
-      });
-      dif<8, 0, 8>(zr, zi);                                   // frequency kc at position bitrev(kc)
-      lds_wave_fence();
-      static_for<8>([&](auto kk) {
-        constexpr int kc = decltype(kk)::value;
-        constexpr int pos = bitrev(kc, 3);
-        float r = zr[pos], i = zi[pos];
-        if constexpr (kc != 0) {
-          const float2 t = tw2_l[kc];
-          const float c = t.x, s = t.y;
-          const float tr = __builtin_fmaf(r, c, -(i * s)); i = __builtin_fmaf(r, s, i * c); r = tr;
-        }
-        ex2_w[blk + 4 * kc] = make_float2(r, i);
-      });
-    });
-    lds_wave_fence();
-    // ---- pass 3: lane (kj, h) takes z[kj][2 h + e][a], a < 4: radix 4 over a; the frame's peak ----
-    {
       float pk = 0.f;
-      static_for<2 * kRounds>([&](auto ee) {
-        constexpr int e = decltype(ee)::value & 1, blk = 4 * (decltype(ee)::value >> 1) * kKjStride;
-        const float4 v01 = *reinterpret_cast<const float4*>(ex2_r + blk + 4 * e);
-        const float4 v23 = *reinterpret_cast<const float4*>(ex2_r + blk + 4 * e + 2);
-        float wr[4] = {v01.x, v01.z, v23.x, v23.z}, wi[4] = {v01.y, v01.w, v23.y, v23.w};
-        dif<4, 0, 4>(wr, wi);
-        static_for<4>([&](auto kk) {
-          constexpr int k = decltype(kk)::value;
-          pk = __builtin_fmaxf(pk, __builtin_fmaf(wr[k], wr[k], wi[k] * wi[k]));
+      static_for<C::kHalves>([&](auto hh) {
+        constexpr int half = decltype(hh)::value;
+        // y[kj][2 l], y[kj][2 l + 1] of this batch's kBlocks values of kj -> the exchange block
+        static_for<kBlocks>([&](auto kk) {
+          constexpr int jb = decltype(kk)::value, kj = half * kBlocks + jb;
+          constexpr int pos = bitrev(kj, C::kLogRows);
+          float r0 = yr[0][pos], i0 = yi[0][pos], r1 = yr[1][pos], i1 = yi[1][pos];
+          if constexpr (kj != 0) {
+            const float4 t = tw1_l[kj - 1];
+            const float c0 = t.x, s0 = t.y, c1 = t.z, s1 = t.w;
+            const float tr0 = __builtin_fmaf(r0, c0, -(i0 * s0)); i0 = __builtin_fmaf(r0, s0, i0 * c0); r0 = tr0;
+            const float tr1 = __builtin_fmaf(r1, c1, -(i1 * s1)); i1 = __builtin_fmaf(r1, s1, i1 * c1); r1 = tr1;
+          }
+          *reinterpret_cast<float4*>(ex1_w + jb * kKjStride) = make_float4(r0, i0, r1, i1);
         });
+        lds_wave_fence();
+        // ---- pass 2: lane (kj, a) takes y[kj][4 c + a], c < 8: radix 8 over c, times W_32^(a kc) -> z[kj][kc][a] ----
+        // (a lane reads and writes the same 8 places of its block: positions = a mod 4 of block kj)
+        static_for<kRounds>([&](auto rr) {
+          constexpr int blk = 4 * decltype(rr)::value * kKjStride;   // round r: block l / 4 + 4 r of the batch
+          float zr[8], zi[8];
+          static_for<8>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            const float2 v = ex1_r[blk + 4 * c];
+            zr[c] = v.x; zi[c] = v.y;
+          });
+          dif<8, 0, 8>(zr, zi);                                 // frequency kc at position bitrev(kc)
+          lds_wave_fence();
+          static_for<8>([&](auto kk) {
+            constexpr int kc = decltype(kk)::value;
+            constexpr int pos = bitrev(kc, 3);
+            float r = zr[pos], i = zi[pos];
+            if constexpr (kc != 0) {
+              const float2 t = tw2_l[kc];
+              const float c = t.x, s2 = t.y;
+              const float tr = __builtin_fmaf(r, c, -(i * s2)); i = __builtin_fmaf(r, s2, i * c); r = tr;
+            }
+            ex2_w[blk + 4 * kc] = make_float2(r, i);
+          });
+        });
+        lds_wave_fence();
+        // ---- pass 3: lane (kj, h) takes z[kj][2 h + e][a], a < 4: radix 4 over a; the frame's peak ----
+        static_for<2 * kRounds>([&](auto ee) {
+          constexpr int e = decltype(ee)::value & 1, blk = 4 * (decltype(ee)::value >> 1) * kKjStride;
+          const float4 v01 = *reinterpret_cast<const float4*>(ex2_r + blk + 4 * e);
+          const float4 v23 = *reinterpret_cast<const float4*>(ex2_r + blk + 4 * e + 2);
+          float wr[4] = {v01.x, v01.z, v23.x, v23.z}, wi[4] = {v01.y, v01.w, v23.y, v23.w};
+          dif<4, 0, 4>(wr, wi);
+          static_for<4>([&](auto kk) {
+            constexpr int k = decltype(kk)::value;
+            pk = __builtin_fmaxf(pk, __builtin_fmaf(wr[k], wr[k], wi[k] * wi[k]));
+          });
+        });
+        lds_wave_fence();                                       // the block is free for the next batch / pass
       });
       pk = row_max(pk);
       if (l == 0) row[27] = pk;
@@ -353,12 +391,13 @@ inline hipError_t launch_short_n(const float2* iq, int64_t n_frames, int64_t row
   return hipGetLastError();
 }
 
-inline bool short_supports(int frame_size) { return frame_size == 128 || frame_size == 256; }
+inline bool short_supports(int frame_size) { return frame_size == 128 || frame_size == 256 || frame_size == 512; }
 
 inline hipError_t launch_short(const float2* iq, int64_t n_frames, int32_t frame_size, int64_t row_stride, float* out,
                                int64_t out_stride, hipStream_t stream, int cus) {
-  return frame_size == 128 ? launch_short_n<128>(iq, n_frames, row_stride, out, out_stride, stream, cus)
-                           : launch_short_n<256>(iq, n_frames, row_stride, out, out_stride, stream, cus);
+  return frame_size == 128   ? launch_short_n<128>(iq, n_frames, row_stride, out, out_stride, stream, cus)
+         : frame_size == 256 ? launch_short_n<256>(iq, n_frames, row_stride, out, out_stride, stream, cus)
+                             : launch_short_n<512>(iq, n_frames, row_stride, out, out_stride, stream, cus);
 }
 
 }  // namespace shortk

@@ -1256,7 +1256,7 @@ inline const char* wave_kernel_name(int frame_size) {
   switch (frame_size) {
     case 128: return "amcx_features18_short_kernel<128>";      // four frames per wave: amcx_short_kernel.h
     case 256: return "amcx_features18_short_kernel<256>";
-    case 512: return "amcx_features18_wave_kernel<512>";
+    case 512: return "amcx_features18_short_kernel<512>";
     case 1024: return "amcx_features18_wave_kernel<1024>";
     case 2048: return "amcx_features18_wave_kernel<2048>";
     case 4096: return "amcx_features18_wave_kernel<4096>";
@@ -1295,13 +1295,12 @@ inline hipError_t launch_wave(const float2* iq, int64_t n_frames, int32_t frame_
                               int64_t row_stride, float* out, int64_t out_stride,
                               hipStream_t stream, int cus) {
   switch (frame_size) {
-    // (128 and 256 ran here until late in round 5 -- kGroup = 8 / 4 frames sharing one run of FFT passes 2-3 -- and
-    //  have a kernel of their own now, amcx_short_kernel.h: +34 % / +13 %; the template still takes those sizes)
-    case 512: return launch_wave_n<512>(iq, n_frames, row_stride, out, out_stride, stream, cus);
+    // (128, 256 and 512 ran here until late in round 5 -- kGroup = 8 / 4 / 2 frames sharing one run of FFT passes 2-3 -- and
+    //  have a kernel of their own now, amcx_short_kernel.h: +34 % / +13 % / +2.5 ... 5 %; the template still takes those sizes)
     case 1024: return launch_wave_n<1024>(iq, n_frames, row_stride, out, out_stride, stream, cus);
     case 2048: return launch_wave_n<2048>(iq, n_frames, row_stride, out, out_stride, stream, cus);
     case 4096: return launch_wave_n<4096>(iq, n_frames, row_stride, out, out_stride, stream, cus);
-    default: return hipErrorNotSupported;       // 128, 256, 8192, 16384, 32768 have kernels of their own (amcx.hip)
+    default: return hipErrorNotSupported;       // 128, 256, 512, 8192, 16384, 32768 have kernels of their own (amcx.hip)
   }
 }
 

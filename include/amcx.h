@@ -31,7 +31,7 @@
  *     un-scales in fp64.  The throughput kernel's fp32 sums hold inside 1e-5 <~ rms|x| <~ 1e5;
  *     a frame outside that (or any of whose sums overflows: a single 1e7 sample among unit
  *     ones) is re-run on a copy multiplied by an exact power of two by the throughput kernel itself
- *     -- at the frame sizes 512 ... 4096 right behind the batch it was found in (128 and 256 take EVERY frame times a
+ *     -- at the frame sizes 1024 ... 4096 right behind the batch it was found in (128, 256 and 512 take EVERY frame times a
  *     power of two, as the block kernel does: nothing to re-run), at 8192 in a pass of
  *     the quad at the end of the launch, at 16384 / 32768 at the end of every epoch of 2048 frames of a
  *     workgroup (a data set that is out of range throughout, e.g. raw 24-bit ADC counts, runs at half
@@ -114,8 +114,8 @@ extern "C" {
 #define AMCX_VARIANT_WAVE 2     /* the throughput kernels: the frame held in registers, register
                                    FFT with LDS exchanges, fp32 sums with an fp64 finaliser, frames
                                    outside the fp32 range re-run inside the launch; frame_size a
-                                   power of two, 128 ... 32768 (512 ... 4096: one wavefront per
-                                   frame; 128 / 256: four frames per wavefront; 8192: four waves
+                                   power of two, 128 ... 32768 (1024 ... 4096: one wavefront per
+                                   frame; 128 ... 512: four frames per wavefront; 8192: four waves
                                    per frame, 16384 / 32768: eight / sixteen) */
 
 #define AMCX_MIN_FRAME_SIZE 2

@@ -188,7 +188,7 @@ def test_random_frames_against_oracle():
             _assert_parity(_run(x, variant), gold, x, f"synthetic N={N} {variant}")
 
 
-@pytest.mark.parametrize("N", [128, 256, 1024, 2048, 4096])
+@pytest.mark.parametrize("N", [128, 256, 512, 1024, 2048, 4096])
 def test_full_snr_grid_against_oracle(N):
     """The whole SNR grid of the BASELINE configs -- 6 modulations x 26 SNRs (-20 ... +30 dB, step 2) x 8 frames = 1 248
     frames per frame size, the host generator with SURVEY 8d's seeds (1000 + 10 mod + snr index) -- against the oracle,
@@ -220,14 +220,14 @@ def test_variants_agree():
 
 
 def test_wave_kernel_short_power_of_two_frames():
-    """N = 128, 256: four frames per wave, sixteen lanes per frame (amcx_short_kernel.h: row reductions, a 4 x 8 x 4 /
-    8 x 8 x 4 register FFT with two LDS transposes, every frame scaled by a power of two); N = 512: the one-wave kernel with
-    fewer rows per lane (two frames sharing one run of FFT passes 2-3).  Frame counts chosen to leave ragged passes, batches and
+    """N = 128, 256, 512: four frames per wave, sixteen lanes per frame (amcx_short_kernel.h: row reductions, a 4 x 8 x 4 /
+    8 x 8 x 4 / 16 x 8 x 4 register FFT with two LDS transposes -- at 512 in two batches of eight 32-point transforms --, every
+    frame scaled by a power of two).  Frame counts chosen to leave ragged passes, batches and
     tail chunks; pure tones on bins of every residue of the short kernel's index split X[kj + R (kc + 8 ka)] (each residue takes
     another lane and register through the transposes).  Checked against the oracle and the block kernel."""
     from amcpy_amd import synth, _lib
     for N, F in ((128, 1531), (256, 777), (512, 403)):
-        assert ("short_kernel" if N <= 256 else "wave_kernel") in _lib.kernel_name(N, _lib.VARIANT_AUTO)
+        assert "short_kernel" in _lib.kernel_name(N, _lib.VARIANT_AUTO)
         x = np.concatenate([synth.host_block(m, snr, F // 3 + 1, N, seed=N + i)
                             for i, (m, snr) in enumerate((("BPSK", 0.0), ("16QAM", 12.0), ("WGN", -10.0)))])[:F]
         n = np.arange(N)
