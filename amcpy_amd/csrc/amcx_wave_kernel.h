@@ -23,12 +23,11 @@
 // Index maps (verified against np.fft.fft with the LDS bank rules in
 // tools/wave_fft_model.py).  A frame is ROWS = N/128 rows of 128 samples:
 //   load     lane l, row i, b in {0,1}  <- x[128 i + 2 l + b]   (global_load_dwordx4, coalesced)
-// Register FFT of NF = 128 R points (R = 16 -> 2048, 8 -> 1024, 4 -> 512, 2 -> 256, 1 -> 128), NF = R * 16 * 8:
+// Register FFT of NF = 128 R points (R = 16 -> 2048, 8 -> 1024), NF = R * 16 * 8:
 //   pass 1   R-point DFT over i   -> k1   (no twiddle here: W_NF^((8 n2 + n3) k1) rides passes 2 and 3)
-//   xchg 1   phases g (R = 16: k1 = 2 kk + g, the two independent halves of pass 1's output; R <= 8: one phase,
+//   xchg 1   phases g (R = 16: k1 = 2 kk + g, the two independent halves of pass 1's output; R = 8: one phase,
 //            k1 = kk):  LDS[kk*136 + b*68 + l]; reader lane l' (kk = l'>>3, n3 = l'&7) takes n2 = 0..15 at
-//            [kk*136 + (n3&1)*68 + 4 n2 + (n3>>1)]; for R < 8 the eight kk slots are filled by 8/R consecutive
-//            frames (slot j R + k1)
+//            [kk*136 + (n3&1)*68 + 4 n2 + (n3>>1)]
 //   pass 2   16-point DFT over n2 of z[n2] (W_(NF/8)^k1)^n2 -> k2   (twisted decimation in time, factors T2[slot][15])
 //   xchg 2   LDS[k2*65 + 8 kk + n3]; reader lane l'' (kk = l''>>3, k2 = (l''&7) + 8 j)
 //   pass 3   8-point DFT over n3 of u[n3] (W_NF^(R k2 + k1))^n3 -> X[k1 + R k2 + 16 R k3]   (factors T3[g][j][7][lane]);
@@ -105,35 +104,27 @@ constexpr int kTw3Row = 64 * 8;                        // pass 3: [phase][j][7][
 
 template <int N>
 struct Cfg {
-  static_assert(N == 128 || N == 256 || N == 512 || N == 1024 || N == 2048 || N == 4096, "wave kernel frame sizes");
+  static_assert(N == 1024 || N == 2048 || N == 4096, "one wave per frame (128 ... 512: amcx_short_kernel.h; 8192 up: quad / group)");
   static constexpr bool kSplit = N == 4096;            // radix-2 DIF split in front of a 2048 FFT
-  // frames per wave per batch, finalised together one frame per lane: the fp64 algebra costs
-  // the same per batch whatever N is, so short frames come in larger batches
+  // frames per wave per batch, finalised together one frame per lane
   // (N = 2048 runs 16 waves per CU, below: batches of four are what its LDS then holds)
-  static constexpr int kFramesPerWave = N == 2048 ? 4 : N >= 1024 ? 8 : (N == 512 ? 16 : 32);
+  static constexpr int kFramesPerWave = N == 2048 ? 4 : 8;
   // how many times per frame the per-lane fp32 sums are reduced into the stash and started
   // afresh (the finaliser adds the rows in fp64): a lane that runs 64 samples into one accumulator
   // moves the worst scaled error of the N = 4096 sweep from 5.8e-6 to 6.9e-6
   static constexpr int kFlushes = N == 4096 ? 2 : 1;
   static constexpr int kStashBytes = kFramesPerWave * kFlushes * kStashStride * 4;
-  // short frames (R < 8 rows) fill only R of the 8 k1 slots of exchange 1, so kGroup = 8/R
-  // consecutive frames share one run of FFT passes 2 and 3: frame j's k1 goes to slot j R + k1,
-  // its bins come out in lanes [8 R j, 8 R (j+1))
-  static constexpr int kGroup = N < 1024 ? 1024 / N : 1;
   // frames per grab over the last stretch of a workgroup's slice (levels the waves' finish)
-  static constexpr int kTailChunk = kGroup > 2 ? kGroup : 2;
-  // waves per workgroup = waves per CU: 2 per SIMD when the frame alone takes 128 VGPRs (N >= 4096), 3 per SIMD for
-  // the short frames (their batches of 16 / 32 frames leave LDS for 12 waves; halving the batch doubles the fp64
-  // finaliser's share), 4 per SIMD at N = 2048 and N = 1024: the kernels fit 128 VGPRs there (2048: three spilled
+  static constexpr int kTailChunk = 2;
+  // waves per workgroup = waves per CU: 2 per SIMD when the frame alone takes 128 VGPRs (N = 4096),
+  // 4 per SIMD at N = 2048 and N = 1024: the kernels fit 128 VGPRs there (2048: three spilled
   // dwords, 1024: none -- kernel_resources.json).  N = 2048: the fourth wave hides 4.3 % of the SIMD's cycles, +0.5 %
   // through the library's step in round 3 (profiles/r3_waves16_ab.txt), +2.5 % under wave priority
   // (profiles/r4_wave_priority_ab.txt, section 7).  N = 1024 (round 4): 16 waves AND no second register set, +2.9 %
   // same box through the library (section 8); 16 waves with the prefetch kept spill 37 registers, -2.2 %.
-  static constexpr int kWavesPerWG = kSplit ? 8 : (N == 2048 || N == 1024 ? 16 : 12);
-  // next frame of the chunk loaded into a second register set while this one is processed: the short frames, whose
-  // load latency is a large share of the frame -- unless four waves share the SIMD and cover it for each other
-  // (at N = 1024 with 12 waves the second set buys nothing any more under wave priority: -0.1 %)
-  static constexpr bool kPrefetch = N <= 1024 && kWavesPerWG < 16;
+  // (Until late in round 5 this kernel also ran 128 ... 512 -- 8 / 4 / 2 frames sharing one run of FFT passes 2-3, twelve
+  // waves per CU, a second register set for the next frame: tools/experiments/r5_wave_short_frames.patch has those paths.)
+  static constexpr int kWavesPerWG = kSplit ? 8 : 16;
   static constexpr int kThreads = 64 * kWavesPerWG;
   static constexpr int kTailFrames = kWavesPerWG * kFramesPerWave;
   static constexpr int kRows = N / 128;                // rows of 128 samples per frame
@@ -496,7 +487,7 @@ __device__ __forceinline__ void twisted_dit(float (&re)[LEN], float (&im)[LEN], 
 template <int R>
 __device__ __forceinline__ float fft_peak(const float (&xr)[2 * R], const float (&xi)[2 * R],
                                           const LaneAddr& la) {
-  static_assert(R == 8 || R == 16, "shorter frames go through fft_front / fft_back");
+  static_assert(R == 8 || R == 16, "1024 or 2048 points (shorter frames: amcx_short_kernel.h)");
   constexpr int PH = R / 8;                  // exchange phases of 8 k1 values
   // pass 1 (both b groups): plain DFT over the rows, no twiddle (it rides pass 2 and pass 3).
   // With two exchange phases (R = 16) phase g takes the k1 of parity g: after the first
@@ -566,77 +557,6 @@ __device__ __forceinline__ float fft_peak(const float (&xr)[2 * R], const float 
       });
     });
     if constexpr (gph + 1 < PH) __builtin_amdgcn_sched_barrier(0);   // the other half starts only now
-  });
-  lds_wave_fence();
-  return peak;
-}
-
-// The same machine in two halves for R < 8 (one exchange phase), so that 8/R frames can share
-// the second half.  fft_front: pass 1 + exchange-1 write of one frame into k1 slots
-// [SLOT0, SLOT0 + R).
-template <int R, int SLOT0>
-__device__ __forceinline__ void fft_front(const float (&xr)[2 * R], const float (&xi)[2 * R],
-                                          const LaneAddr& la) {
-  static_assert(R < 8 && SLOT0 + R <= 8, "one exchange phase");
-  constexpr int LOG2R = R == 4 ? 2 : R == 2 ? 1 : 0;
-  float v0r[R], v0i[R], v1r[R], v1i[R];
-  static_for<R>([&](auto ii) {
-    constexpr int i = decltype(ii)::value;
-    v0r[i] = xr[2 * i]; v0i[i] = xi[2 * i]; v1r[i] = xr[2 * i + 1]; v1i[i] = xi[2 * i + 1];
-  });
-  dif<R, 0>(v0r, v0i);
-  dif<R, 0>(v1r, v1i);
-  static_for<R>([&](auto kk_) {
-    constexpr int k1 = decltype(kk_)::value;
-    constexpr int p = bitrev(k1, LOG2R);
-    constexpr int kk = SLOT0 + k1;
-    *reinterpret_cast<float2*>(la.ex1_w + (kk * kEx1StrideKK) * 8) = make_float2(v0r[p], v0i[p]);
-    *reinterpret_cast<float2*>(la.ex1_w + (kk * kEx1StrideKK + kEx1StrideB) * 8) = make_float2(v1r[p], v1i[p]);
-  });
-}
-
-// fft_back: exchange-1 read, pass 2, exchange 2, pass 3 over all eight k1 slots at once (the
-// twiddle tables know which frame-local k1 a slot holds); returns this lane's max |X|^2 over its
-// 16 bins (of the frame that owns slot lane>>3)
-__device__ __forceinline__ float fft_back(const LaneAddr& la) {
-  float zr[16], zi[16];
-  lds_wave_fence();
-  static_for<16>([&](auto nn) {
-    constexpr int n2 = decltype(nn)::value;
-    const float2 v = *reinterpret_cast<const float2*>(la.ex1_r + n2 * 32);
-    zr[n2] = v.x; zi[n2] = v.y;
-  });
-  asm volatile("; MARK fft2");
-  __builtin_amdgcn_sched_barrier(0);
-  const char* const tw2 = la.tw2;
-  twisted_dit<16>(zr, zi, [&](auto ii) {
-    return *reinterpret_cast<const float2*>(tw2 + decltype(ii)::value * 8);
-  });
-  float peak = 0.f;
-  lds_wave_fence();
-  static_for<16>([&](auto kk2) {
-    constexpr int k2 = decltype(kk2)::value;
-    constexpr int p = bitrev(k2, 4);
-    *reinterpret_cast<float2*>(la.ex2_w + (k2 * kEx2StrideK2) * 8) = make_float2(zr[p], zi[p]);
-  });
-  lds_wave_fence();
-  const char* const tw3 = la.tw3;
-  static_for<2>([&](auto jj) {
-    constexpr int j = decltype(jj)::value;
-    float ur[8], ui[8];
-    static_for<8>([&](auto nn) {
-      constexpr int n3 = decltype(nn)::value;
-      const float2 v = *reinterpret_cast<const float2*>(la.ex2_r + (j * 8 * kEx2StrideK2 + n3) * 8);
-      ur[n3] = v.x; ui[n3] = v.y;
-    });
-    twisted_dit<8>(ur, ui, [&](auto ii) {
-      return *reinterpret_cast<const float2*>(tw3 + (j * 7 + decltype(ii)::value) * kTw3Row);
-    });
-    static_for<4>([&](auto pp) {
-      constexpr int p = 2 * decltype(pp)::value;
-      peak = __builtin_fmaxf(__builtin_fmaxf(peak, __builtin_fmaf(ur[p], ur[p], ui[p] * ui[p])),
-                             __builtin_fmaf(ur[p + 1], ur[p + 1], ui[p + 1] * ui[p + 1]));
-    });
   });
   lds_wave_fence();
   return peak;
@@ -740,8 +660,7 @@ __device__ __forceinline__ void wave_exact_frequency(const float2* __restrict__ 
 // to do, and a consumer that did not order itself behind the call could see marked rows.  Round 4 moved the re-run
 // here: one launch per step; same box, through the library: +1.3 % at N = 2048, +0.6 % at 1024, +-0 at 4096, +3.0 % /
 // +0.5 % / +1.8 % at 128 / 256 / 512 -- profiles/r4_redo_in_kernel_ab.txt.  A launch boundary costs more than the 8 us of
-// the second kernel: 4 096 persistent waves drain and ramp up twice per step.)  The short-frame kernels (N < 1024),
-// whose frames share the FFT's back half in groups, re-run a frame as a group of one.
+// the second kernel: 4 096 persistent waves drain and ramp up twice per step.)
 template <int N>
 __device__ __forceinline__ void wave_body(
     const float2* __restrict__ iq, long long n_frames, long long row_stride,
@@ -844,10 +763,7 @@ __device__ __forceinline__ void wave_body(
       });
     };
     // one frame, registers -> stash row g
-    // (SLOT: for grouped short frames, which eighth of exchange 1 this frame's FFT front fills)
-    auto frame = [&](const float (&xr)[2 * ROWS], const float (&xi)[2 * ROWS], int g, auto slot_tag) {
-      constexpr int SLOT = decltype(slot_tag)::value;
-      constexpr bool kAInRegs = C::kGroup > 1;   // |x| stays in registers: exchange 1 is shared by the group
+    auto frame = [&](const float (&xr)[2 * ROWS], const float (&xi)[2 * ROWS], int g) {
       asm volatile("; MARK load");
       __builtin_amdgcn_s_setprio(AMCX_PRIO_OF(0));
       AMCX_STAMP(7);
@@ -922,16 +838,12 @@ __device__ __forceinline__ void wave_body(
       // =====================================================================
       Stats S;
       float sa_flushed = 0.f;                    // this lane's sum of |x| over the stretches flushed so far
-      float av[kAInRegs ? 2 * ROWS : 1];
       {
         static_for<ROWS>([&](auto ii) {
           constexpr int i = decltype(ii)::value;
           float a0, a1;
           S.template row<i == 0, i == ROWS - 1>(xr[2 * i], xi[2 * i], xr[2 * i + 1], xi[2 * i + 1], lane, a0, a1);
-          if constexpr (kAInRegs) {
-            av[2 * i] = a0;
-            av[2 * i + 1] = a1;
-          } else if constexpr (!C::kSplit) {
+          if constexpr (!C::kSplit) {
             a_lds[(2 * i) * 64] = a0;
             a_lds[(2 * i + 1) * 64] = a1;
           }
@@ -958,9 +870,7 @@ __device__ __forceinline__ void wave_body(
       {
         static_for<2 * ROWS>([&](auto ee) {
           constexpr int e = decltype(ee)::value;
-          if constexpr (kAInRegs) {
-            S.envelope(av[e], mu);
-          } else if constexpr (C::kSplit) {
+          if constexpr (C::kSplit) {
             S.envelope(__builtin_amdgcn_sqrtf(__builtin_fmaf(xr[e], xr[e], __builtin_fmaf(xi[e], xi[e], kTinyPower))), mu);
           } else {
             S.envelope(a_lds[e * 64], mu);
@@ -1001,10 +911,7 @@ __device__ __forceinline__ void wave_body(
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(AMCX_PRIO_OF(3));
       float peak;
-      if constexpr (C::kGroup > 1) {
-        fft_front<R, SLOT * R>(xr, xi, la);     // the group's shared back half follows the last frame
-        return;
-      } else if constexpr (!C::kSplit) {
+      if constexpr (!C::kSplit) {
         peak = fft_peak<R>(xr, xi, la);
       } else {
         // 4096 points in registers: radix-2 DIF split, s = y[n] + y[n+2048],
@@ -1120,7 +1027,6 @@ __device__ __forceinline__ void wave_body(
       return __builtin_amdgcn_ballot_w64(redo);
     };
 
-    using Slot0 = std::integral_constant<int, 0>;
     // frames `todo` (bit i: frame f0 + i) again, each multiplied by 2^-ex first (see the comment above wave_body)
     [[maybe_unused]] const LaneAddr& la_redo = la;
     auto rerun_scaled = [&](unsigned long long todo) {
@@ -1144,75 +1050,17 @@ __device__ __forceinline__ void wave_body(
             constexpr int e = decltype(ee)::value;
             xr[e] *= sc; xi[e] *= sc;
           });
-          if constexpr (C::kGroup > 1) lds_wave_fence();      // the previous exchange reads are done
-          frame(xr, xi, cnt, Slot0{});
-          if constexpr (C::kGroup > 1) {
-            // a group of ONE: the frame's pass-1 output sits in k1 slots [0, R); the shared back half runs over all
-            // eight slots (the others hold stale data) and lanes [0, 8 R) come out with this frame's bins
-            float pk = fft_back(la_redo);
-            pk = __builtin_fmaxf(pk, dpp<kQuadXor1>(pk));
-            pk = __builtin_fmaxf(pk, dpp<kQuadXor2>(pk));
-            pk = __builtin_fmaxf(pk, dpp<kRowHalfMirror>(pk));
-            if constexpr (R >= 2) pk = __builtin_fmaxf(pk, dpp<kRowMirror>(pk));
-            if constexpr (R >= 4) pk = __builtin_fmaxf(pk, dpp<kRowBcast15, 0xa, 0xf, false>(pk));
-            if (lane == 8 * R - 1) stash[cnt * kStashStride + kNumSums] = pk;
-          }
+          frame(xr, xi, cnt);
           if (lane == 63)
             stash[(cnt * C::kFlushes + (C::kFlushes - 1)) * kStashStride + kNumSums + 5] = (float)((ex + 128) * 64 + idx);
         }
         finalise(std::true_type{}, cnt);
       }
     };
-    if constexpr (C::kGroup > 1) {
-      // short frames, ping-pong prefetch as below, kGroup frames per run of FFT passes 2-3
-      constexpr int G = C::kGroup;
-      float ar[2 * ROWS], ai[2 * ROWS], br[2 * ROWS], bi[2 * ROWS];
-      load_frame(ar, ai, f0);
-      for (int g = 0; g < n_here; g += G) {
-        lds_wave_fence();                       // the previous group's exchange reads are done
-        static_for<G / 2>([&](auto jj) {
-          constexpr int j0 = 2 * decltype(jj)::value, j1 = j0 + 1;
-          if (g + j0 < n_here) {
-            if (g + j1 < n_here) load_frame(br, bi, f0 + g + j1);
-            frame(ar, ai, g + j0, std::integral_constant<int, j0>{});
-          }
-          if (g + j1 < n_here) {
-            if (g + j1 + 1 < n_here) load_frame(ar, ai, f0 + g + j1 + 1);
-            frame(br, bi, g + j1, std::integral_constant<int, j1>{});
-          }
-        });
-        // lanes [8 R j, 8 R (j+1)) hold frame j's bins (slots of frames that do not exist hold
-        // stale data and are not written back)
-        float pk = fft_back(la);
-        pk = __builtin_fmaxf(pk, dpp<kQuadXor1>(pk));
-        pk = __builtin_fmaxf(pk, dpp<kQuadXor2>(pk));
-        pk = __builtin_fmaxf(pk, dpp<kRowHalfMirror>(pk));
-        if constexpr (R >= 2) pk = __builtin_fmaxf(pk, dpp<kRowMirror>(pk));
-        if constexpr (R >= 4) pk = __builtin_fmaxf(pk, dpp<kRowBcast15, 0xa, 0xf, false>(pk));
-        const int j = lane / (8 * R);
-        if ((lane & (8 * R - 1)) == 8 * R - 1 && g + j < n_here)
-          stash[(g + j) * kStashStride + kNumSums] = pk;    // over the zero pad slot 27
-      }
-    } else if constexpr (C::kPrefetch) {
-      // short frames: the load latency at the head of every frame is a large share of the
-      // frame, and there are registers to spare -- ping-pong between two register sets, the
-      // next frame of the chunk in flight while this one is worked on
-      float ar[2 * ROWS], ai[2 * ROWS], br[2 * ROWS], bi[2 * ROWS];
-      load_frame(ar, ai, f0);
-      for (int g = 0; g < n_here; g += 2) {
-        if (g + 1 < n_here) load_frame(br, bi, f0 + g + 1);
-        frame(ar, ai, g, Slot0{});
-        if (g + 1 < n_here) {
-          if (g + 2 < n_here) load_frame(ar, ai, f0 + g + 2);
-          frame(br, bi, g + 1, Slot0{});
-        }
-      }
-    } else {
-      for (int g = 0; g < n_here; ++g) {
-        float xr[2 * ROWS], xi[2 * ROWS];
-        load_frame(xr, xi, f0 + g);
-        frame(xr, xi, g, Slot0{});
-      }
+    for (int g = 0; g < n_here; ++g) {
+      float xr[2 * ROWS], xi[2 * ROWS];
+      load_frame(xr, xi, f0 + g);
+      frame(xr, xi, g);
     }
 
     AMCX_STAMP(4);
@@ -1295,8 +1143,8 @@ inline hipError_t launch_wave(const float2* iq, int64_t n_frames, int32_t frame_
                               int64_t row_stride, float* out, int64_t out_stride,
                               hipStream_t stream, int cus) {
   switch (frame_size) {
-    // (128, 256 and 512 ran here until late in round 5 -- kGroup = 8 / 4 / 2 frames sharing one run of FFT passes 2-3 -- and
-    //  have a kernel of their own now, amcx_short_kernel.h: +34 % / +13 % / +2.5 ... 5 %; the template still takes those sizes)
+    // (128, 256 and 512 ran here until late in round 5 -- 8 / 4 / 2 frames sharing one run of FFT passes 2-3 -- and have a
+    //  kernel of their own now, amcx_short_kernel.h: +34 % / +13 % / +2.5 ... 5 %)
     case 1024: return launch_wave_n<1024>(iq, n_frames, row_stride, out, out_stride, stream, cus);
     case 2048: return launch_wave_n<2048>(iq, n_frames, row_stride, out, out_stride, stream, cus);
     case 4096: return launch_wave_n<4096>(iq, n_frames, row_stride, out, out_stride, stream, cus);
