@@ -722,7 +722,7 @@ def test_odd_row_stride_and_ragged_counts():
     torch = _torch()
     from amcpy_amd.features import features18
     rng = np.random.default_rng(11)
-    for N, F in ((128, 2111), (256, 1033), (1024, 1237), (2048, 611), (4096, 205), (8192, 77), (16384, 37), (32768, 19)):
+    for N, F in ((128, 2111), (256, 1033), (512, 779), (1024, 1237), (2048, 611), (4096, 205), (8192, 77), (16384, 37), (32768, 19)):
         L = N + 3                                             # odd stride: frames 8-byte aligned only
         x = (rng.standard_normal((F, L)) + 1j * rng.standard_normal((F, L))).astype(np.complex64)
         xd = torch.from_numpy(x).cuda()
