@@ -17,7 +17,7 @@
 //     a transpose through LDS so that lane (kj, a) holds y[kj][4 c + a], c < 8; pass 2 radix 8 over c in registers (twiddle
 //     W_32^(a kc)); a second transpose so that lane (kj, h) holds z[kj][kc = 2 h + e][a], a < 4; pass 3 radix 4 over a.
 //     All three passes are the wave kernel's compile-time dif<>; the four frames of a wave go through together;
-//   * after eight passes (32 frames) lanes 0-31 turn a stash row each into 18 features in fp64; frames with a phase step
+//   * after eight passes (32 frames; four passes at N = 256 / 512) lanes 0-31 turn a stash row each into 18 features in fp64; frames with a phase step
 //     within an angle rounding of +-pi get f5 / f9 from the exact fp64 sweep (wave_exact_frequency).
 // N = 256 is the same machine with eight rows per lane: pass 1 is a radix 8 over j, and a lane takes TWO of the eight
 // 32-point transforms of passes 2 and 3 (kj = l / 4 and l / 4 + 4), one after the other.  N = 512 has sixteen rows per lane:
