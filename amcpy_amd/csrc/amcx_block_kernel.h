@@ -184,6 +184,22 @@ __device__ __forceinline__ void block_frame(const float2* __restrict__ src, int 
     }
 
     FrameSums S;
+    // N <= 64 (kBlockDirect -- the size class of the reference's own known-answer vector, N = 10, features.py:240-255):
+    // envelope, angle and wrapped step in fp64 (atan2, IEEE sqrt and division), as the reference computes them
+    // (features.py:27-30).  A std or kurtosis over three or nine values shows every rounding of an fp32 angle (2e-7 rad):
+    // until round 6 these sizes were held to 2e-4 instead of 1e-5.  At most one sample per thread, so the cost is nil.
+    [[maybe_unused]] auto env_phase_d = [&](int n, double& a, double& th) {
+      const double re = xs[n].x, im = xs[n].y;
+      a = __builtin_sqrt(re * re + im * im);
+      th = atan2(im, re);
+    };
+    [[maybe_unused]] auto step_d = [&](int n) -> double {             // diff(unwrap(theta))[n]: d - 2 pi rint(d / 2 pi), half to even
+      double a0, t0, a1, t1;
+      env_phase_d(n, a0, t0);
+      env_phase_d(n + 1, a1, t1);
+      const double d = t1 - t0;
+      return d - kTwoPiD * __builtin_rint(d / kTwoPiD);
+    };
     // ---- pass A: mixed moments, envelope and phase first sums ------------
     {
       double m[15];
@@ -201,10 +217,16 @@ __device__ __forceinline__ void block_frame(const float2* __restrict__ src, int 
         m[6] += AP; m[7] += Bh * P;
         m[8] += AA * A; m[9] += A * BB; m[10] += AA * Bh; m[11] += BB * Bh;
         m[12] += AA * P; m[13] += X4 * P; m[14] += AP * Bh;
-        const float a = __builtin_amdgcn_sqrtf(__builtin_fmaf(x.x, x.x, __builtin_fmaf(x.y, x.y, kTinyPower)));
-        const float th = fast_angle(x.x, x.y, a);
-        at[n] = make_float2(a, th);
-        e[0] += a; e[1] += th; e[2] += __builtin_fabsf(th);
+        if constexpr (MODE == kBlockDirect) {
+          double a, th;
+          env_phase_d(n, a, th);
+          e[0] += a; e[1] += th; e[2] += __builtin_fabs(th);
+        } else {
+          const float a = __builtin_amdgcn_sqrtf(__builtin_fmaf(x.x, x.x, __builtin_fmaf(x.y, x.y, kTinyPower)));
+          const float th = fast_angle(x.x, x.y, a);
+          at[n] = make_float2(a, th);
+          e[0] += a; e[1] += th; e[2] += __builtin_fabsf(th);
+        }
       }
       block_sum(m, scratch);
       block_sum(e, scratch);   // the barrier inside also publishes `at`
@@ -218,14 +240,23 @@ __device__ __forceinline__ void block_frame(const float2* __restrict__ src, int 
       const double mu = S.sa / N;
       double c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       for (int n = tid; n < N; n += kBlockThreads) {
-        const float2 v = at[n];
-        const double d = (double)v.x - mu, d2 = d * d;
+        double va, vth;
+        if constexpr (MODE == kBlockDirect) {
+          env_phase_d(n, va, vth);
+        } else {
+          const float2 v = at[n];
+          va = v.x; vth = v.y;
+        }
+        const double d = va - mu, d2 = d * d;
         c[0] += __builtin_fabs(d); c[1] += d2; c[2] += d2 * d2;
-        const double dt = (double)v.y - S.Kt;
+        const double dt = vth - S.Kt;
         c[3] += dt; c[4] += dt * dt;
-        const double da = __builtin_fabs((double)v.y) - S.Ka;
+        const double da = __builtin_fabs(vth) - S.Ka;
         c[6] += da; c[7] += da * da;
-        if (n + 1 < N) c[5] += exact_step(at[n + 1].y, v.y, xs[n].x, xs[n].y, xs[n + 1].x, xs[n + 1].y);
+        if (n + 1 < N) {
+          if constexpr (MODE == kBlockDirect) c[5] += step_d(n);
+          else c[5] += exact_step(at[n + 1].y, (float)vth, xs[n].x, xs[n].y, xs[n + 1].x, xs[n + 1].y);
+        }
       }
       block_sum(c, scratch);
       S.sad1 = c[0]; S.sad2 = c[1]; S.sad4 = c[2]; S.std1 = c[3]; S.std2 = c[4];
@@ -236,8 +267,10 @@ __device__ __forceinline__ void block_frame(const float2* __restrict__ src, int 
     {
       double c[4] = {0, 0, 0, 0};
       for (int n = tid; n + 1 < N; n += kBlockThreads) {
-        const double d = (double)exact_step(at[n + 1].y, at[n].y, xs[n].x, xs[n].y, xs[n + 1].x, xs[n + 1].y) - S.Kw,
-                     d2 = d * d;
+        double w;
+        if constexpr (MODE == kBlockDirect) w = step_d(n);
+        else w = (double)exact_step(at[n + 1].y, at[n].y, xs[n].x, xs[n].y, xs[n + 1].x, xs[n + 1].y);
+        const double d = w - S.Kw, d2 = d * d;
         c[0] += d; c[1] += d2; c[2] += d2 * d; c[3] += d2 * d2;
       }
       block_sum(c, scratch);   // trailing barrier: `at` may now be overwritten

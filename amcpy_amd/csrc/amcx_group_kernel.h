@@ -184,7 +184,7 @@ __device__ __attribute__((noinline)) void group_finalise(const float2* __restric
                                                          unsigned* redo_mask, int lane) {
   constexpr int kN = G<W>::kN, kStashRow = G<W>::kStashRow;
   float feat[18];
-  bool tie = false, marked = false;
+  bool tie = false, marked = false, cancel = false;
   float kw0 = 0.f;
   if (lane < count) {
     const float* rows = stash + lane * W * kStashRow;
@@ -252,6 +252,9 @@ __device__ __attribute__((noinline)) void group_finalise(const float2* __restric
 #pragma unroll
           for (int j = 9; j < 18; ++j) feat[j] = 0.f;
         } else {
+          const float s15[15] = {(float)sA, (float)sBh, (float)sP, (float)sAA, (float)sX4, (float)sAB, (float)sAP, (float)sBP,
+                                 (float)sAAA, (float)sABB, (float)sAAB, (float)sBBB, (float)sAAP, (float)sX4P, (float)sABP};
+          cancel = cancellation_suspect(s15, (float)kN, (float)cancel_kappa(kN));       // fp32, on the summed values (amcx_math.h)
           moment_features(sA, sBh, sP, sAA, sX4, sAB, sAP, sBP, sAAA, sABB, sAAB, sBBB, sAAP, sX4P, sABP, n, put);
         }
       }
@@ -269,6 +272,7 @@ __device__ __attribute__((noinline)) void group_finalise(const float2* __restric
       }
     }
     tie = __builtin_signbitf(feat[4]) && feat[4] == feat[4] && !marked;
+    cancel = cancel && !marked;
   }
   unsigned long long ties = __builtin_amdgcn_ballot_w64(tie);
   const float sct = RG ? __builtin_bit_cast(float, (127 - ex_pow) << 23) : 1.0f;     // the 2^-ex the frame was multiplied by
@@ -285,6 +289,12 @@ __device__ __attribute__((noinline)) void group_finalise(const float2* __restric
 #pragma unroll
     for (int j = 0; j < 18; ++j) dst[j] = feat[j];
   }
+  unsigned long long cz = __builtin_amdgcn_ballot_w64(cancel);
+  while (cz != 0) {                                         // a cumulant that cancels below what fp32 sums resolve: ids 10-18 from fp64 sums, over the stored row
+    const int idx = __builtin_ctzll(cz);
+    cz &= cz - 1;
+    wave_exact_cumulants<kN>(iq + (f_first + idx) * row_stride, sct, RG ? ex_pow / 2 : 0, lane, lane == idx, out + (f_first + idx) * out_stride);
+  }
 }
 
 template <int W>
@@ -293,7 +303,7 @@ __global__ __launch_bounds__(64 * W, 1) void amcx_features18_group_kernel(
     float* __restrict__ out, long long out_stride) {
   using Cg = G<W>;
   constexpr int kN = Cg::kN, kBatch = Cg::kBatch, kThreads = Cg::kThreads, kRegionBytes = Cg::kRegionBytes;
-  constexpr int kStashRow = Cg::kStashRow, kStashFloats = Cg::kStashFloats;
+  constexpr int kStashRow = Cg::kStashRow;
   extern __shared__ float4 amcx_group_smem[];
   char* smem = reinterpret_cast<char*>(amcx_group_smem);
   const int tid = threadIdx.x;

@@ -153,6 +153,76 @@ __device__ __forceinline__ double q_sqrt(double x) { return __builtin_amdgcn_sqr
 __device__ __forceinline__ double q_div(double a, double b) { return a * __builtin_amdgcn_rcp(b); }
 constexpr double kInvTwoPiD = 1.0 / 6.283185307179586476925286766559;
 
+// ---------------------------------------------------------------------------
+// CANCELLATION.  The cumulants |C40|, |C41|, |C60|, |C61|, |C62| (ids 12, 13, 15, 16, 17) are sums of terms that can cancel
+// to any degree: over thousands of noise-like frames a few have a whole sixth-order moment 1000x below the size of its
+// summands, by chance.  The throughput kernels' fp32 sums are good to a few 1e-9 of the SUMMANDS' scale (measured tail
+// over 135 000 cancelled cumulants at N = 2048: 99 % below 1.4e-8, 99.9 % below 2.2e-8, largest 5.2e-8 --
+// tests/manual/cancel_study.py, profiles/r6_cancel_study_*.txt), not of such a sum; the parity contract is 1e-5 of
+// S = sum |terms| (the reference evaluates in complex128, features.py:144-185).  So the finaliser asks,
+// per frame, whether any of the five has  S < kappa E,  E the first-order error scale of that cumulant (every moment's
+// absolute error taken as one unit of the mean of its summands' magnitudes: m21, m42, m63), and a frame that does gets
+// its 15 moment sums again from an fp64 sweep by the whole wave, in the same launch (wave_exact_moments,
+// amcx_wave_kernel.h) -- the mechanism the +-pi ties already use for f5 / f9.  Ids 10, 11, 14, 18 cannot cancel below
+// ~1/7 of their E (m21, m42 + 2 m21^2, m63 + 9 m21 m42 + 12 m21^3 are sums of non-negatives).
+// kappa = 4e-3 (2048 / N)^(1/3): the measured tail shrinks slowly with the frame size while the share of frames below a
+// fixed kappa grows like N; at this kappa 0.3 ... 0.6 % of the BASELINE configs' frames are flagged (1.0 % at N = 4096),
+// and the chance that an UNFLAGGED frame misses 1e-5 S, extrapolating the measured tail, is ~1e-8 per frame.
+// The predicate is conservative: the leading moment enters exactly (as a square), the other complex moments through
+// max(|re|, |im|) <= |z| <= |re| + |im| (|m40|: the octagon, within 8 %) -- S from below, E from above.  NaN / inf moments compare false: those frames have
+// their own paths.
+// ---------------------------------------------------------------------------
+constexpr double cancel_kappa(int N) {
+  double k = 4.0e-3;
+  for (int n = N; n < 2048; n *= 2) k *= 1.2599210498948732;
+  for (int n = N; n > 2048; n /= 2) k /= 1.2599210498948732;
+  return k;
+}
+
+// Evaluated in fp32 on the 15 reduced sums as they lie in the stash (sA, sBh, sP, sAA, sX4, sAB, sAP, sBP, sAAA, sABB, sAAB,
+// sBBB, sAAP, sX4P, sABP), in units of the frame's mean power (m21 = 1: m20 / m21 = sA / sP, m4x / m21^2 = n s / sP^2,
+// m6x / m21^3 = n^2 s / sP^3 -- nothing overflows anywhere in the range the fp32 sums are trusted in), ahead of the fp64
+// algebra and independent of it: ~85 fp32 instructions per finaliser batch and a dozen registers (as part of
+// finalize_features, in fp64, the 128-register wave kernels spilled five doubles per batch).
+__device__ __forceinline__ bool cancellation_suspect(const float (&s)[15], float n, float kappa) {
+  const float c2 = __builtin_amdgcn_rcpf(s[2]);
+  const float c4 = n * c2 * c2, c6 = c4 * (n * c2);
+  const float b20r = s[0] * c2, b20i = 2.0f * s[1] * c2;
+  const float n20 = __builtin_fmaf(b20r, b20r, b20i * b20i), a20 = __builtin_amdgcn_sqrtf(n20);
+  const float b40r = s[4] * c4, b40i = 4.0f * s[5] * c4, b41r = s[6] * c4, b41i = 2.0f * s[7] * c4;
+  const float b42 = __builtin_fmaf(2.0f, s[3], -s[4]) * c4;
+  const float b60r = __builtin_fmaf(-12.0f, s[9], s[8]) * c6, b60i = __builtin_fmaf(6.0f, s[10], -8.0f * s[11]) * c6;
+  const float b61r = s[13] * c6, b61i = 4.0f * s[14] * c6;
+  const float b62 = __builtin_fmaf(4.0f, s[9], s[8]) * c6, b63 = __builtin_fmaf(2.0f, s[12], -s[13]) * c6;
+  // |m40| sits in three of the five tests: the octagon max(max(|re|, |im|), (|re| + |im|) / sqrt 2) <= |z| <= 1.0824 x that
+  const float s40 = __builtin_fabsf(b40r) + __builtin_fabsf(b40i);
+  const float a40l = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(b40r), __builtin_fabsf(b40i)), 0.70710678f * s40), a40h = 1.0823922f * a40l;
+  const float a41l = __builtin_fmaxf(__builtin_fabsf(b41r), __builtin_fabsf(b41i)), a41h = __builtin_fabsf(b41r) + __builtin_fabsf(b41i);
+  const float g = a20 * b42, u = a20 * a40l, c3 = a20 * n20, v = a20 * a41l;
+  // id 12: m40 - 3 m20^2                       S >= |m40| + 3 |m20|^2,  E = m42 + 6 |m20| m21
+  const float t12 = __builtin_fmaf(kappa, __builtin_fmaf(6.0f, a20, b42), -3.0f * n20);
+  // id 13: m41 - 3 m20 m21                     E = m42 + 3 m21^2 + 3 |m20| m21
+  const float t13 = __builtin_fmaf(kappa, __builtin_fmaf(3.0f, a20, b42 + 3.0f), -3.0f * a20);
+  // id 15: m60 - 15 m20 m40 + 3 m20^3          E = m63 + 15 (|m20| m42 + |m40| m21) + 9 |m20|^2 m21
+  const float e15 = __builtin_fmaf(9.0f, n20, __builtin_fmaf(15.0f, g + a40h, b63));
+  const float t15 = __builtin_fmaf(kappa, e15, __builtin_fmaf(-15.0f, u, -3.0f * c3));
+  // id 16: m61 - 5 m21 m40 - 10 m20 m41 + 30 m20^2 m21
+  //        E = m63 + 5 (m21 m42 + |m40| m21) + 10 (|m20| m42 + |m41| m21) + 30 (2 |m20| m21^2 + |m20|^2 m21)
+  const float e16 = __builtin_fmaf(60.0f, a20, __builtin_fmaf(30.0f, n20, __builtin_fmaf(10.0f, g + a41h, __builtin_fmaf(5.0f, b42 + a40h, b63))));
+  const float t16 = __builtin_fmaf(kappa, e16, __builtin_fmaf(-5.0f, a40l, __builtin_fmaf(-10.0f, v, -30.0f * n20)));
+  // id 17: m62 - 6 m20 m42 - 8 m21 m41 - m22 m40 + 6 m20^2 m22 + 24 m21^2 m20
+  //        E = m63 + 6 (|m20| m42 + m42 m21) + 8 (m21 m42 + |m41| m21) + (|m20| m42 + |m40| m21) + 18 |m20|^2 m21 + 24 (2 m21^2 |m20| + m21^3)
+  const float e17 = __builtin_fmaf(48.0f, a20, __builtin_fmaf(18.0f, n20, __builtin_fmaf(8.0f, a41h, __builtin_fmaf(7.0f, g,
+                    __builtin_fmaf(14.0f, b42, b63 + a40h + 24.0f)))));
+  const float t17 = __builtin_fmaf(kappa, e17, __builtin_fmaf(-6.0f, g + c3, __builtin_fmaf(-8.0f, a41l, __builtin_fmaf(-24.0f, a20, -u))));
+  bool f = t12 > 0.f && __builtin_fmaf(b40r, b40r, b40i * b40i) < t12 * t12;
+  f |= t13 > 0.f && __builtin_fmaf(b41r, b41r, b41i * b41i) < t13 * t13;
+  f |= t15 > 0.f && __builtin_fmaf(b60r, b60r, b60i * b60i) < t15 * t15;
+  f |= t16 > 0.f && __builtin_fmaf(b61r, b61r, b61i * b61i) < t16 * t16;
+  f |= __builtin_fabsf(b62) < t17;
+  return f;
+}
+
 // f5 = std1(phi), f9 = kurt(phi) of phi = w / 2pi from sums of d = w - Kw over the N-1 steps
 __device__ inline void frequency_features(double Kw, double swd1, double swd2, double swd3, double swd4,
                                           int N, float& f5, float& f9) {
@@ -177,8 +247,9 @@ __device__ inline void frequency_features(double Kw, double swd1, double swd2, d
 // feature j of the frame itself is the scaled one times 2^(ex * order_j) with order = 2, 0, 0, 0, 0, 1, 1/2, 0, 0, 2, 2,
 // 4, 4, 4, 6, 6, 6, 6 -- applied in fp64 before the float32 store, so that store overflows / underflows exactly where the
 // reference's does (feature_extraction.py:35,56).
+// Returns whether the frame is an ordinary one (false: a non-finite sample, or all zeros -- no cumulant to refine).
 template <bool SCALED = false>
-__device__ inline void finalize_features(const FrameSums& s, int N, float* __restrict__ out, int ex = 0) {
+__device__ inline bool finalize_features(const FrameSums& s, int N, float* __restrict__ out, int ex = 0) {
   [[maybe_unused]] const int h = ex / 2;                 // ex is even: 2^(h * twice_order) is exact
   auto put = [&](int j, int twice_order, double v) {
     if constexpr (SCALED) v = __builtin_ldexp(v, h * twice_order);
@@ -191,7 +262,7 @@ __device__ inline void finalize_features(const FrameSums& s, int N, float* __res
   if (!(__builtin_fabs(s.sP) <= 1.79e308) || !(s.gmax_raw == s.gmax_raw)) {
 #pragma unroll
     for (int j = 0; j < 18; ++j) out[j] = __builtin_nanf("");
-    return;
+    return false;
   }
   // ---- f1: gamma_max
   put(0, 4, s.gmax_raw * inv);
@@ -233,7 +304,7 @@ __device__ inline void finalize_features(const FrameSums& s, int N, float* __res
   if (zero_frame) {   // the guard's kTinyPower must not leak into |C20| ... |C63| of a zero frame
 #pragma unroll
     for (int j = 9; j < 18; ++j) out[j] = 0.f;
-    return;
+    return false;
   }
   const double m20r = s.sA * inv, m20i = 2.0 * s.sBh * inv;
   const double m21 = s.sP * inv;
@@ -281,6 +352,7 @@ __device__ inline void finalize_features(const FrameSums& s, int N, float* __res
     put(17, 12, __builtin_fabs(m63 - 9.0 * m21 * m42 + 12.0 * m21 * m21 * m21 -
                                3.0 * cross + 18.0 * m21 * n20));
   }
+  return true;
 }
 
 // finalize_features in PIECES, each from the sums it needs alone, for a caller whose sums come from several places

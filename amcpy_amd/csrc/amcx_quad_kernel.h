@@ -252,7 +252,7 @@ __global__ __launch_bounds__(kThreads, 2) void amcx_features18_quad_kernel(
   auto finalise = [&](auto range_tag, long long f_first, int count, const float* stash, int ex) {
     constexpr bool RG = decltype(range_tag)::value;
     float feat[18];
-    bool tie = false, marked = false;
+    bool tie = false, marked = false, cancel = false;
     float kw0 = 0.f;
     if (lane < count) {
       const float* rows = stash + lane * kWavesPerQuad * kStashRow;
@@ -284,13 +284,19 @@ __global__ __launch_bounds__(kThreads, 2) void amcx_features18_quad_kernel(
       F.swd1 = ws.s1; F.swd2 = ws.s2; F.swd3 = ws.s3; F.swd4 = ws.s4;
       F.gmax_raw = pk;
       F.pi_tie = flagged;
+      {                                                     // fp32, on the summed values (amcx_math.h)
+        const float s15[15] = {(float)F.sA, (float)F.sBh, (float)F.sP, (float)F.sAA, (float)F.sX4, (float)F.sAB, (float)F.sAP, (float)F.sBP,
+                               (float)F.sAAA, (float)F.sABB, (float)F.sAAB, (float)F.sBBB, (float)F.sAAP, (float)F.sX4P, (float)F.sABP};
+        cancel = cancellation_suspect(s15, (float)kN, (float)cancel_kappa(kN));
+      }
       if constexpr (RG) {
-        finalize_features<true>(F, kN, feat, ex);
+        cancel = finalize_features<true>(F, kN, feat, ex) && cancel;
       } else {
-        finalize_features(F, kN, feat);
+        cancel = finalize_features(F, kN, feat) && cancel;
         // outside the fp32 sums' range: noted in the workgroup's re-run mask (below) and run again by the whole quad
         // in the pass at the end of this kernel, which overwrites the row -- the row is final when the launch is
         marked = is_outside_fp32_range(F, kN);
+        cancel = cancel && !marked;
       }
       tie = !marked && __builtin_signbitf(feat[4]) && feat[4] == feat[4] && feat[4] != -__builtin_inff();
     }
@@ -316,6 +322,12 @@ __global__ __launch_bounds__(kThreads, 2) void amcx_features18_quad_kernel(
       float* dst = out + (f_first + lane) * out_stride;
 #pragma unroll
       for (int j = 0; j < 18; ++j) dst[j] = feat[j];
+    }
+    unsigned long long cz = __builtin_amdgcn_ballot_w64(cancel);
+    while (cz != 0) {                                       // a cumulant that cancels below what fp32 sums resolve: ids 10-18 from fp64 sums, over the stored row
+      const int idx = __builtin_ctzll(cz);
+      cz &= cz - 1;
+      wave_exact_cumulants<kN>(iq + (f_first + idx) * row_stride, sct, RG ? ex / 2 : 0, lane, lane == idx, out + (f_first + idx) * out_stride);
     }
   };
 

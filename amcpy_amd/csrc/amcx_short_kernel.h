@@ -167,9 +167,16 @@ __global__ __launch_bounds__(SCfg<N>::kThreads, SCfg<N>::kWavesPerWG / 4) void a
     lds_wave_fence();
     float feat[18];
     float sc = 1.0f, kw_shift = 0.f;
-    bool tie = false;
+    int ex_half = 0;
+    bool tie = false, cancel = false;
     if (lane < count) {
       const float* row = stash + lane * kRow;
+      {                                                       // fp32, on the stash values, ahead of the fp64 algebra (amcx_math.h)
+        float s15[15];
+#pragma unroll
+        for (int k = 0; k < 15; ++k) s15[k] = row[k];
+        cancel = cancellation_suspect(s15, (float)kN, (float)cancel_kappa(kN));
+      }
       FrameSums F;
       F.sA = row[0]; F.sBh = row[1]; F.sP = row[2]; F.sAA = row[3]; F.sX4 = row[4]; F.sAB = row[5];
       F.sAP = row[6]; F.sBP = row[7]; F.sAAA = row[8]; F.sABB = row[9]; F.sAAB = row[10];
@@ -181,8 +188,9 @@ __global__ __launch_bounds__(SCfg<N>::kThreads, SCfg<N>::kWavesPerWG / 4) void a
       F.pi_tie = row[31] != 0.0f;
       kw_shift = row[29];
       const int ex_f = (int)row[32];
-      finalize_features<true>(F, kN, feat, ex_f);
+      cancel = finalize_features<true>(F, kN, feat, ex_f) && cancel;
       sc = __builtin_bit_cast(float, (127 - ex_f) << 23);     // the 2^-ex the frame was multiplied by
+      ex_half = ex_f / 2;
       // flagged by the sweep (f5 came back negated) and not NaN
       tie = __builtin_signbitf(feat[4]) && feat[4] == feat[4] && feat[4] != -__builtin_inff();
     }
@@ -200,6 +208,14 @@ __global__ __launch_bounds__(SCfg<N>::kThreads, SCfg<N>::kWavesPerWG / 4) void a
       float* dst = out + (f0 + lane) * out_stride;
 #pragma unroll
       for (int j = 0; j < 18; ++j) dst[j] = feat[j];
+    }
+    unsigned long long cz = __builtin_amdgcn_ballot_w64(cancel);
+    while (cz != 0) {                                         // a cumulant that cancels below what fp32 sums resolve: ids 10-18 from fp64 sums, over the stored row
+      const int idx = __builtin_ctzll(cz);
+      cz &= cz - 1;
+      const float sct = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc), idx));
+      const int hx = __builtin_amdgcn_readlane(ex_half, idx);
+      wave_exact_cumulants<kN>(iq + (f0 + idx) * row_stride, sct, hx, lane, lane == idx, out + (f0 + idx) * out_stride);
     }
     lds_wave_fence();
   };

@@ -116,6 +116,8 @@ struct Cfg {
   static constexpr int kStashBytes = kFramesPerWave * kFlushes * kStashStride * 4;
   // frames per grab over the last stretch of a workgroup's slice (levels the waves' finish)
   static constexpr int kTailChunk = 2;
+  // frames per interleaved run of a workgroup (wave_body: work distribution)
+  static constexpr int kRunFrames = kFramesPerWave;
   // waves per workgroup = waves per CU: 2 per SIMD when the frame alone takes 128 VGPRs (N = 4096),
   // 4 per SIMD at N = 2048 and N = 1024: the kernels fit 128 VGPRs there (2048: three spilled
   // dwords, 1024: none -- kernel_resources.json).  N = 2048: the fourth wave hides 4.3 % of the SIMD's cycles, +0.5 %
@@ -649,6 +651,91 @@ __device__ __forceinline__ void wave_exact_frequency(const float2* __restrict__ 
   frequency_features(Kw, wave_sum_f64(c0), wave_sum_f64(c1), wave_sum_f64(c2), wave_sum_f64(c3), N, f5, f9);
 }
 
+// The 15 mixed-moment sums of ONE frame in fp64, by the whole wave: the slow path behind the finaliser's cancellation flag
+// (cancellation_suspect, amcx_math.h) -- ~0.5 % of frames.  Same shape as wave_exact_frequency: the frame re-read from
+// memory (L2 / Infinity Cache), lane l takes samples l, l + 64, ..., eight loads in flight per trip; every product and
+// sum in fp64, so what is left is the rounding of the complex64 samples themselves -- the reference's complex128
+// evaluation of the same samples (features.py:46-58) to ~1e-16 of the summands' scale.  t: sA, sBh, sP, sAA, sX4, sAB,
+// sAP, sBP, sAAA, sABB, sAAB, sBBB, sAAP, sX4P, sABP (FrameSums' order), the totals in every lane.  sc: the power of two
+// a re-run multiplies the frame by (1 in the throughput pass).
+template <int N>
+__device__ __forceinline__ void wave_exact_moments(const float2* __restrict__ src, float sc, int lane, double (&t)[15]) {
+  // lane l takes the sample pairs (2 l, 2 l + 1) + 128 j, one global_load_dwordx4 each, kG of them per trip of a ROLLED
+  // loop, the next trip's requested before this one's are used.  Compact on purpose: this code runs for one frame in
+  // ~150, cold every time -- what it costs is its instruction-cache misses and the round trips of the re-read, not its
+  // ~26 fp64 instructions per sample.
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  typedef const __attribute__((address_space(1))) v4f* gv4f;   // (a function argument: without this the loads are flat_load)
+  constexpr int kAll = N / 128, kWant = N >= 4096 ? 8 : 4, kG = kAll < kWant ? kAll : kWant, kTrips = kAll / kG;
+  static_assert(kAll >= 1 && kAll % kG == 0, "frame sizes are powers of two >= 128");
+  gv4f const base = (gv4f)reinterpret_cast<const v4f*>(src + 2 * lane);
+  double a[15];
+#pragma unroll
+  for (int k = 0; k < 15; ++k) a[k] = 0.0;
+  v4f nxt[kG];
+#pragma unroll
+  for (int u = 0; u < kG; ++u) nxt[u] = base[64 * u];
+#pragma unroll 1
+  for (int tr = 0; tr < kTrips; ++tr) {
+    v4f p[kG];
+#pragma unroll
+    for (int u = 0; u < kG; ++u) p[u] = nxt[u];
+    if (tr + 1 < kTrips) {
+#pragma unroll
+      for (int u = 0; u < kG; ++u) nxt[u] = base[64 * (kG * (tr + 1) + u)];
+    }
+#pragma unroll
+    for (int u = 0; u < 2 * kG; ++u) {
+      const double re = (double)(((u & 1) ? p[u >> 1].z : p[u >> 1].x) * sc), im = (double)(((u & 1) ? p[u >> 1].w : p[u >> 1].y) * sc);
+      const double im2 = im * im;
+      const double A = __builtin_fma(re, re, -im2), P = __builtin_fma(re, re, im2), Bh = re * im;
+      const double AA = A * A, BB = Bh * Bh, AP = A * P;
+      const double X4 = __builtin_fma(-4.0, BB, AA);
+      a[0] += A; a[1] += Bh; a[2] += P; a[3] += AA; a[4] += X4;
+      a[5] = __builtin_fma(A, Bh, a[5]);
+      a[6] += AP;
+      a[7] = __builtin_fma(Bh, P, a[7]);
+      a[8] = __builtin_fma(AA, A, a[8]);
+      a[9] = __builtin_fma(A, BB, a[9]);
+      a[10] = __builtin_fma(AA, Bh, a[10]);
+      a[11] = __builtin_fma(BB, Bh, a[11]);
+      a[12] = __builtin_fma(AA, P, a[12]);
+      a[13] = __builtin_fma(X4, P, a[13]);
+      a[14] = __builtin_fma(AP, Bh, a[14]);
+      if (u & 1) __builtin_amdgcn_sched_barrier(0);       // (or the scheduler converts every sample of the trip to fp64 first)
+    }
+  }
+#pragma unroll 1
+  for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+    for (int k = 0; k < 15; ++k) a[k] += __shfl_xor(a[k], off, 64);
+  }
+#pragma unroll
+  for (int k = 0; k < 15; ++k) t[k] = a[k];
+}
+
+// ... and |C20| ... |C63| (features 10-18) of that frame from them, stored by the lane with `mine` set over columns 9-17 of
+// the frame's row, which the same lane has stored before (one thread, one address: program order) -- what every throughput
+// kernel's finaliser does with a frame it flagged.  h: half the exponent of the power of two the frame was multiplied by
+// (finalize_features<SCALED>: feature j of the frame itself is the scaled one times 2^(h * twice_order_j)); 0 where the
+// frame was not scaled.
+// What this path costs (N = 2048, same box, tools/cancel_cost.py, profiles/r6_cancel_cost.txt): the predicate +0.4 %; the code
+// merely being there +0.1 % in this form -- a ROLLED loop, ~3 KB -- but +1.0 % with the sweep unrolled over sixteen
+// samples per trip and +1.3 % as a noinline function (no frame was flagged in those runs: the hot loop's instructions were
+// the same, their layout and registers were not); a flagged frame itself 0.6 frame times.  The rest of what flagged frames
+// cost was IMBALANCE between workgroups (one contiguous slice = one (modulation, SNR) cell: 5 % of noiseless QPSK
+// frames are flagged, none of BPSK's), gone with the interleaved runs of wave_body.
+template <int N>
+__device__ __forceinline__ void wave_exact_cumulants(const float2* __restrict__ src, float sc, int h, int lane, bool mine,
+                                                     float* __restrict__ dst_row) {
+  double t[15];
+  wave_exact_moments<N>(src, sc, lane, t);
+  if (mine) {
+    moment_features(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9], t[10], t[11], t[12], t[13], t[14], (double)N,
+                    [&](int j, int twice_order, double v) { dst_row[j] = (float)__builtin_ldexp(v, h * twice_order); });
+  }
+}
+
 // ---------------------------------------------------------------------------
 // The throughput kernel.  Frames OUTSIDE the fp32 sums' range (mean power outside [1e-10, 1e10], or a sum that is not
 // finite: is_outside_fp32_range) are found by the finaliser and re-run by the same wave right behind its batch, in this
@@ -682,21 +769,33 @@ __device__ __forceinline__ void wave_body(
                  wave * (kFramesPerWave * C::kFlushes * kStashStride);
 
   // ---- work distribution ------------------------------------------------------
-  // Each workgroup owns a contiguous slice of frames; its waves take chunks of it
-  // from an LDS counter instead of a fixed share.  With a fixed share the oldest wave
+  // The frames are cut into runs of kRunFrames; workgroup w owns runs w, w + G, w + 2 G, ... (G workgroups) and its
+  // waves take chunks of kFramesPerWave of them from an LDS counter instead of a fixed share.  With a fixed share the oldest wave
   // of each SIMD (VALU issue is arbitrated by age) finished in 52 % of the kernel's
   // time and the youngest set its length, the SIMD idling with one wave left
   // (tools/wave_stamps.hip: lifetimes 1.22 / 1.77 / 2.36 ms min / mean / max).  The
-  // last kTailFrames frames go out in chunks of kTailChunk to level the finish.
+  // last kTailFrames frames of a workgroup go out in chunks of kTailChunk to level the finish.
+  // INTERLEAVED chunks, not one contiguous slice per workgroup (rounds 1-5): what a frame costs depends on its data where
+  // a slow path is taken -- the exact f5 / f9 of +-pi ties, the fp64 moment sums of cancelling cumulants: 5 % of
+  // noiseless QPSK frames, none of BPSK's -- and a container holds its frames sorted by modulation and SNR, so a
+  // contiguous slice is one (modulation, SNR) cell and the launch lasted as long as its unluckiest cell.
+  // `v` below is an index into the workgroup's own frames in the order it takes them: frame = ((v / Q) G + w) Q + v % Q.
   unsigned* const counters = reinterpret_cast<unsigned*>(smem + C::kCounterOffset);
   if (tid == 0) { counters[0] = 0; counters[1] = 0; }
-  const long long per_wg = (n_frames + gridDim.x - 1) / gridDim.x;
-  const long long slice0 = (long long)blockIdx.x * per_wg;
-  long long slice1 = slice0 + per_wg;
-  if (slice1 > n_frames) slice1 = n_frames;
-  const long long slice_len = slice1 > slice0 ? slice1 - slice0 : 0;
-  const long long tail_len = slice_len < kTailFrames ? slice_len : kTailFrames;
-  const long long body_len = slice_len - tail_len;          // grabbed kFramesPerWave at a time
+  constexpr int kQ = C::kRunFrames;                        // frames per interleaved run
+  static_assert(kQ % kFramesPerWave == 0 && kFramesPerWave % kTailChunk == 0, "grabs stay inside a run");
+  const long long n_wg = gridDim.x, wg = blockIdx.x;
+  const long long full_runs = n_frames / kQ;
+  const int rem_frames = (int)(n_frames - full_runs * kQ);                     // the last, short run: index full_runs
+  const long long my_full = full_runs > wg ? (full_runs - wg - 1) / n_wg + 1 : 0;
+  const long long slice_len = my_full * kQ + (rem_frames > 0 && full_runs % n_wg == wg ? rem_frames : 0);
+  // whole chunks in the body, so that a tail grab never straddles two runs
+  const long long body_len = slice_len > kTailFrames ? (slice_len - kTailFrames) / kFramesPerWave * kFramesPerWave : 0;
+  const long long tail_len = slice_len - body_len;
+  auto frame_of = [&](long long v) -> long long {
+    const long long k = v / kQ;
+    return (k * n_wg + wg) * kQ + (v - k * kQ);
+  };
 
   // ---- twiddle tables, once per workgroup -----------------------------------
   build_fft_tables<C::kFftN>(t2, t3, tid, kThreads);
@@ -735,7 +834,7 @@ __device__ __forceinline__ void wave_body(
                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
       got = __builtin_amdgcn_readfirstlane(got);
       if ((long long)got < body_len) {
-        f0 = slice0 + got;
+        f0 = frame_of(got);
         const long long left = body_len - got;
         n_here = left < kFramesPerWave ? (int)left : kFramesPerWave;
       } else {
@@ -744,7 +843,7 @@ __device__ __forceinline__ void wave_body(
                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
         t = __builtin_amdgcn_readfirstlane(t);
         if ((long long)t >= tail_len) break;
-        f0 = slice0 + body_len + t;
+        f0 = frame_of(body_len + t);
         const long long left = tail_len - t;
         n_here = left < kTailChunk ? (int)left : kTailChunk;
       }
@@ -967,8 +1066,9 @@ __device__ __forceinline__ void wave_body(
       float feat[18];
       long long f = 0;
       [[maybe_unused]] float sc = 1.0f;
+      [[maybe_unused]] int ex_half = 0;
       float kw_shift = 0.f;
-      bool tie = false;
+      bool tie = false, cancel = false;
       if (lane < count) {
         const float* row = stash + (lane * C::kFlushes + (C::kFlushes - 1)) * kStashStride;   // the frame's last row
         auto sm = [&](int k) -> double {           // sum k of the frame: its stash rows added in fp64
@@ -979,6 +1079,18 @@ __device__ __forceinline__ void wave_body(
           }
           return t;
         };
+        {                                          // fp32, on the stash values, ahead of the fp64 algebra (amcx_math.h)
+          float s15[15];
+#pragma unroll
+          for (int k = 0; k < 15; ++k) {
+            s15[k] = row[k];
+            if constexpr (C::kFlushes > 1) {
+#pragma unroll
+              for (int h = 1; h < C::kFlushes; ++h) s15[k] += row[k - h * kStashStride];
+            }
+          }
+          cancel = cancellation_suspect(s15, (float)N, (float)cancel_kappa(N));
+        }
         FrameSums F;
         F.sA = sm(0); F.sBh = sm(1); F.sP = sm(2); F.sAA = sm(3); F.sX4 = sm(4); F.sAB = sm(5);
         F.sAP = sm(6); F.sBP = sm(7); F.sAAA = sm(8); F.sABB = sm(9); F.sAAB = sm(10);
@@ -992,14 +1104,16 @@ __device__ __forceinline__ void wave_body(
         if constexpr (RG) {
           const int code = (int)row[kNumSums + 5];              // (ex + 128) * 64 + index within the block
           const int ex = (code >> 6) - 128;
-          finalize_features<true>(F, N, feat, ex);
+          cancel = finalize_features<true>(F, N, feat, ex) && cancel;
           sc = __builtin_bit_cast(float, (127 - ex) << 23);     // the 2^-ex the frame was multiplied by
+          ex_half = ex / 2;
           f = f0 + (code & 63);
         } else {
-          finalize_features(F, N, feat);
+          cancel = finalize_features(F, N, feat) && cancel;
           if (is_outside_fp32_range(F, N)) redo = true;         // re-run below, in this kernel; the row is not stored
           f = f0 + lane;
         }
+        cancel = cancel && !redo;
         // flagged by the sweep (f5 came back negated) and neither NaN nor on its way to a re-run
         tie = __builtin_signbitf(feat[4]) && feat[4] == feat[4] && feat[4] != -__builtin_inff() && !redo;
       }
@@ -1022,6 +1136,23 @@ __device__ __forceinline__ void wave_body(
         float* dst = out + f * out_stride;
 #pragma unroll
         for (int j = 0; j < 18; ++j) dst[j] = feat[j];
+      }
+      // frames one of whose cumulants cancels below what fp32 sums resolve (cancellation_suspect): ids 10-18 again from
+      // fp64 sums, the wave on one frame at a time, over the row stored above
+      unsigned long long cz = __builtin_amdgcn_ballot_w64(cancel);
+      while (cz != 0) {
+        const int idx = __builtin_ctzll(cz);
+        cz &= cz - 1;
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(f & 0xffffffffLL), idx);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)f >> 32), idx);
+        const long long ft = (long long)(((unsigned long long)hi << 32) | lo);
+        float sct = 1.0f;
+        int hx = 0;
+        if constexpr (RG) {
+          sct = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc), idx));
+          hx = __builtin_amdgcn_readlane(ex_half, idx);
+        }
+        wave_exact_cumulants<N>(iq + ft * row_stride, sct, hx, lane, lane == idx, out + ft * out_stride);
       }
       lds_wave_fence();
       return __builtin_amdgcn_ballot_w64(redo);

@@ -1577,7 +1577,7 @@ def test_kernel_resources_match_the_committed_table():
     assert got["amcx_features18_wave_kernel<2048>"]["vgpr"] <= 128            # 4 waves per SIMD
     assert got["amcx_features18_wave_kernel<1024>"]["vgpr"] <= 168            # 3 waves per SIMD
     assert got["amcx_features18_wave_kernel<4096>"]["vgpr"] <= 256            # 2 waves per SIMD
-    assert got["amcx_features18_wave_kernel<2048>"]["scratch"] <= 16          # one fp64 value in the per-batch finaliser
+    assert got["amcx_features18_wave_kernel<2048>"]["scratch"] <= 24          # three lane-dependent dwords + one fp64 value in the per-batch finaliser
     # N = 32768: sixteen waves per frame = 4 per SIMD: 128 registers, and next to nothing spilled in the frame loop (a
     # spilled register is a 256-byte transaction per wave that reaches HBM: the first version moved 4x the frame's bytes)
     assert got["group::amcx_features18_group_kernel<16>"]["vgpr"] <= 128 and got["group::amcx_features18_group_kernel<16>"]["spill"] <= 16
