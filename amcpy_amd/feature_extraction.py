@@ -58,7 +58,15 @@ import numpy as np
 
 from . import _lib
 from .config import Config
-from .sharding import gather_frame_columns, gather_rows, shard_by_frames, shard_range, sharded_features
+from .sharding import collectives_forced, gather_frame_columns, gather_rows, shard_by_frames, shard_range, sharded_features
+
+
+def _process_group_up() -> bool:
+    try:
+        import torch.distributed as dist
+        return _lib.torch_wanted() and dist.is_available() and dist.is_initialized()
+    except Exception:
+        return False
 
 
 def _rank_world():
@@ -931,7 +939,7 @@ def run_extraction(cfg: Config, *, compute=None, device: Optional[int] = None, d
     published: List[Path] = []          # rank 0: shared files not yet removed
     feed = None
     try:
-        if world == 1:
+        if world == 1 and not (collectives_forced() and _process_group_up()):
             from .matfile import BufferPool, compressed_variable_bytes
             # A compressed container is inflate-bound: three reader threads run ahead (zlib releases the GIL).  An
             # uncompressed variable is only LOCATED here: the native engine's staging threads read it from the file

@@ -17,6 +17,15 @@ from typing import Callable, Optional, Tuple
 import numpy as np
 
 
+def collectives_forced() -> bool:
+    """TEST SWITCH (AMCX_TEST_FORCE_COLLECTIVES=1): take the multi-rank code -- status words, the padded tensor gather,
+    the all-gather -- even with a process group of ONE rank, instead of the world == 1 shortcuts.  One GPU is all a test
+    box has; with this the branch that the first 8-GPU run will execute (device tensors over RCCL) has executed before:
+    tests/test_gpu_parity.py::test_one_rank_nccl_takes_the_collective_path."""
+    import os
+    return os.environ.get("AMCX_TEST_FORCE_COLLECTIVES") == "1"
+
+
 def shard_range(n_frames: int, rank: int, world: int) -> Tuple[int, int]:
     """Half-open frame range of ``rank``; empty ranges are (k, k)."""
     if world < 1 or not 0 <= rank < world:
@@ -49,7 +58,7 @@ def gather_blocks(local: np.ndarray, counts, rank: int, world: int, group=None):
     counts = [int(c) for c in counts]
     if len(counts) != world or local.shape[0] != counts[rank]:
         raise RuntimeError(f"rank {rank} holds {local.shape[0]} rows, expected {counts}")
-    if world == 1:
+    if world == 1 and not collectives_forced():
         return [local]
     import torch
     import torch.distributed as dist
@@ -70,7 +79,7 @@ def gather_blocks(local: np.ndarray, counts, rank: int, world: int, group=None):
 def gather_rows(local: np.ndarray, n_frames: int, rank: int, world: int, group=None) -> Optional[np.ndarray]:
     """Collect every rank's (n_local, 18) block of the contiguous cut (:func:`shard_range`) on rank 0 as
     (n_frames, 18): :func:`gather_blocks` + concatenation.  Returns the full matrix on rank 0 and None elsewhere."""
-    if world == 1:
+    if world == 1 and not collectives_forced():
         return local
     ranges = [shard_range(n_frames, r, world) for r in range(world)]
     lo, hi = ranges[rank]
@@ -105,7 +114,7 @@ def all_gather_rows(local, n_frames: int, rank: int, world: int, group=None):
     per-SNR statistics (amcpy_amd/postprocess.py) -- without a trip through rank 0's host memory: 0.7 GB in all at
     BASELINE configs[3].  Blocks are padded to the common ceil(F / W) rows, as in :func:`gather_rows`."""
     import torch
-    if world == 1:
+    if world == 1 and not collectives_forced():
         return local
     import torch.distributed as dist
     lo, hi = shard_range(n_frames, rank, world)

@@ -158,9 +158,7 @@ def cpu_baseline(max_procs: int | None = None, seconds: float = 10.0):
     return {
         "value": value, "unit": "frames/s", "cores": procs, "kind": "port", "cpu_model": _cpu_model(),
         "one_core_frames_per_s": one_core, "effective_cores": value / one_core,
-        "sample": f"{procs} processes x {wall:.1f} s after warm-up, each cycling over 64 frames of one (mod, SNR) block "
-                  f"of configs[0] ({n_mods} x {n_snr} x {n_frames} x {N} complex128), oracle.calculate_features per "
-                  f"frame: {frames} frames",
+        "sample": f"{procs} procs x {wall:.1f} s, each cycling 64 frames of one (mod,SNR) block of configs[0], oracle.calculate_features per frame: {frames} frames",
         "extrapolated_configs1_seconds": N_MODS * N_SNR * N_FRAMES / value,
     }
 
@@ -218,25 +216,63 @@ def cpu_baseline_reference_shaped(n_threads: int = 8):
     return {
         "value": value, "unit": "frames/s", "cores": min(n_mods, _host_cores()), "kind": "reference-shaped",
         "cpu_model": _cpu_model(),
-        "sample": f"configs[0] whole ({n_mods} x {n_snr} x {n_frames} x {N} complex128): {n_mods} processes x "
-                  f"{n_threads} threads fed by a Queue (feature_extraction.py:58-61,89-97); slowest process "
-                  f"{compute_wall:.1f} s",
+        "sample": f"configs[0] whole: {n_mods} procs x {n_threads} threads on a Queue (feature_extraction.py:58-61,89-97); slowest {compute_wall:.1f} s",
         "extrapolated_configs1_seconds": N_MODS * N_SNR * N_FRAMES / value,
     }
 
 
 # ----------------------------------------------------------------------------
-def _pmc_traffic(frames_per_launch: int, frame_size: int):
-    """(HBM bytes per launch, source file) from the newest committed PMC summary for this frame
-    size, if any -- replayed from profiles/, not measured in this run."""
-    best, src = None, None
-    for p in sorted((REPO / "profiles").glob("*pmc*.json"), key=lambda q: (q.name.split("_")[0], q.name)):   # r1.. < r2.. < r3..
+def _binary_identity(kernel_name: str):
+    """Which GPU program this process runs: SHA-256 of the loaded library's gfx950 code object and of the machine code of
+    `kernel_name` in it (tools/codeobj_gate.py: .hip_fatbin -> clang-offload-bundler; the build is reproducible, so the
+    same sources give the same digests anywhere).  Every committed profile summary carries the same two digests
+    (tools/prof_summary.py): counters are replayed into the line only for the binary they were taken on."""
+    try:
+        import importlib.util
+        from amcpy_amd import _lib
+        spec = importlib.util.spec_from_file_location("codeobj_gate", REPO / "tools" / "codeobj_gate.py")
+        gate = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(gate)
+        lib = _lib.LIB_PATH
+        whole = gate.digests(lib)["code_object_sha256"]
+        per_kernel = gate.kernel_digests(lib)
+        kern = gate.kernel_digest(per_kernel, kernel_name)
+        return {"code_object_sha256": whole, "kernel_sha256": kern, "kernel": kernel_name}
+    except Exception as exc:                               # no llvm tools on this host, ...: nothing is replayed then
+        return {"error": repr(exc)[:200]}
+
+
+def _same_binary(record: dict, ident) -> bool:
+    """A committed measurement belongs to the running binary if the dominant kernel's machine code is the same (a change
+    to another kernel of the library leaves it valid), or the whole code object is."""
+    if not ident or "error" in ident or not isinstance(record, dict):
+        return False
+    if record.get("kernel_sha256") and record.get("kernel_sha256") == ident.get("kernel_sha256"):
+        return True
+    return bool(record.get("code_object_sha256")) and record.get("code_object_sha256") == ident.get("code_object_sha256")
+
+
+def _pmc_traffic(frames_per_launch: int, frame_size: int, ident=None, directory=None):
+    """(HBM bytes per launch, source) from the newest committed PMC summary for this frame size TAKEN ON THIS BINARY
+    (profiles/*pmc*.json carry the digests of the library they were collected on) -- replayed, not measured in this
+    run; (None, reason) when there is none: a kernel change invalidates the replay instead of leaving it in the line."""
+    best, src, stale = None, None, None
+    directory = Path(directory) if directory else REPO / "profiles"
+    for p in sorted(directory.glob("*pmc*.json"), key=lambda q: (q.name.split("_")[0], q.name)):   # r1.. < r2.. < r3..
         try:
             d = json.loads(p.read_text())
-            if d.get("frame_size") == frame_size and d.get("hbm_bytes_per_frame"):
-                best, src = d["hbm_bytes_per_frame"] * frames_per_launch, f"profiles/{p.name}"
         except Exception:
             continue
+        if d.get("frame_size") != frame_size or not d.get("hbm_bytes_per_frame"):
+            continue
+        if _same_binary(d, ident):
+            best, src = d["hbm_bytes_per_frame"] * frames_per_launch, f"profiles/{p.name}"
+        else:
+            stale = p.name
+    if best is None:
+        why = ("no code-object digest for the running library" if not ident or "error" in ident else
+               f"no committed PMC pass was taken on this binary (newest for N = {frame_size}: {stale})")
+        return None, why
     return best, src
 
 
@@ -244,7 +280,7 @@ def _parity_block():
     """Where parity is established -- not a replay of numbers: the live gate is `pytest -m gpu` (the driver runs it), whose
     test_full_snr_grid_against_oracle covers 6 modulations x 26 SNRs x 8 frames at N = 1024 / 2048 / 4096 with zero frames
     beyond the unfloored criterion."""
-    return {"source": "pytest -m gpu (golden fixtures, 26-SNR grid, 1 024-frame full-shard samples); nothing replayed here"}
+    return {"source": "pytest -m gpu; nothing replayed here"}
 
 
 def _committed_json(name: str):
@@ -293,17 +329,13 @@ def h2d_path(dev, frame_size: int = FRAME_SIZE, big: bool = True):
 
     small = FrameRows(_fortran_container(n_snr, n_frames, N), n_snr, n_frames)
     rec = timed(HipEngine(N, dev.index), small, 2 * n_mods)  # the six modulations run_extraction loops over, twice
-    rec["what"] = (f"2 x {n_mods} x ({n_snr}, {n_frames}, {N}) complex128 Fortran-ordered (configs[0] as loadmat returns "
-                   f"it); GBps = container bytes / wall: host threads round + stage planes -> pinned -> H2D -> device "
-                   f"transposition -> kernel -> D2H")
+    rec["what"] = f"2x{n_mods}x({n_snr},{n_frames},{N}) c128 F-order: stage+round->pinned->H2D->transpose->kernel->D2H; GBps = container bytes/wall"
     rec["round_on_device"] = timed(HipEngine(N, dev.index, round_on_device=True), small, 2 * n_mods)
-    rec["round_on_device"]["what"] = "same, doubles over PCIe, rounded on the device"
     if big:
         try:
             rows = FrameRows(_fortran_container(N_SNR, N_FRAMES, N), N_SNR, N_FRAMES)
             rec["configs1_modulation"] = timed(HipEngine(N, dev.index), rows, 2)
-            rec["configs1_modulation"]["what"] = (f"one configs[1] modulation, ({N_SNR}, {N_FRAMES}, {N}) complex128 "
-                                                  f"= {N_SNR * N_FRAMES * N * 16 / 1e9:.2f} GB, twice")
+            rec["configs1_modulation"]["what"] = f"({N_SNR},{N_FRAMES},{N}) c128 = {N_SNR * N_FRAMES * N * 16 / 1e9:.2f} GB, twice"
             del rows
         except Exception as exc:                           # a host short of 3.5 GB: reported, never fatal to the headline
             rec["configs1_modulation"] = {"error": repr(exc)}
@@ -390,26 +422,28 @@ def run_fanout_leg(n_devices: int, share_gpu: bool, frame_size: int, n_frames: i
         return {"error": repr(exc)}
 
 
-def _valu_note(frames_per_s: float):
-    """Secondary bounds of the N = 2048 kernel from this round's committed budget
-    (profiles/r2_wave_budget.json: in-kernel clock, issue slots, ablations -- DESIGN.md 4.6, HISTORY.md 4.3)."""
-    b, name = None, None
-    for name in ("r5_wave_budget.json", "r4_wave_budget.json", "r3_wave_budget.json", "r2_wave_budget.json"):
-        b = _committed_json(name)
-        if b is not None:
-            break
-    if b is None:
-        return None
-    per_frame = b.get("valu_instr_per_frame")
-    out = {"bound": b.get("bound", "board power, then VALU issue"), "valu_instr_per_frame": per_frame,
-           "source": f"profiles/{name} (committed; replayed, not measured in this run)"}
-    if per_frame:
-        out["achieved_Gwaveinstr_per_s"] = per_frame * frames_per_s / 1e9
-    for k in ("in_kernel_clock_GHz", "in_kernel_clock_zeros_GHz", "simd_cycles_per_frame",
-              "valu_issue_slot_use", "frames_per_s_on_zero_data", "frames_per_s_L2_resident"):
-        if k in b:
-            out[k] = b[k]
-    return out
+def _valu_note(frames_per_s: float, ident=None, directory=None):
+    """Secondary bounds of the N = 2048 kernel from the newest committed budget TAKEN ON THIS BINARY
+    (profiles/r*_wave_budget.json: instructions per frame, in-kernel clock, issue slots -- DESIGN.md 4.6); None when the
+    running kernel is not the one the budget was measured on."""
+    directory = Path(directory) if directory else REPO / "profiles"
+    for p in sorted(directory.glob("r*_wave_budget.json"), key=lambda q: q.name, reverse=True):
+        try:
+            b = json.loads(p.read_text())
+        except Exception:
+            continue
+        if not _same_binary(b, ident):
+            continue
+        per_frame = b.get("valu_instr_per_frame")
+        out = {"bound": b.get("bound", "board power, then VALU issue"), "valu_instr_per_frame": per_frame,
+               "source": f"profiles/{p.name} (committed, same kernel digest; replayed)"}
+        if per_frame:
+            out["achieved_Gwaveinstr_per_s"] = per_frame * frames_per_s / 1e9
+        for k in ("in_kernel_clock_GHz", "in_kernel_clock_zeros_GHz", "simd_cycles_per_frame", "valu_issue_slot_use"):
+            if k in b:
+                out[k] = b[k]
+        return out
+    return None
 
 
 def _ensure_library(local_rank: int):
@@ -575,6 +609,8 @@ def main():
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal: ranks take device local_rank %% device_count instead of one GPU each")
     ap.add_argument("--no-fma-probe", action="store_true", help="skip the ~1 s instruction-issue ceiling probe")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the configs[2] (N = 4096) and configs[4] (N = 1024) legs behind the timed region")
     ap.add_argument("--no-fanout", action="store_true", help="N > 1: skip the one-process fan-out upload leg")
     ap.add_argument("--fanout-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--launch-timeout", type=float, default=1500.0,
@@ -747,9 +783,25 @@ def main():
         except Exception as exc:
             fma = {"error": repr(exc)}
 
+    # the other BASELINE frame sizes, driver-timed in the same run (N = 1, the default shape only): configs[2] whole
+    # (6 x 26 x 4096 frames x 4096 samples, 20.9 GB) and one GPU's eighth of configs[4] (3 of 24 modulations x 26 x 4096 x
+    # 1024 samples, 2.6 GB) -- 5 warm + 20 timed launches each, events on the launch stream
+    other = None
+    if rank == 0 and world == 1 and not args.no_other_configs and FS == FRAME_SIZE and args.frames == N_FRAMES and n_mods == N_MODS:
+        del arena
+        arena = None
+        torch.cuda.empty_cache()
+        other = {}
+        for label, fs2, mods2 in (("configs[2]", 4096, 6), ("configs[4]/8", 1024, 3)):
+            try:
+                other[str(fs2)] = _timed_config(torch, synth, features18, dev, rank, fs2, mods2, N_FRAMES, label, _lib)
+            except Exception as exc:                           # never fatal to the headline
+                other[str(fs2)] = {"error": repr(exc)[:200]}
+            torch.cuda.empty_cache()
+
     h2d = None
     if rank == 0 and world == 1 and not args.no_h2d:
-        del arena
+        arena = None
         torch.cuda.empty_cache()
         try:
             h2d = h2d_path(dev, big=not args.no_h2d_big)
@@ -806,8 +858,11 @@ def main():
     mean_launch_s = sum(launch_ms) / len(launch_ms) * 1e-3
     srt = sorted(launch_ms)
     alg_bytes = (8 * FS + 72) * frames_per_launch
-    traffic, traffic_src = _pmc_traffic(frames_per_launch, FS)
+    kname = _lib.kernel_name(FS, _lib.VARIANTS[args.variant])
+    ident = _binary_identity(kname)
+    traffic, traffic_src = _pmc_traffic(frames_per_launch, FS, ident)
     achieved = alg_bytes / mean_launch_s / 1e9
+    short = lambda h: h[:16] if isinstance(h, str) else h     # noqa: E731  (64 bits of a SHA-256 name a build)
     # about 3.5 KB: the driver keeps only the tail of a long line, and round 3's 7 KB `parity` block pushed h2d /
     # wall_incl_d2h_ms out of its record
     rec = {
@@ -821,9 +876,12 @@ def main():
                         f"complex64 per GPU ({_config_label(FS, args.frames, n_mods, world)}), resident in HBM; "
                         f"one launch per step",
             "frames_per_gpu_per_step": frames_per_launch, "frame_size": FS,
-            "kernel": _lib.kernel_name(FS, _lib.VARIANTS[args.variant]),
+            "kernel": kname,
             "sharding": f"frames x{world}, no collective on the data path",
         },
+        # the GPU program that was timed (tools/codeobj_gate.py --print; amcpy_amd/csrc/codeobj.json holds the tree's)
+        "binary": ({"code_object_sha256": short(ident.get("code_object_sha256")), "kernel_sha256": short(ident.get("kernel_sha256"))}
+                   if "error" not in ident else ident),
         "rccl_ranks": rccl_ranks,
         "launcher": ("none" if not launched else
                      "self" if os.environ.get("AMCX_BENCH_SELF_LAUNCHED") == "1" else "external") + f"/{args.dist_backend}",
@@ -837,8 +895,11 @@ def main():
             "frac_at_min": alg_bytes / (srt[0] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             "measured_read_peak_GBps": read_peak,
             "frac_of_measured_read_peak": None if not read_peak else achieved / read_peak,
-            "secondary": _secondary(value / world, fma, brief=world > 1) if FS == FRAME_SIZE else None,
+            # flat, so that a reader that keeps only this object's scalars still has the three BASELINE frame sizes
+            **({} if not other else {f"frac_n{k}": v.get("frac") for k, v in other.items()}),
+            "secondary": _secondary(value / world, fma, brief=world > 1, ident=ident) if FS == FRAME_SIZE else None,
         },
+        **({} if other is None else {"other_configs": other}),
         "wall_incl_d2h_ms": wall_d2h_ms,
         "h2d": h2d,
         "gather": gather,
@@ -853,24 +914,52 @@ def main():
     print(json.dumps(_rounded(rec)), flush=True)
 
 
-def _secondary(frames_per_s_per_gpu: float, fma, brief: bool = False):
-    """The replayed budget of the N = 2048 kernel (profiles/r*_wave_budget.json) plus what THIS run measured: the
-    device's FMA ceiling under the power cap and the kernel's instruction rate (committed VALU instructions per frame x
-    the measured frames/s) against it."""
-    out = _valu_note(frames_per_s_per_gpu)
+def _timed_config(torch, synth, features18, dev, rank, frame_size, n_mods, n_frames, label, _lib, warm=5, steps=20):
+    """One more BASELINE shape, resident in HBM, `warm` untimed + `steps` timed launches bracketed by events on the launch
+    stream: frames/s and the fraction of the HBM roofline, the way the headline's roofline.achieved is formed."""
+    arena = torch.empty((n_mods, N_SNR, n_frames, frame_size), dtype=torch.complex64, device=dev)
+    for mi in range(n_mods):
+        synth.device_frames(synth.MODS6[mi % 6], N_SNR, n_frames, frame_size, device=dev, rank=rank, mod_idx=mi, out=arena[mi])
+    out = torch.empty((n_mods, N_SNR, n_frames, 18), dtype=torch.float32, device=dev)
+    for _ in range(warm):
+        features18(arena, out=out)
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for a, b in ev:
+        a.record()
+        features18(arena, out=out)
+        b.record()
+    torch.cuda.synchronize()
+    ms = [a.elapsed_time(b) for a, b in ev]
+    assert torch.isfinite(out[0, N_SNR // 2, :64]).all()
+    frames = n_mods * N_SNR * n_frames
+    mean_s = sum(ms) / len(ms) * 1e-3
+    gbps = (8 * frame_size + 72) * frames / mean_s / 1e9
+    return {"config": label, "frames_per_s": frames / mean_s, "frac": gbps / HBM_PEAK_GBPS, "achieved_GBps": gbps,
+            "mean_launch_ms": mean_s * 1e3, "frames_per_launch": frames, "kernel": _lib.kernel_name(frame_size),
+            "warm": warm, "steps": steps}
+
+
+def _secondary(frames_per_s_per_gpu: float, fma, brief: bool = False, ident=None, directory=None):
+    """What THIS run measured -- the device's FMA ceiling under the power cap (amcx_probe_fma_rate: 4 waves / SIMD of
+    independent v_fma_f32, 0.5 s to settle + 0.5 s timed) -- and, when a committed budget of the running kernel exists
+    (same machine-code digest), the kernel's own instruction rate against it."""
+    out = _valu_note(frames_per_s_per_gpu, ident, directory)
     if out is not None and brief:                  # a multi-rank line carries per_rank and h2d_fanout instead of the replayed budget
         out = {k: out[k] for k in ("valu_instr_per_frame", "source") if k in out}
-    if out is None or fma is None:
+    if out is None:
+        out = {"replayed": None, "why": "no committed budget of this kernel's machine code"}
+    if fma is None:
         return out
     if "error" in fma:
         out["measured"] = fma
         return out
-    kern = out.get("valu_instr_per_frame", 0) * frames_per_s_per_gpu / 1e9
     ceil = fma["wave_instr_per_s"] / 1e9
-    out["measured"] = {"fma_Gwaveinstr_per_s": ceil, "fma_clock_GHz": fma["clock_GHz"],
-                       "kernel_Gwaveinstr_per_s": kern, "ratio": kern / ceil if ceil else None,
-                       "what": "amcx_probe_fma_rate, this run: 4 waves/SIMD of v_fma_f32, 0.5 s settle + 0.5 s timed; "
-                               "kernel = valu_instr_per_frame x frames/s/GPU"}
+    meas = {"fma_Gwaveinstr_per_s": ceil, "fma_clock_GHz": fma["clock_GHz"]}
+    if out.get("valu_instr_per_frame"):
+        kern = out["valu_instr_per_frame"] * frames_per_s_per_gpu / 1e9
+        meas.update(kernel_Gwaveinstr_per_s=kern, ratio=kern / ceil if ceil else None)
+    out["measured"] = meas
     return out
 
 

@@ -10,6 +10,7 @@ stored float32); the cancellation-dominated cumulants 10, 12-18 within
 those ids by up to 8.5e-3, so plain relative error is
 reported, not asserted, for them.
 """
+import json
 import os
 import textwrap
 from pathlib import Path
@@ -685,6 +686,106 @@ def test_two_ranks_run_extraction_sharded(tmp_path):
         assert a[key].shape == b[key].shape == (2, n_frames, 18)
         diff = np.argwhere(a[key] != b[key])
         assert diff.size == 0, (m, diff[:5], a[key][tuple(diff[0])], b[key][tuple(diff[0])])
+
+
+_NCCL_ONE_RANK_WORKER = """
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["AMCX_REPO"])
+import torch, torch.distributed as dist
+from pathlib import Path
+from amcpy_amd.config import Config, Paths, SignalConfig
+from amcpy_amd.feature_extraction import run_extraction
+from amcpy_amd import sharding
+assert sharding.collectives_forced()
+rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+assert (rank, world) == (0, 1)
+torch.cuda.set_device(local)
+dev = torch.device("cuda", local)
+dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+assert "nccl" in str(dist.get_backend()).lower()
+one = torch.ones(1, dtype=torch.int32, device=dev)
+dist.all_reduce(one)                                                  # the first RCCL collective of the process
+assert int(one.item()) == 1
+# 1. gather_blocks down its DEVICE-TENSOR branch (padded cuda tensors, dist.gather over RCCL) against the host shortcut
+rng = np.random.default_rng(3)
+block = rng.standard_normal((1237, 18)).astype(np.float32)
+block[5, 3] = np.nan
+got = sharding.gather_blocks(block, [1237], 0, 1)
+assert isinstance(got, list) and len(got) == 1 and np.array_equal(got[0].view(np.int32), block.view(np.int32))
+rows = sharding.gather_rows(block, 1237, 0, 1)
+assert rows is not block and np.array_equal(rows.view(np.int32), block.view(np.int32))
+cols = sharding.gather_frame_columns(block[:1236], 2, 618, 0, 1)
+assert np.array_equal(cols.view(np.int32), block[:1236].reshape(2, 618, 18).view(np.int32))
+t = torch.from_numpy(block).to(dev)
+every = sharding.all_gather_rows(t, 1237, 0, 1)                      # all_gather_into_tensor over RCCL
+assert every.is_cuda and every.data_ptr() != t.data_ptr() and torch.equal(every.view(torch.int32), t.view(torch.int32))
+# 2. run_extraction through the multi-rank branch: status words, broadcast of the container's place, the gather
+cfg = Config(paths=Paths(root=Path(os.environ["AMCX_ROOT"])),
+             signals=SignalConfig(snr_values={0: "0", 1: "10"}, num_frames=int(os.environ["AMCX_NFRAMES"]),
+                                  frame_size=int(os.environ["AMCX_FS"])))
+run_extraction(cfg, verbose=False)
+dist.barrier()
+dist.destroy_process_group()
+print("NCCL_ONE_RANK_DONE")
+"""
+
+
+def test_one_rank_nccl_takes_the_collective_path(tmp_path):
+    """What one GPU can exercise of the code the first 8-GPU run will execute.  Every multi-rank run of rounds 1-5 shared
+    the box's one device over gloo: the `nccl` branch of sharding.gather_blocks (cuda tensors, dist.gather over RCCL),
+    all_gather_rows on device tensors and run_extraction's multi-rank branch under an RCCL process group had never run.
+    Here ONE rank under torch.distributed.run with the nccl backend, with the test switch AMCX_TEST_FORCE_COLLECTIVES=1
+    (amcpy_amd/sharding.py: the world == 1 shortcuts are not taken): the collectives run over RCCL on device tensors and
+    the files equal the plain single-process run's bit for bit (reference: feature_extraction.py:89-97 -- its fork/join).
+    Then bench.py as one rank of the launcher: its nccl init, all-reduce, barriers and timing MAX."""
+    import socket
+    import subprocess
+    import sys
+    import scipy.io
+    from amcpy_amd.config import Config, Paths, SignalConfig
+    from amcpy_amd.feature_extraction import run_extraction
+    g = load_npz("extract_roundtrip.npz")
+    fs, n_frames = int(g["frame_size"]), int(g["n_frames"])
+    mods = [str(m) for m in g["mods"]]
+    roots = {k: tmp_path / k for k in ("single", "nccl")}
+    for root in roots.values():
+        cfg = Config(paths=Paths(root=root), signals=SignalConfig(snr_values={0: "0", 1: "10"}, num_frames=n_frames, frame_size=fs))
+        cfg.paths.ensure_dirs()
+        scipy.io.savemat(str(cfg.paths.mat_data / cfg.paths.mat_filename),
+                         {cfg.signals.mat_info[m]: g[f"in_{m}"].astype(np.complex128) for m in mods})
+    run_extraction(Config(paths=Paths(root=roots["single"]),
+                          signals=SignalConfig(snr_values={0: "0", 1: "10"}, num_frames=n_frames, frame_size=fs)), verbose=False)
+    script = tmp_path / "nccl_one_rank.py"
+    script.write_text(_NCCL_ONE_RANK_WORKER)
+
+    def free_port():
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            return s.getsockname()[1]
+
+    repo = str(Path(__file__).resolve().parents[1])
+    env = dict(_launcher_free_env(), AMCX_REPO=repo, AMCX_ROOT=str(roots["nccl"]), AMCX_NFRAMES=str(n_frames), AMCX_FS=str(fs),
+               AMCX_TEST_FORCE_COLLECTIVES="1", PYTHONDONTWRITEBYTECODE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1"]
+    r = subprocess.run(launch + ["--master-port", str(free_port()), str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "NCCL_ONE_RANK_DONE" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    cfg = Config(paths=Paths(root=roots["single"]))
+    for m in mods:
+        a = scipy.io.loadmat(str(roots["single"] / "calculated-features" / f"{m}_features.mat"))
+        b = scipy.io.loadmat(str(roots["nccl"] / "calculated-features" / f"{m}_features.mat"))
+        key = cfg.signals.mat_info[m]
+        assert a[key].shape == b[key].shape == (2, n_frames, 18)
+        assert np.array_equal(a[key].view(np.int32), b[key].view(np.int32)), m
+    # bench.py as the one rank of an external launcher, RCCL backend (the driver's own command line at N = 1 is launcher-free)
+    env_b = dict(_launcher_free_env(), PYTHONDONTWRITEBYTECODE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(launch + ["--master-port", str(free_port()), str(Path(repo) / "bench.py"), "--gpus", "1", "--steps", "3",
+                                 "--warmup", "2", "--frames", "128", "--no-cpu-baseline", "--no-h2d", "--no-d2h", "--no-other-configs"],
+                       env=env_b, capture_output=True, text=True, timeout=600, cwd=repo)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["rccl_ranks"] == 1 and line["launcher"] == "external/nccl" and line["value"] > 0
+    assert line["per_rank"][0]["rank"] == 0 and line["per_rank"][0]["frames"] == 6 * 26 * 128
 
 
 def test_raw_complex64_stream_file(tmp_path):

@@ -1401,12 +1401,64 @@ def test_bench_scaling_block_at_eight_ranks():
     assert [r["rank"] for r in blk["per_rank"]] == list(range(8)) and blk["per_rank"][5]["ms"][0] == 3.9
     text = json.dumps(bench._rounded(blk))
     assert len(text) < 1300, len(text)                      # + ~1.7 KB of an N > 1 line without it + ~0.65 KB of h2d_fanout: under 4 096
-    sec = bench._secondary(200e6, {"wave_instr_per_s": 850e9, "clock_GHz": 2.1})
-    assert sec is not None and abs(sec["measured"]["ratio"] - sec["valu_instr_per_frame"] * 200e6 / 850e9) < 1e-12
-    assert bench._secondary(200e6, {"error": "boom"})["measured"] == {"error": "boom"}
-    assert bench._secondary(200e6, None) == bench._valu_note(200e6)
-    brief = bench._secondary(200e6, {"wave_instr_per_s": 850e9, "clock_GHz": 2.1}, brief=True)
+    # (the replayed half of roofline.secondary: test_replayed_counters_are_bound_to_the_timed_binary)
+    assert bench._secondary(200e6, {"error": "boom"}, ident={"error": "x"})["measured"] == {"error": "boom"}
+
+
+def test_replayed_counters_are_bound_to_the_timed_binary(tmp_path):
+    """roofline.traffic and roofline.secondary are replays of committed profiles -- and only of profiles TAKEN ON THE
+    BINARY THAT IS RUNNING: every summary carries the SHA-256 of the library's gfx950 code object and of the dominant
+    kernel's machine code (tools/prof_summary.py), bench.py computes the same two for the library it loaded
+    (bench._binary_identity) and emits a replay only when they agree -- the kernel's digest (a change to another kernel
+    leaves the profile valid), or the whole code object's.  A mismatching digest gives null and says why; so does a
+    host without the LLVM tools.  (Round 5's line carried the previous binary's counters without a way to tell.)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", REPO / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    ident = bench._binary_identity("amcx_features18_wave_kernel<2048>")
+    assert "error" not in ident and len(ident["code_object_sha256"]) == 64 and len(ident["kernel_sha256"]) == 64, ident
+    committed = json.loads((REPO / "amcpy_amd" / "csrc" / "codeobj.json").read_text())
+    assert ident["code_object_sha256"] == committed["code_object_sha256"]          # the built library is the tree's
+    other = bench._binary_identity("amcx_features18_wave_kernel<4096>")
+    assert other["kernel_sha256"] != ident["kernel_sha256"] and other["code_object_sha256"] == ident["code_object_sha256"]
+
+    def pmc(name, **digests):
+        (tmp_path / name).write_text(json.dumps({"frame_size": 2048, "hbm_bytes_per_frame": 16500.0, **digests}))
+
+    frames = 6 * 26 * 4096
+    # 1. a summary of ANOTHER binary (or one without any digest, as every profile before round 6): nothing is replayed
+    pmc("r5_n2048_pmc_traffic.json")
+    pmc("r6_n2048_pmc_traffic.json", code_object_sha256="0" * 64, kernel_sha256="1" * 64)
+    traffic, why = bench._pmc_traffic(frames, 2048, ident, directory=tmp_path)
+    assert traffic is None and "r6_n2048_pmc_traffic.json" in why
+    # 2. the same kernel inside a library whose other kernels changed: valid
+    pmc("r6b_n2048_pmc_traffic.json", code_object_sha256="0" * 64, kernel_sha256=ident["kernel_sha256"])
+    traffic, src = bench._pmc_traffic(frames, 2048, ident, directory=tmp_path)
+    assert traffic == 16500.0 * frames and src == "profiles/r6b_n2048_pmc_traffic.json"
+    # 3. the whole code object agrees (a summary that names no kernel digest)
+    (tmp_path / "r6b_n2048_pmc_traffic.json").unlink()
+    pmc("r6c_n2048_pmc_traffic.json", code_object_sha256=ident["code_object_sha256"])
+    assert bench._pmc_traffic(frames, 2048, ident, directory=tmp_path)[0] == 16500.0 * frames
+    # 4. no identity (no llvm-objcopy on the host): null, with the reason
+    traffic, why = bench._pmc_traffic(frames, 2048, {"error": "FileNotFoundError"}, directory=tmp_path)
+    assert traffic is None and "digest" in why
+    # the instruction budget behind roofline.secondary: the same rule
+    fma = {"wave_instr_per_s": 850e9, "clock_GHz": 2.1}
+    (tmp_path / "r6_wave_budget.json").write_text(json.dumps({"valu_instr_per_frame": 3400.0, "kernel_sha256": "2" * 64}))
+    sec = bench._secondary(200e6, fma, ident=ident, directory=tmp_path)
+    assert sec["replayed"] is None and "valu_instr_per_frame" not in sec and "ratio" not in sec["measured"]
+    assert sec["measured"]["fma_Gwaveinstr_per_s"] == 850.0                          # what THIS run measured stays
+    (tmp_path / "r6b_wave_budget.json").write_text(json.dumps({"valu_instr_per_frame": 3400.0, "kernel_sha256": ident["kernel_sha256"]}))
+    sec = bench._secondary(200e6, fma, ident=ident, directory=tmp_path)
+    assert abs(sec["measured"]["ratio"] - 3400.0 * 200e6 / 850e9) < 1e-12 and sec["source"].startswith("profiles/r6b_wave_budget.json")
+    brief = bench._secondary(200e6, fma, brief=True, ident=ident, directory=tmp_path)
     assert set(brief) == {"valu_instr_per_frame", "source", "measured"} and brief["measured"]["ratio"] == sec["measured"]["ratio"]
+    # the committed profiles of THIS tree: whatever bench.py would replay now names this binary
+    traffic, src = bench._pmc_traffic(frames, 2048, ident)
+    if traffic is not None:
+        d = json.loads((REPO / src).read_text())
+        assert bench._same_binary(d, ident)
 
 
 def test_numa_mapper_on_a_fake_sysfs_tree(tmp_path):

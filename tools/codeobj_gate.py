@@ -62,6 +62,39 @@ def kernel_digests(lib) -> dict:
         return out
 
 
+def _leaf(name: str) -> str:
+    """`amcx::wave::amcx_features18_wave_kernel<2048>(HIP_vector_type<...> const*, ...)` -> `amcx_features18_wave_kernel<2048>`"""
+    name = name.replace("void ", "").replace("(anonymous namespace)::", "").strip()
+    depth, cut = 0, len(name)
+    for i, ch in enumerate(name):                      # the argument list opens at the first '(' outside template brackets
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            cut = i
+            break
+    name = name[:cut]
+    depth, start = 0, 0
+    for i, ch in enumerate(name):                      # the last '::' outside template brackets
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == ":" and depth == 0 and name[i:i + 2] == "::":
+            start = i + 2
+    return name[start:]
+
+
+def kernel_digest(per_kernel: dict, name: str):
+    """The digest of ONE kernel out of kernel_digests(), by whatever spelling of its name (with or without namespaces,
+    'void', an argument list -- what rocprofv3, the library's amcx_kernel_name and c++filt each print); None if it is
+    not there or ambiguous."""
+    want = _leaf(name)
+    hits = {v for k, v in per_kernel.items() if k and _leaf(k) == want}
+    return hits.pop() if len(hits) == 1 else None
+
+
 def build_rev(rev: str, out: Path) -> None:
     with tempfile.TemporaryDirectory() as d:
         tar = subprocess.run(["git", "-C", str(REPO), "archive", rev, "amcpy_amd", "include"], check=True, capture_output=True).stdout
