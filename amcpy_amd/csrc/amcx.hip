@@ -347,6 +347,17 @@ int amcx_features18_c64_ex(const void* iq_dev, int64_t n_frames, int32_t frame_s
     (void)hipGetLastError();
     ws = nullptr;
   }
+  // Which form ran is otherwise invisible (amcx_kernel_name says amcx_features18_stream_kernel either way, the results
+  // agree to 8e-7): AMCX_VERBOSE=1 says it once per process on stderr when the O(N^2) form is taken.  A caller that
+  // must not fall back hands in its own workspace (amcx_features18_c64_ws), as amcpy_amd.features.features18 does.
+  if (ws == nullptr) {
+    static const bool verbose = [] { const char* t = getenv("AMCX_VERBOSE"); return t != nullptr && t[0] != '\0' && t[0] != '0'; }();
+    static std::atomic<bool> said{false};
+    if (verbose && !said.exchange(true))
+      fprintf(stderr, "amcx: frame_size %d runs the DFT by its definition (O(N^2)): %s; amcx_features18_c64_ws with %lld "
+                      "bytes of workspace selects the FFT form\n", (int)frame_size,
+              cap != hipStreamCaptureStatusNone ? "the stream is being captured" : "hipMallocAsync had no workspace", (long long)want);
+  }
   const int rc = amcx_features18_c64_ws(iq_dev, n_frames, frame_size, row_stride_elems, out_dev, out_row_stride,
                                         hip_stream, variant, ws, ws != nullptr ? want : 0);
   if (ws != nullptr) {
@@ -404,6 +415,9 @@ struct amcx_ctx {
   int graph_next = 0;               // slot the next capture replaces
   int graph_hits = 0, graph_misses = 0;
   bool graphs_ok = true;            // false: capture failed once, or the calls vary too much for a cache of four
+  // calls in flight on this context (a context serves one call at a time; the counter is there so that
+  // amcx_ctx_bind_cpus can refuse to rebuild the staging pool's binding under a running upload)
+  std::atomic<int> in_call{0};
 };
 
 }  // extern "C"
@@ -507,6 +521,11 @@ int ctx_run_strided(amcx_ctx* c, amcx::Source src, int64_t S, int64_t K,
   if (S == 0 || K == 0) return AMCX_OK;
   if (S > (int64_t(1) << 40) / K) return AMCX_EINVAL;
   if ((src.fd < 0 && src.re == nullptr) || (src.fd >= 0 && src.re_off < 0) || out_host == nullptr) return AMCX_EINVAL;
+  struct InCall {
+    std::atomic<int>& n;
+    explicit InCall(std::atomic<int>& c) : n(c) { n.fetch_add(1, std::memory_order_acq_rel); }
+    ~InCall() { n.fetch_sub(1, std::memory_order_acq_rel); }
+  } in_call(c->in_call);
   if (kind < AMCX_SRC_F32_SPLIT) { src.im = nullptr; src.im_off = -1; }
   std::atomic<int> io_error{0};
   src.io_error = &io_error;
@@ -770,6 +789,23 @@ int amcx_ctx_create(int32_t device, amcx_ctx** ctx_out) {
   c->device = device;
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreateWithFlags"); }
+  // Warm the runtime HERE, under the creating thread's own affinity mask: the first pinned allocation and the first
+  // copy on a stream may start HIP / HSA helper threads, and a thread inherits its creator's mask for good.  Left to the
+  // first upload they would be started inside its AffinityGuard window (ctx_run_strided narrows the calling thread to
+  // the device's socket for the duration of a threaded upload) and stay on those CPUs.  Best effort: a failure here
+  // surfaces where the real allocation is made.
+  {
+    void* warm_pin = nullptr;
+    void* warm_dev = nullptr;
+    if (hipHostMalloc(&warm_pin, 4096, hipHostMallocDefault) == hipSuccess && hipMalloc(&warm_dev, 4096) == hipSuccess) {
+      memset(warm_pin, 0, 4096);
+      if (hipMemcpyAsync(warm_dev, warm_pin, 4096, hipMemcpyHostToDevice, c->stream) == hipSuccess)
+        (void)hipStreamSynchronize(c->stream);
+    }
+    if (warm_dev != nullptr) (void)hipFree(warm_dev);
+    if (warm_pin != nullptr) (void)hipHostFree(warm_pin);
+    (void)hipGetLastError();
+  }
   // which CPUs are local to this device: from the kernel's PCI tree, unless AMCX_NUMA=0 (AMCX_SYSFS_ROOT: another tree)
   if (hipDeviceGetPCIBusId(c->pci_bus_id, (int)sizeof c->pci_bus_id, device) != hipSuccess) {
     (void)hipGetLastError();
@@ -796,6 +832,8 @@ int amcx_ctx_bind_cpus(amcx_ctx* ctx, const int32_t* cpus, int32_t n_cpus) {
     if (cpus[i] < 0 || cpus[i] >= CPU_SETSIZE) return AMCX_EINVAL;
     v.push_back((int)cpus[i]);
   }
+  // not while an upload runs on this context: its staging threads are reading the list this call replaces
+  if (ctx->in_call.load(std::memory_order_acquire) != 0) return AMCX_EINVAL;
   ctx->bind_cpus = v;
   if (v.empty()) ctx->numa_node = -1;
   ctx->pool.set_cpus(ctx->bind_cpus);

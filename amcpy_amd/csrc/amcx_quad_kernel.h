@@ -570,10 +570,11 @@ inline hipError_t launch_quad(const float2* iq, int64_t n_frames, int64_t row_st
   // a workgroup's re-run mask covers kMaskFrames frames of its own run: longer inputs (more than 8.4 M frames of
   // 64 KiB at 512 workgroups -- beyond one device's memory unless rows overlap) go as several launches
   int64_t per_launch = full_grid * kMaskFrames;
-  if (const char* t = getenv("AMCX_TEST_QUAD_SPLIT")) {       // tests only: cut at this many frames (any cut is valid; the
-    const long long v = atoll(t);                            // real one needs more frames than a device holds)
-    if (v >= kBatch && v < per_launch) per_launch = v / kBatch * kBatch;
-  }
+  // tests only: cut at this many frames (any cut is valid; the real one needs more frames than a device holds).  Read ONCE
+  // per process (a function-local static: getenv on every launch raced with setenv / putenv from other threads --
+  // Python writes os.environ while DeviceFanOut's threads launch with the GIL released)
+  static const long long test_split = [] { const char* t = getenv("AMCX_TEST_QUAD_SPLIT"); return t ? atoll(t) : 0LL; }();
+  if (test_split >= kBatch && test_split < per_launch) per_launch = test_split / kBatch * kBatch;
   for (int64_t f0 = 0; f0 < n_frames; f0 += per_launch) {
     const int64_t n_here = n_frames - f0 < per_launch ? n_frames - f0 : per_launch;
     const int64_t n_batches = (n_here + kBatch - 1) / kBatch;

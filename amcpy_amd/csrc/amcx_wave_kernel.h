@@ -486,31 +486,48 @@ __device__ __forceinline__ void twisted_dit(float (&re)[LEN], float (&im)[LEN], 
 
 // Register FFT of 128*R points held as xr/xi[2*i+b] (see header); returns this
 // lane's max |X|^2 over the 2R bins it ends up with.
+// In two pieces -- fft_head (the part of pass 1 that comes before the exchange phases) and fft_tail (the phases) -- so that
+// a caller with TWO transforms to run (N = 4096: the sum and the difference branch of the radix-2 split) can put the
+// second one's pass 1, which touches registers only, into the shadows of the first one's LDS round trips: fft_tail calls
+// hook(phase, which) right behind the reads of exchange 1 (which = 0) and of exchange 2 (which = 1) of every phase, before
+// it waits for them.  fft_peak = head + tail without a hook: the one-transform kernels' machine code is what it was.
+struct NoFftHook {
+  template <class G, class W>
+  __device__ __forceinline__ void operator()(G, W) const {}
+};
+
 template <int R>
-__device__ __forceinline__ float fft_peak(const float (&xr)[2 * R], const float (&xi)[2 * R],
-                                          const LaneAddr& la) {
+__device__ __forceinline__ void fft_head(const float (&xr)[2 * R], const float (&xi)[2 * R], float (&v0r)[R], float (&v0i)[R],
+                                         float (&v1r)[R], float (&v1i)[R]) {
   static_assert(R == 8 || R == 16, "1024 or 2048 points (shorter frames: amcx_short_kernel.h)");
-  constexpr int PH = R / 8;                  // exchange phases of 8 k1 values
   // pass 1 (both b groups): plain DFT over the rows, no twiddle (it rides pass 2 and pass 3).
   // With two exchange phases (R = 16) phase g takes the k1 of parity g: after the first
   // decimation-in-frequency stage those are the two independent halves of the register set, so
   // the odd half waits as 8 + 8 complex values while the even half goes through exchange 1,
   // pass 2, exchange 2 and pass 3 -- 32 registers fewer in flight than with both phases' pass-2
   // inputs read before either is processed.
-  float v0r[R], v0i[R], v1r[R], v1i[R];
   static_for<R>([&](auto ii) {
     constexpr int i = decltype(ii)::value;
     v0r[i] = xr[2 * i]; v0i[i] = xi[2 * i]; v1r[i] = xr[2 * i + 1]; v1i[i] = xi[2 * i + 1];
   });
-  if constexpr (PH == 2) {
+  if constexpr (R / 8 == 2) {
     dif_stage<R, 0>(v0r, v0i);
     dif_stage<R, 0>(v1r, v1i);
   }
+}
+
+// kDifDone: the 8-point transforms of pass 1 (dif<8, 8 g> of both b groups) have been done by the caller already
+template <int R, bool kDifDone = false, class Hook = NoFftHook>
+__device__ __forceinline__ float fft_tail(float (&v0r)[R], float (&v0i)[R], float (&v1r)[R], float (&v1i)[R], const LaneAddr& la,
+                                          Hook&& hook = Hook{}) {
+  constexpr int PH = R / 8;                  // exchange phases of 8 k1 values
   float peak = 0.f;
   static_for<PH>([&](auto gg) {
     constexpr int gph = decltype(gg)::value;
-    dif<8, 8 * gph>(v0r, v0i);
-    dif<8, 8 * gph>(v1r, v1i);
+    if constexpr (!kDifDone) {
+      dif<8, 8 * gph>(v0r, v0i);
+      dif<8, 8 * gph>(v1r, v1i);
+    }
     float zr[16], zi[16];
     lds_wave_fence();
     static_for<8>([&](auto kk_) {
@@ -525,6 +542,7 @@ __device__ __forceinline__ float fft_peak(const float (&xr)[2 * R], const float 
       const float2 v = *reinterpret_cast<const float2*>(la.ex1_r + n2 * 32);
       zr[n2] = v.x; zi[n2] = v.y;
     });
+    hook(gg, std::integral_constant<int, 0>{});
     if constexpr (gph == 0) asm volatile("; MARK fft2");
     if constexpr (gph == 0) __builtin_amdgcn_s_setprio(AMCX_PRIO_OF(4));
     __builtin_amdgcn_sched_barrier(0);
@@ -549,6 +567,7 @@ __device__ __forceinline__ float fft_peak(const float (&xr)[2 * R], const float 
         const float2 v = *reinterpret_cast<const float2*>(la.ex2_r + (j * 8 * kEx2StrideK2 + n3) * 8);
         ur[n3] = v.x; ui[n3] = v.y;
       });
+      if constexpr (j == 0) hook(gg, std::integral_constant<int, 1>{});
       twisted_dit<8>(ur, ui, [&](auto ii) {
         return *reinterpret_cast<const float2*>(tw3 + ((gph * 2 + j) * 7 + decltype(ii)::value) * kTw3Row);
       });
@@ -562,6 +581,14 @@ __device__ __forceinline__ float fft_peak(const float (&xr)[2 * R], const float 
   });
   lds_wave_fence();
   return peak;
+}
+
+template <int R>
+__device__ __forceinline__ float fft_peak(const float (&xr)[2 * R], const float (&xi)[2 * R],
+                                          const LaneAddr& la) {
+  float v0r[R], v0i[R], v1r[R], v1i[R];
+  fft_head<R>(xr, xi, v0r, v0i, v1r, v1i);
+  return fft_tail<R>(v0r, v0i, v1r, v1i, la);
 }
 
 // ---------------------------------------------------------------------------
@@ -1041,10 +1068,20 @@ __device__ __forceinline__ void wave_body(
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(AMCX_PRIO_OF(3));
           }
-          float pk4 = fft_peak<R>(sr, si, la);
+          // Two independent transforms, one wave (and only one more on the SIMD): the difference branch's pass 1 --
+          // registers only -- is issued in the shadows of the sum branch's LDS round trips (fft_tail's hook), in three
+          // pieces: the first stage behind the reads of exchange 1 of phase 0, the 8-point transforms of parity 0
+          // behind those of exchange 2, those of parity 1 behind exchange 1 of phase 1.
+          float s0r[R], s0i[R], s1r[R], s1i[R], d0r[R], d0i[R], d1r[R], d1i[R];
+          fft_head<R>(sr, si, s0r, s0i, s1r, s1i);
+          const float pk4 = fft_tail<R>(s0r, s0i, s1r, s1i, la, [&](auto gg, auto ww) {
+            constexpr int g = decltype(gg)::value, w = decltype(ww)::value;
+            if constexpr (g == 0 && w == 0) fft_head<R>(dr, di, d0r, d0i, d1r, d1i);
+            if constexpr (g == 0 && w == 1) { dif<8, 0>(d0r, d0i); dif<8, 0>(d1r, d1i); }
+            if constexpr (g == 1 && w == 0) { dif<8, 8>(d0r, d0i); dif<8, 8>(d1r, d1i); }
+          });
           __builtin_amdgcn_sched_barrier(0);
-          if constexpr (AMCX_PRIO_OF(7) != AMCX_PRIO_OF(4)) __builtin_amdgcn_s_setprio(AMCX_PRIO_OF(7));   // pass 1 of the second FFT
-          return __builtin_fmaxf(pk4, fft_peak<R>(dr, di, la));
+          return __builtin_fmaxf(pk4, fft_tail<R, true>(d0r, d0i, d1r, d1i, la));
         };
         peak = fft4096([&](auto ic) {
           constexpr int i = decltype(ic)::value;

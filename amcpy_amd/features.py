@@ -75,11 +75,23 @@ def features18(iq, out=None, *, frame_size: int | None = None, variant="auto"):
         raise ValueError("out must be uniformly strided with unit stride in the last dimension")
     out_stride = oflat.stride(0) if n_frames > 1 else out.shape[-1]
     lib = _lib.load()
+    v = _variant(variant)
     with torch.cuda.device(iq.device):
         stream = torch.cuda.current_stream(iq.device).cuda_stream
-        _lib.check(lib.amcx_features18_c64_ex(
-            iq.data_ptr(), n_frames, N, row_stride, oflat.data_ptr(), out_stride,
-            stream, _variant(variant)))
+        # The any-size path above 8192 samples wants a workspace for its FFT form (amcx_features18_workspace_bytes: 0 for
+        # every other size).  It comes from TORCH's allocator here -- the allocator that owns this process's device
+        # memory -- through amcx_features18_c64_ws: left to amcx_features18_c64_ex it would come from HIP's own
+        # stream-ordered pool, which knows nothing of what torch has cached, and a failed allocation there silently
+        # selects the O(N^2) form (~100x slower at N = 32767).  torch raises if it cannot provide the bytes.
+        need = int(lib.amcx_features18_workspace_bytes(N, n_frames, v)) if n_frames > 0 else 0
+        if need > 0:
+            ws = torch.empty(need, dtype=torch.uint8, device=iq.device)
+            _lib.check(lib.amcx_features18_c64_ws(iq.data_ptr(), n_frames, N, row_stride, oflat.data_ptr(), out_stride,
+                                                  stream, v, ws.data_ptr(), need))
+            ws.record_stream(torch.cuda.current_stream(iq.device))       # freed for reuse behind the launch, not before
+        else:
+            _lib.check(lib.amcx_features18_c64_ex(
+                iq.data_ptr(), n_frames, N, row_stride, oflat.data_ptr(), out_stride, stream, v))
     return out[..., :_lib.NUM_FEATURES]
 
 

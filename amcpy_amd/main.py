@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import argparse
 import os
+import time
 import sys
 from dataclasses import replace
 from pathlib import Path
@@ -82,11 +83,38 @@ def _run_as_rank(cfg, args) -> None:
     # (torch's own env:// rendezvous: it knows whether the launcher's agent already serves the store -- torch.distributed.run
     # does -- or rank 0 has to)
     store, _, _ = next(dist.rendezvous("env://", rank=rank, world_size=world))
+    # A rank that dies before it has said anything (import error, bad environment) must not hold the others for the
+    # store's default timeout (minutes): the exchange has a minute of its own, and running out of it is an error that
+    # names the ranks that stayed silent.
+    from datetime import timedelta
+    wait_s = float(os.environ.get("AMCX_STATUS_TIMEOUT", "60"))
+    store.set_timeout(timedelta(seconds=wait_s))
     store.set(f"amcx/status/{rank}", problem or "ok")
-    problems = [store.get(f"amcx/status/{r}").decode() for r in range(world)]         # get() waits for the key
-    problems = [q for q in problems if q != "ok"]
+    problems, silent = [], []
+    for r in range(world):
+        try:
+            word = store.get(f"amcx/status/{r}").decode()                            # get() waits for the key
+        except Exception:
+            silent.append(r)
+            continue
+        if word != "ok":
+            problems.append(word)
+    if silent:
+        problems.append(f"rank(s) {silent} reported nothing within {wait_s:.0f} s (died before the rendezvous?)")
+    # Every rank has now read every status: say so before anyone leaves.  Without a launcher rank 0 SERVES the store, and
+    # a rank 0 that exits on a problem while others are still inside store.get() takes the store down under them: they
+    # would die of a connection error instead of printing the collected message.
+    try:
+        store.add("amcx/status/read", 1)
+        if problems and rank == 0:
+            deadline = time.monotonic() + min(wait_s, 30.0)
+            while int(store.add("amcx/status/read", 0)) < world - len(silent) and time.monotonic() < deadline:
+                time.sleep(0.02)
+    except Exception:
+        pass
     if problems:
         raise SystemExit("; ".join(problems))
+    store.set_timeout(timedelta(seconds=1800))                                        # the process group's own default
     torch.cuda.set_device(dev)
     if backend == "nccl":
         dist.init_process_group("nccl", store=store, rank=rank, world_size=world, device_id=torch.device("cuda", dev))

@@ -158,7 +158,10 @@ int amcx_features18_c64_ex(const void* iq_dev, int64_t n_frames, int32_t frame_s
  * 32768 -- and, without one, the DFT by its definition (O(N^2), ~100x slower at 32767; same results within the parity
  * contract).  amcx_features18_c64 / _ex take the workspace from the stream-ordered allocator (hipMallocAsync /
  * hipFreeAsync on hip_stream), except while the stream is being captured into a graph or when the allocator fails:
- * then they run the form that needs none.  amcx_features18_c64_ws takes the caller's: at least
+ * then they run the form that needs none (AMCX_VERBOSE=1 in the environment: one line on stderr, once per process,
+ * when that happens -- the kernel's name and the results do not show which form ran; a caller whose device memory is
+ * owned by another allocator, e.g. torch's caching one, should hand in the workspace itself).
+ * amcx_features18_c64_ws takes the caller's: at least
  * amcx_features18_workspace_bytes(frame_size, n_frames, variant) bytes of device memory (contents undefined before,
  * garbage after; 8-byte aligned; on the current device) for the full number of frames in flight, fewer bytes mean fewer
  * workgroups, less than one workgroup's share (or NULL) the workspace-free form.  _workspace_bytes is 0 for every
@@ -362,11 +365,16 @@ int amcx_probe_fma_rate(double seconds, void* hip_stream, double* wave_instr_per
  *   are local (0 with node -1), the first min(n, cpus_cap) of them in cpus_out (ascending).  A platform that does
  *   not say (numa_node -1, a missing file, a malformed list) is not an error: node -1, no CPUs, nothing gets bound.
  * amcx_ctx_create does this for its device by itself (environment: AMCX_NUMA=0 turns it off, AMCX_SYSFS_ROOT names
- *   another tree); amcx_ctx_bind_cpus replaces the choice (n_cpus = 0: bind nothing).  Bound are: the context's
+ *   another tree); amcx_ctx_bind_cpus replaces the choice (n_cpus = 0: bind nothing; AMCX_EINVAL while a call is
+ *   running on the context: bind between calls).  Bound are: the context's
  *   staging threads, and the CALLING thread for the duration of an upload large enough to use them (its own
  *   affinity mask is restored on return) -- so the pinned slots, allocated on first use inside such a call, are placed
  *   on that node too.  A binding never widens the mask the process was given (cpusets, taskset): CPUs outside it
- *   are dropped, and if none is left nothing is bound.
+ *   are dropped, and if none is left nothing is bound.  A thread that the CALLER's thread creates while such an upload
+ *   runs (from another thread of the same Python process, say) does not inherit the narrowed mask -- only threads created
+ *   BY the calling thread inside that window would, and the library creates none there: its staging threads exist before,
+ *   and amcx_ctx_create warms the HIP runtime (first pinned allocation, first stream copy) so that the runtime's own
+ *   helper threads are started under the creator's mask, not inside the window.
  * amcx_ctx_placement: what a context did.
  */
 typedef struct amcx_placement {

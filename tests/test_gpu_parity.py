@@ -1977,10 +1977,13 @@ def test_the_two_forms_of_the_any_size_path_agree(N, variant):
 
 
 def test_any_size_path_inside_a_graph_capture():
-    """While its stream is being captured amcx_features18_c64_ex allocates nothing: the captured node is the
-    workspace-free form, and replaying the graph gives that form's rows."""
+    """The any-size path while its stream is being captured into a graph.  The C entry amcx_features18_c64_ex allocates
+    nothing then: the captured node is the workspace-free form (the DFT by its definition), and replaying the graph gives
+    that form's rows.  amcpy_amd.features.features18 takes the workspace from TORCH's allocator (round 6: the allocator
+    that owns the device memory, and one that is capture-aware -- the graph keeps the bytes), so the node it captures is
+    the FFT form: the rows of the eager call, bit for bit."""
     torch = _torch()
-    from amcpy_amd import synth
+    from amcpy_amd import _lib, synth
     from amcpy_amd.features import features18
     N = 9000
     x = torch.from_numpy(synth.host_block("QPSK", 10.0, 5, N, seed=77).astype(np.complex64)).cuda()
@@ -1988,10 +1991,13 @@ def test_any_size_path_inside_a_graph_capture():
     features18(x, out=out)                                        # warm (attributes, allocator)
     torch.cuda.synchronize()
     eager = out.clone()
+    lib = _lib.load()
+    # 1. the C entry under capture: no allocation, the workspace-free form
     out.zero_()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
-        features18(x, out=out)
+        _lib.check(lib.amcx_features18_c64_ex(x.data_ptr(), 5, N, N, out.data_ptr(), 18, torch.cuda.current_stream().cuda_stream,
+                                              _lib.VARIANTS["auto"]))
     out.zero_()
     g.replay()
     torch.cuda.synchronize()
@@ -1999,12 +2005,27 @@ def test_any_size_path_inside_a_graph_capture():
     assert np.array_equal(out.cpu().numpy(), direct)
     assert np.array_equal(out.cpu().numpy()[:, 1:], eager.cpu().numpy()[:, 1:])
     assert np.allclose(out.cpu().numpy()[:, 0], eager.cpu().numpy()[:, 0], rtol=2e-6, atol=0)
+    # 2. the torch entry under capture: the workspace comes from the graph's own pool, the FFT form is captured
+    out.zero_()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        features18(x, out=out)
+    out.zero_()
+    g2.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), eager.cpu().numpy())
+    g2.replay()                                                    # ... and again: the workspace is the graph's for its lifetime
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), eager.cpu().numpy())
 
 
-def test_quad_launch_cut_into_several(monkeypatch):
+def test_quad_launch_cut_into_several(tmp_path):
     """launch_quad cuts an input longer than its workgroups' re-run masks cover (8.4 M frames of 64 KiB: more than a device
-    holds) into several launches.  With the cut forced at 52 frames (AMCX_TEST_QUAD_SPLIT) 211 frames go as five launches:
-    same rows as one launch, an out-of-range frame on either side of a cut included."""
+    holds) into several launches.  With the cut forced at 52 frames (AMCX_TEST_QUAD_SPLIT, which the library reads once per
+    process: the cut run is a process of its own) 211 frames go as five launches: same rows as one launch, an
+    out-of-range frame on either side of a cut included."""
+    import subprocess
+    import sys
     from amcpy_amd import synth
     N, F = 8192, 211
     x = synth.host_block("16QAM", 9.0, F, N, seed=4242).astype(np.complex64)
@@ -2012,7 +2033,19 @@ def test_quad_launch_cut_into_several(monkeypatch):
     x[52] *= np.float32(1e-14)
     x[207] *= np.float32(3e12)
     whole = _run(x, "wave")
-    monkeypatch.setenv("AMCX_TEST_QUAD_SPLIT", "52")
-    cut = _run(x, "wave")
+    np.save(tmp_path / "x.npy", x)
+    code = textwrap.dedent(f"""
+        import sys, numpy as np, torch
+        sys.path.insert(0, {str(REPO)!r})
+        from amcpy_amd.features import features18
+        x = torch.from_numpy(np.load({str(tmp_path / 'x.npy')!r})).cuda()
+        y = features18(x, variant="wave")
+        torch.cuda.synchronize()
+        np.save({str(tmp_path / 'cut.npy')!r}, y.cpu().numpy())
+    """)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, AMCX_TEST_QUAD_SPLIT="52", PYTHONDONTWRITEBYTECODE="1"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    cut = np.load(tmp_path / "cut.npy")
     assert np.array_equal(cut, whole, equal_nan=True)
     assert np.isinf(whole[51]).any() and np.isfinite(whole[50]).all()

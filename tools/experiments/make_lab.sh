@@ -16,7 +16,13 @@ LAB_BASE=b5f15f3          # "Product kernels without the laboratory"
 cd "$(dirname "$0")/../.."
 CHECK=0; DIR=tools/experiments/lab
 for a in "$@"; do if [ "$a" = "--check" ]; then CHECK=1; else DIR=$a; fi; done
-rm -rf "$DIR"; mkdir -p "$DIR"
+# DIR is deleted and rebuilt: only ever a directory this script made before (it leaves a marker file in it), never an
+# existing path that happens to be named on the command line (`make_lab.sh amcpy_amd` would have removed the package)
+MARK=.amcx_lab_tree
+if [ -e "$DIR" ] && [ ! -f "$DIR/$MARK" ]; then
+  echo "make_lab.sh: $DIR exists and was not made by this script (no $MARK in it): refusing to delete it" >&2; exit 2
+fi
+rm -rf "$DIR"; mkdir -p "$DIR"; : > "$DIR/$MARK"
 git archive "$LAB_BASE" amcpy_amd include tools/wave_clock.hip tools/wave_stamps.hip tools/ab_lib.sh tools/ab_libs.sh \
     tools/ab_lib_timing.py tools/ab_wave_clock.sh tools/ab_summary.py tools/ab_bench_d2h.sh tools/resource_usage.py bench.py | tar -x -C "$DIR"
 cp tools/experiments/amcx_pair_kernel.h tools/experiments/amcx_fixup_kernel.h "$DIR/amcpy_amd/csrc/"
