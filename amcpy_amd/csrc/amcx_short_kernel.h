@@ -140,13 +140,22 @@ __global__ __launch_bounds__(SCfg<N>::kThreads, SCfg<N>::kWavesPerWG / 4) void a
   float2* const ex2_w = ex + kjL * kKjStride + aL;             // + 4 kc
   const float2* const ex2_r = ex + kjL * kKjStride + 8 * aL;   // kc = 2 h + e, a: + 4 e + a
 
-  // ---- work: passes of four consecutive frames; a wave owns a contiguous run of passes ----
+  // ---- work: passes of four consecutive frames, kBatchPasses of them a batch; wave g of G owns batches g, g + G, g + 2 G, ...
+  // INTERLEAVED, not one contiguous run per wave (round 5): a container holds its frames sorted by modulation and SNR,
+  // the slow paths (exact f5 / f9 of +-pi ties, fp64 moment sums of cancelling cumulants) are taken by 8 % of the frames
+  // of one cell and by none of another, and a wave that owned one cell set the launch's length: +60 % at N = 128 on the
+  // benchmark's data at a flag rate of 0.7 % (profiles/r6_short_interleave_ab.txt).  v: index into the wave's own passes.
   const long long n_pass = (n_frames + kQuad - 1) / kQuad;
   const long long n_waves = (long long)gridDim.x * kWavesPerWG;
-  const long long per = (n_pass + n_waves - 1) / n_waves;
-  const long long p_lo = ((long long)blockIdx.x * kWavesPerWG + wave) * per;
-  long long p_hi = p_lo + per;
-  if (p_hi > n_pass) p_hi = n_pass;
+  const long long gw = (long long)blockIdx.x * kWavesPerWG + wave;
+  const long long n_batches = (n_pass + kBatchPasses - 1) / kBatchPasses;
+  const long long my_batches = n_batches > gw ? (n_batches - gw - 1) / n_waves + 1 : 0;
+  long long my_passes = my_batches * kBatchPasses;
+  if (my_batches > 0 && (my_batches - 1) * n_waves + gw == n_batches - 1) my_passes -= n_batches * kBatchPasses - n_pass;   // the last, short batch
+  auto pass_of = [&](long long v) -> long long {
+    const long long k = v / kBatchPasses;
+    return (k * n_waves + gw) * kBatchPasses + (v - k * kBatchPasses);
+  };
 
   // rows [FIRST, FIRST + COUNT) of this lane's frame of pass p
   auto load_rows = [&](auto first, auto& v, long long p) {
@@ -221,11 +230,11 @@ __global__ __launch_bounds__(SCfg<N>::kThreads, SCfg<N>::kWavesPerWG / 4) void a
   };
 
   v4f nxt[kHead];
-  if (p_lo < p_hi) load_rows(HeadRows{}, nxt, p_lo);
+  if (my_passes > 0) load_rows(HeadRows{}, nxt, pass_of(0));
   int in_batch = 0;                                           // passes whose rows are in the stash
-  long long batch_f0 = p_lo * kQuad;
 
-  for (long long p = p_lo; p < p_hi; ++p) {
+  for (long long v = 0; v < my_passes; ++v) {
+    const long long p = pass_of(v);
     float xr[2 * kRows], xi[2 * kRows];
     if constexpr (kHead < kRows) {                            // the rows that were not requested a pass ahead
       v4f late[kRows - kHead];
@@ -239,7 +248,7 @@ __global__ __launch_bounds__(SCfg<N>::kThreads, SCfg<N>::kWavesPerWG / 4) void a
       constexpr int j = decltype(jj)::value;
       xr[2 * j] = nxt[j].x; xi[2 * j] = nxt[j].y; xr[2 * j + 1] = nxt[j].z; xi[2 * j + 1] = nxt[j].w;
     });
-    if (p + 1 < p_hi) load_rows(HeadRows{}, nxt, p + 1);      // lands behind this pass
+    if (v + 1 < my_passes) load_rows(HeadRows{}, nxt, pass_of(v + 1));   // lands behind this pass
     __builtin_amdgcn_s_setprio(1);
     // ---- the frame times 2^-ex (exact), ex the even-rounded exponent of its largest component: NaNs drop out of the
     // maximum (the sums carry them), an infinite or all-zero frame keeps 0 ----
@@ -373,11 +382,11 @@ __global__ __launch_bounds__(SCfg<N>::kThreads, SCfg<N>::kWavesPerWG / 4) void a
     }
     lds_wave_fence();                                         // the exchange block is free for the next pass
     ++in_batch;
-    if (in_batch == kBatchPasses || p + 1 == p_hi) {
+    if (in_batch == kBatchPasses || v + 1 == my_passes) {
+      const long long batch_f0 = (p - (in_batch - 1)) * kQuad;   // a batch's passes are consecutive
       long long left = n_frames - batch_f0;
       const int count = left < (long long)(in_batch * kQuad) ? (int)left : in_batch * kQuad;
       finalise(batch_f0, count);
-      batch_f0 += (long long)in_batch * kQuad;
       in_batch = 0;
     }
   }

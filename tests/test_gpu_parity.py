@@ -156,6 +156,12 @@ def test_golden_edges(golden_edges):
                 skip[4] = True
             sel = ~np.isnan(r) & ~skip
             assert not np.isnan(o[sel]).any(), (variant, name, o, r)
+            # the kurtoses that are not held to the reference here (rounding noise on a numerically constant series, in the
+            # reference as well) are still held to what a Pearson kurtosis of n values can be at all: NaN (scipy's
+            # degenerate rule) or a number in [1, n]
+            for j, n_vals in ((7, N), (8, N - 1)):
+                if skip[j]:
+                    assert np.isnan(o[j]) or (1.0 - 1e-3 <= o[j] <= n_vals * (1.0 + 1e-3)), (variant, name, j + 1, o[j])
             # cumulants (ids 10-18): 1e-5 of max(|ref|, S) like everywhere else (rounds 1-4 allowed 2e-5 here without a
             # reason; tightened in round 5); ids 1-9: the same plus 2e-6 absolute, because series that are exactly
             # constant in fp64 (zero std) carry fp32 rounding dust of ~1e-7 here

@@ -14,4 +14,11 @@ done
 for f in bench_all_sizes.jsonl bench_default.json wave_clock.txt; do
   [ -f gpurun_out/${TAG}_$f ] && cp gpurun_out/${TAG}_$f profiles/${TAG}_$f
 done
+for f in bench_driver_flags.json bench_all_sizes.txt; do
+  [ -f gpurun_out/${TAG}_$f ] && cp gpurun_out/${TAG}_$f profiles/${TAG}_$f
+done
+# the N = 2048 kernel's instruction budget, bound to the digests of the binary the counters were taken on (bench.py replays
+# it into roofline.secondary only while the running kernel's machine code is the same)
+[ -f profiles/${TAG}_n2048_summary.json ] && [ -f profiles/${TAG}_wave_clock.txt ] && \
+  python3 tools/make_wave_budget.py profiles/${TAG}_n2048_summary.json profiles/${TAG}_wave_clock.txt > profiles/${TAG}_wave_budget.json
 ls -la profiles/${TAG}_n2048_* profiles/${TAG}_bench_default.json

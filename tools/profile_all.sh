@@ -14,6 +14,7 @@ print(f\"trace: feature kernel {k['mean_of_the_timed_launches']/1e3:.1f} us + ra
 done
 bash tools/bench_sizes.sh gpurun_out/${TAG}_bench_all_sizes.jsonl > gpurun_out/${TAG}_bench_all_sizes.txt 2>&1 || exit 1
 cat gpurun_out/${TAG}_bench_all_sizes.txt
+timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_driver_flags.json 2> gpurun_out/${TAG}_bench_driver_flags.err || { tail -5 gpurun_out/${TAG}_bench_driver_flags.err; exit 1; }
 timeout -k 10 400 python3 bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err || { tail -5 gpurun_out/${TAG}_bench_default.err; exit 1; }
 python3 -c "
 import json; d=json.load(open('gpurun_out/${TAG}_bench_default.json')); r=d['roofline']
