@@ -236,13 +236,14 @@ __global__ __launch_bounds__(kThreads, 2) void amcx_features18_quad_kernel(
   la.ex2_w = ex + lane * 8;
   la.ex2_r = ex + (n3L * kEx2StrideK2 + kkL * 8) * 8;
 
-  // ---- work: batches of kBatch frames; workgroup w owns a contiguous run of them ----
+  // ---- work: batches of kBatch frames; workgroup w of G owns batches w, w + G, w + 2 G, ... ----
+  // (interleaved, not one contiguous run per workgroup as in rounds 3-5: the slow paths -- exact f5 / f9 of +-pi ties, fp64
+  //  moment sums of cancelling cumulants -- are taken by several per cent of the frames of one (modulation, SNR) cell
+  //  and by none of another, and a workgroup that owned one cell set the launch's length; amcx_wave_kernel.h, wave_body)
   const long long n_batches = (n_frames + kBatch - 1) / kBatch;
-  const long long per_wg = (n_batches + gridDim.x - 1) / gridDim.x;
-  const long long b0 = (long long)blockIdx.x * per_wg;
-  long long b1 = b0 + per_wg;
-  if (b1 > n_batches) b1 = n_batches;
-  const int n_iters = (int)(b1 > b0 ? b1 - b0 : 0);
+  const long long n_wg = gridDim.x, wg = blockIdx.x;
+  const int n_iters = (int)(n_batches > wg ? (n_batches - wg - 1) / n_wg + 1 : 0);
+  auto first_frame_of = [&](int it) -> long long { return ((long long)it * n_wg + wg) * kBatch; };   // of the workgroup's batch `it`
 
   // the wave with quarter 0: the batch whose stash rows are complete once the next barrier has been passed
   long long pend_f0 = 0;
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(kThreads, 2) void amcx_features18_quad_kernel(
     if constexpr (!RG) {
       const unsigned long long mk = __builtin_amdgcn_ballot_w64(marked);       // bits 0 .. count-1
       if (mk != 0 && lane == 0) {
-        const unsigned rel = (unsigned)(f_first - b0 * kBatch);                // a multiple of kBatch
+        const unsigned rel = (unsigned)((f_first / kBatch - wg) / n_wg) * kBatch;   // the batch's place in this workgroup's own order: a multiple of kBatch
         redo_mask[rel >> 5] |= (unsigned)mk << (rel & 31);                     // this wave is the mask's only writer
         *redo_flag = 1;
       }
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(kThreads, 2) void amcx_features18_quad_kernel(
 
   // frame g of this workgroup's round `it`, if it exists
   auto frame_at = [&](int it, int g, long long& f) -> bool {
-    f = (b0 + it) * kBatch + g;
+    f = first_frame_of(it) + g;
     return it < n_iters && f < n_frames;
   };
   typedef float v4f __attribute__((ext_vector_type(4)));
@@ -459,7 +460,7 @@ __global__ __launch_bounds__(kThreads, 2) void amcx_features18_quad_kernel(
   }
 
   for (int it = 0; it < n_iters; ++it) {
-    const long long f0 = (b0 + it) * kBatch;
+    const long long f0 = first_frame_of(it);
     const long long left = n_frames - f0;
     const int n_here = left < kBatch ? (int)left : kBatch;
     float* const stash = stash_q + (it & 1) * kStashFloats;
@@ -512,18 +513,15 @@ __global__ __launch_bounds__(kThreads, 2) void amcx_features18_quad_kernel(
   // (finalize_features<true>), as the wave kernels do (amcx_wave_kernel.h, rerun_scaled).  A launch leaves every row
   // final; nothing is read back from the result matrix (until round 5 the note was f5 = -inf in the row itself).
   if (__builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile unsigned*>(redo_flag)) != 0) {
-    const long long fa = b0 * kBatch;
-    long long fz = b1 * kBatch;
-    if (fz > n_frames) fz = n_frames;
     float* const stash = stash_q;
-    const int n_words = (int)((fz - fa + 31) >> 5);
+    const int n_words = (n_iters * kBatch + 31) >> 5;         // bit L: frame L % kBatch of the workgroup's batch L / kBatch
     for (int w = 0; w < n_words; ++w) {
       unsigned todo = __builtin_amdgcn_readfirstlane(reinterpret_cast<volatile unsigned*>(redo_mask)[w]);
-      const long long base = fa + 32LL * w;
       while (todo != 0) {
         const int idx = __builtin_ctz(todo);
         todo &= todo - 1;
-        const long long f = base + idx;
+        const int local = 32 * w + idx;
+        const long long f = first_frame_of(local / kBatch) + local % kBatch;
         float xr[2 * kRowsQ], xi[2 * kRowsQ];
         {
           v4f v[kRowsQ];

@@ -783,12 +783,23 @@ def main():
         except Exception as exc:
             fma = {"error": repr(exc)}
 
+    h2d = None
+    if rank == 0 and world == 1 and not args.no_h2d:
+        del arena
+        arena = None
+        torch.cuda.empty_cache()
+        try:
+            h2d = h2d_path(dev, big=not args.no_h2d_big)
+        except Exception as exc:                               # the upload-path leg never takes the headline down with it
+            h2d = {"error": repr(exc)}
+
     # the other BASELINE frame sizes, driver-timed in the same run (N = 1, the default shape only): configs[2] whole
     # (6 x 26 x 4096 frames x 4096 samples, 20.9 GB) and one GPU's eighth of configs[4] (3 of 24 modulations x 26 x 4096 x
     # 1024 samples, 2.6 GB) -- 5 warm + 20 timed launches each, events on the launch stream
     other = None
+    # (AFTER the upload-path leg: freeing the 21 GB configs[2] arena right before it left the driver clearing VRAM on the copy
+    #  engines the uploads use -- 83 instead of 105 GB/s for the configs[1]-sized modulation, 17 instead of 57 for configs[0])
     if rank == 0 and world == 1 and not args.no_other_configs and FS == FRAME_SIZE and args.frames == N_FRAMES and n_mods == N_MODS:
-        del arena
         arena = None
         torch.cuda.empty_cache()
         other = {}
@@ -798,15 +809,6 @@ def main():
             except Exception as exc:                           # never fatal to the headline
                 other[str(fs2)] = {"error": repr(exc)[:200]}
             torch.cuda.empty_cache()
-
-    h2d = None
-    if rank == 0 and world == 1 and not args.no_h2d:
-        arena = None
-        torch.cuda.empty_cache()
-        try:
-            h2d = h2d_path(dev, big=not args.no_h2d_big)
-        except Exception as exc:                               # the upload-path leg never takes the headline down with it
-            h2d = {"error": repr(exc)}
 
     # N > 1: the one cross-rank step of the real path -- rank 0 collecting every rank's (F x 18) block
     # (amcpy_amd/sharding.py: one padded float32 tensor gather; device tensors over RCCL) -- timed once, outside

@@ -46,9 +46,12 @@
  *     1-9 and 11 within 1e-5 relative of the reference's complex128 evaluation stored as float32;
  *     features 10, 12-18 (cumulants whose terms cancel) within 1e-5 of max(|value|, S), S the sum of
  *     the magnitudes of the terms of that cumulant's formula (the reference's own complex64 path is
- *     up to 8.5e-3 off in plain relative terms there).  Over samples of thousands of frames S is floored
- *     at 2e-3 x the summands' scale, >= 99.9 % of the frames meet the unfloored bound and none exceeds
- *     ten times it.
+ *     up to 8.5e-3 off in plain relative terms there).  EVERY frame, whatever the size of the sample: a
+ *     frame one of whose cumulants cancels below what fp32 sums resolve (S < kappa x the first-order
+ *     error scale of that cumulant, kappa = 4e-3 (2048 / N)^(1/3); ~0.7 % of the BASELINE configs' frames)
+ *     is found by the kernel's finaliser and gets its moment sums from an fp64 sweep in the same launch
+ *     (amcx_math.h: cancellation_suspect; until ABI 6's round-6 build samples of thousands of frames were
+ *     held to a floored S with 0.1 % of the frames excepted).
  *   - DEVICE OWNERSHIP: the entry points that take device pointers launch on the calling thread's
  *     CURRENT HIP device.  The buffers and the stream must belong to it: on a multi-GPU node call
  *     hipSetDevice(d) (torch.cuda.set_device / `with torch.cuda.device(d)`) first.  A pointer

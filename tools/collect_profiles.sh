@@ -14,7 +14,7 @@ done
 for f in bench_all_sizes.jsonl bench_default.json wave_clock.txt; do
   [ -f gpurun_out/${TAG}_$f ] && cp gpurun_out/${TAG}_$f profiles/${TAG}_$f
 done
-for f in bench_driver_flags.json bench_all_sizes.txt; do
+for f in bench_driver_flags.json bench_all_sizes.txt bench_block_sizes.txt bench_block_sizes.jsonl; do
   [ -f gpurun_out/${TAG}_$f ] && cp gpurun_out/${TAG}_$f profiles/${TAG}_$f
 done
 # the N = 2048 kernel's instruction budget, bound to the digests of the binary the counters were taken on (bench.py replays

@@ -87,7 +87,13 @@ summary["counters_mean_per_dispatch"] = {n: {c: sum(v) / len(v) for c, v in cs.i
 # HBM traffic per frame for bench.py's roofline.traffic (gfx950: FETCH_SIZE counts 64 B per 128-B
 # request on wide coalesced reads -> x2, MI355X_MICROARCH.md section HBM; both counters are in KiB)
 frames = int(os.environ.get("AMCX_PROFILE_FRAMES", 6 * 26 * 4096))
+# the DOMINANT feature kernel of the profiled command (most time in the trace): a bench run may launch others behind its
+# timed region (other_configs), and their counters must not stand in for the timed kernel's
+_total = {n: v["mean"] * v["n"] for n, v in summary["dispatch_ns"].items() if "amcx_features18" in n}
+_dominant = max(_total, key=_total.get) if _total else None
 for n, cs in summary["counters_mean_per_dispatch"].items():
+    if _dominant is not None and n != _dominant:
+        continue
     if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
         rd, wr = cs["FETCH_SIZE"] * 1024 * 2, cs["WRITE_SIZE"] * 1024
         m = re.search(r"(?:wave|short)_kernel<(\d+)>", n)

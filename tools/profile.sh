@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 # 100 timed launches behind 5 warm-up ones: rocprofv3's plain --stats average (which cannot tell them apart) is then within
 # 0.2 % of the mean over the timed launches that bench.py's events bracket (prof_summary.py reports that mean as well)
 export AMCX_PROFILE_TIMED=100
-BENCH="python3 bench.py --no-cpu-baseline --no-h2d --no-d2h --no-fma-probe --steps 100 --warmup 5 $@"
+BENCH="python3 bench.py --no-cpu-baseline --no-h2d --no-d2h --no-fma-probe --no-other-configs --steps 100 --warmup 5 $@"
 set -x
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/bench_trace.json 2> $OUT/trace.err || exit 1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > /dev/null 2> $OUT/pmc_fetch.err || exit 1

@@ -14,6 +14,16 @@ print(f\"trace: feature kernel {k['mean_of_the_timed_launches']/1e3:.1f} us + ra
 done
 bash tools/bench_sizes.sh gpurun_out/${TAG}_bench_all_sizes.jsonl > gpurun_out/${TAG}_bench_all_sizes.txt 2>&1 || exit 1
 cat gpurun_out/${TAG}_bench_all_sizes.txt
+# the accuracy-first block kernel at two sizes that are not powers of two (Bluestein in LDS; in registers): its cost, for the record
+: > gpurun_out/${TAG}_bench_block_sizes.jsonl
+for N in 1000 5000; do
+  timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-h2d --no-d2h --no-fma-probe --frame-size $N --frames 1024 --warmup 20 --steps 20 >> gpurun_out/${TAG}_bench_block_sizes.jsonl 2>> gpurun_out/${TAG}_bench_block_sizes.err || exit 1
+done
+python3 -c "
+import json
+for line in open('gpurun_out/${TAG}_bench_block_sizes.jsonl'):
+    d = json.loads(line); r = d['roofline']
+    print(f'N={d[\"config\"][\"frame_size\"]:5d} {d[\"config\"][\"kernel\"]:34s} {d[\"value\"]/1e6:8.2f} M frames/s  frac {r[\"frac\"]:.4f}')" | tee gpurun_out/${TAG}_bench_block_sizes.txt
 timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_driver_flags.json 2> gpurun_out/${TAG}_bench_driver_flags.err || { tail -5 gpurun_out/${TAG}_bench_driver_flags.err; exit 1; }
 timeout -k 10 400 python3 bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err || { tail -5 gpurun_out/${TAG}_bench_default.err; exit 1; }
 python3 -c "
