@@ -49,9 +49,12 @@
 // tables is bank-conflict free and addressed as lane_base + immediate.
 //
 // One workgroup per CU.  N <= 512: 768 threads = 12 waves = 3 per SIMD.  N = 1024 and N = 2048: 1024 threads = 16 waves =
-// 4 per SIMD (N = 1024: 128 VGPRs, no spill, no second register set for the next frame -- the other waves cover the load;
-// N = 2048: 128 VGPRs; two lane-dependent values, 12 bytes, are spilled in the prologue: one 32-bit reload per frame at the
-// end of the wave reduction, one 64-bit reload per batch of four: amcpy_amd/csrc/kernel_resources.json; the exchange buffer at its exact 8672 bytes and batches of four frames make
+// 4 per SIMD (N = 1024: 127 VGPRs, no second register set for the next frame -- the other waves cover the load; one fp64
+// value of the per-batch finaliser in scratch since round 6's predicate;
+// N = 2048: 128 VGPRs; two lane-dependent addresses are spilled in the prologue and reloaded once per frame each (at the end of
+// the wave reduction and of the FFT; no load is in flight at either place; forming them per frame instead removed the scratch
+// traffic and cost 0.4 %, profiles/r6_layout_ab.txt), one fp64 value per batch of four in the finaliser:
+// amcpy_amd/csrc/kernel_resources.json; the exchange buffer at its exact 8672 bytes and batches of four frames make
 // the LDS fit): 4.3 % fewer SIMD cycles per frame than with 12 waves, of which the power cap takes 2.5 % back
 // as clock -- +1.2 ... +1.9 % frames/s for the kernel alone, +0.5 % through the library's step (HISTORY.md section 4.1;
 // tools/experiments/r5_lab_branches.patch holds the 12-wave form).
@@ -119,8 +122,8 @@ struct Cfg {
   // frames per interleaved run of a workgroup (wave_body: work distribution)
   static constexpr int kRunFrames = kFramesPerWave;
   // waves per workgroup = waves per CU: 2 per SIMD when the frame alone takes 128 VGPRs (N = 4096),
-  // 4 per SIMD at N = 2048 and N = 1024: the kernels fit 128 VGPRs there (2048: three spilled
-  // dwords, 1024: none -- kernel_resources.json).  N = 2048: the fourth wave hides 4.3 % of the SIMD's cycles, +0.5 %
+  // 4 per SIMD at N = 2048 and N = 1024: the kernels fit 128 VGPRs there (2048: four spilled
+  // dwords, 1024: two -- kernel_resources.json).  N = 2048: the fourth wave hides 4.3 % of the SIMD's cycles, +0.5 %
   // through the library's step in round 3 (profiles/r3_waves16_ab.txt), +2.5 % under wave priority
   // (profiles/r4_wave_priority_ab.txt, section 7).  N = 1024 (round 4): 16 waves AND no second register set, +2.9 %
   // same box through the library (section 8); 16 waves with the prefetch kept spill 37 registers, -2.2 %.
