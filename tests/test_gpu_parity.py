@@ -200,6 +200,66 @@ def test_full_snr_grid_against_oracle(N):
         _assert_parity(_run(x, variant), gold, x, f"full SNR grid N={N} {variant}")
 
 
+@pytest.mark.parametrize("N", [128, 512, 1024, 2048, 4096, 8192, 16384])
+def test_cancelling_cumulants_take_the_fp64_path(N):
+    """Frames built so that whole cumulants cancel: noiseless QPSK at 8 samples per symbol with EXACTLY balanced squares
+    (as many symbols with x^2 = +u as with x^2 = -u: mean x^2 = 0, so C41 = m41 - 3 m20 m21 and C60 vanish up to the
+    little noise added) -- 5 % of a noiseless QPSK cell's frames are like that by chance.  S = sum |terms| of those
+    cumulants is then ~1e-4 of the summands' scale, far below what fp32 sums resolve (~1e-8 of that scale: the bound
+    1e-5 S would be missed by 10x); every throughput kernel's finaliser must flag such a frame (amcx_math.h:
+    cancellation_suspect) and take its moment sums from the fp64 sweep (wave_exact_cumulants).  Checked: the contract
+    1e-5 max(|value|, S) on every frame; that the path was TAKEN (the result is within 2e-7 of S -- ten times tighter
+    than fp32 sums could be -- on the cancelling ids); rows longer than the frame, an output wider than 18 columns; and
+    the same frames at 2^40 and 2^-40 times the amplitude, where the flagged frame is ALSO outside the fp32 sums'
+    range: the re-run on a scaled copy flags it again and the features follow the scaling laws."""
+    torch = _torch()
+    from amcpy_amd.features import features18
+    rng = np.random.default_rng(N)
+    F, sps = 24, 8
+    n_sym = N // sps
+    pts = np.exp(1j * (np.pi / 4 + np.pi / 2 * np.arange(4)))
+    x = np.empty((F, N + 24), np.complex128)
+    for f in range(F):
+        half = n_sym // 2
+        # x^2 = +i e^{2 i phi} for points 0, 2 and -i e^{2 i phi} for points 1, 3: half of the symbols from each pair
+        sym = np.concatenate([rng.choice([0, 2], half), rng.choice([1, 3], n_sym - half)])
+        rng.shuffle(sym)
+        base = np.repeat(pts[sym], sps) * np.exp(1j * rng.uniform(0, 2 * np.pi))
+        noise = (rng.standard_normal(N) + 1j * rng.standard_normal(N)) * 1e-4
+        x[f, :N] = base + noise
+        x[f, N:] = 7.0 + 3.0j                                     # beyond the frame: must not be read
+    x = x.astype(np.complex64)
+    frames = x[:, :N]
+    gold = orc.features18_batch(frames)
+    S = orc.conditioning_scales(frames)
+    assert (S[:, [12, 14]] < 3e-3).all(), S[:, [12, 14]].max(axis=0)      # ids 13 and 15 do cancel: S << the summands' scale (~1 ... 16)
+    xd = torch.from_numpy(x).cuda()
+    out = torch.full((F, 24), -7.0, dtype=torch.float32, device="cuda")
+    features18(xd, out=out, frame_size=N, variant="wave")
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert (got[:, 18:] == -7.0).all()                                    # columns beyond 18 are the caller's
+    plain, scaled = orc.parity_errors(got[:, :18], gold.astype(np.float32), S)
+    print(f"\n[cancelling QPSK N={N}] worst scaled rel per feature:", " ".join(f"{v:.1e}" for v in scaled.max(axis=0)))
+    # ids 4 and 8 are statistics of |x| about its mean, and |x| is constant here up to the 1e-4 of noise: rounding noise in
+    # the reference as well (SURVEY Appendix C, the constant-modulus edge frames); every other id is held to the contract
+    held = [j for j in range(18) if j not in (3, 7)]
+    assert plain[:, [j for j in held if j < 9 or j == 10]].max() <= TOL and scaled[:, held].max() <= TOL, scaled.max(axis=0)
+    # taken, not merely passed: fp32 sums are good to ~1e-8 of the SUMMANDS' scale = 1e-5 ... 1e-4 of such an S
+    assert scaled[:, [12, 14]].max() <= 2e-6, scaled[:, [12, 14]].max(axis=0)
+    # out of the fp32 sums' range AND cancelling: re-run on a scaled copy, flagged again, un-scaled through the laws
+    order = np.array([2, 0, 0, 0, 0, 1, 0.5, 0, 0, 2, 2, 4, 4, 4, 6, 6, 6, 6])
+    for p2 in (40, -40):
+        sc = np.float32(2.0 ** p2)
+        ys = features18(torch.from_numpy(frames * sc).cuda(), variant="wave").cpu().numpy().astype(np.float64)
+        with np.errstate(over="ignore", under="ignore", invalid="ignore"):
+            want = (got[:, :18].astype(np.float64) * float(sc) ** order[None, :]).astype(np.float32)
+        fin = np.isfinite(want) & (np.abs(want) > 1e-30)
+        rel = np.abs(ys.astype(np.float32)[fin] / want[fin] - 1.0)
+        assert rel.max() <= 3e-6, (N, p2, rel.max())
+        assert (np.isinf(want) == np.isinf(ys)).all()
+
+
 def test_variants_agree():
     from amcpy_amd import synth
     x = np.concatenate([synth.host_block(m, 6.0, 5, 2048, seed=5 + i)
