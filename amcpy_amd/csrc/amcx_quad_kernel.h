@@ -60,7 +60,15 @@ constexpr int kOffFlag = kOffMx + kWavesPerQuad * 4;         // != 0: this workg
 constexpr int kMaskWords = 512;
 constexpr long long kMaskFrames = 32LL * kMaskWords;
 constexpr int kOffMask = kOffFlag + 4;
-constexpr int kLdsBytes = kOffMask + kMaskWords * 4;
+// Cancellation list (round 6): bit k = frame k of the workgroup's own order has a cumulant that cancels below what fp32 sums
+// resolve (amcx_math.h: cancellation_suspect).  Same shape and same writer as the re-run mask; the frames on it get their
+// fp64 moment sums from ALL FOUR waves in a pass at the end of the launch -- each wave its quarter, the partial sums
+// through kOffPart -- instead of from the finalising wave alone while the other three wait at the next barrier
+// (that form: -5.8 % against round 5 on the benchmark's data, profiles/r6_quad_cancel_ab.txt).
+constexpr int kOffCFlag = kOffMask + kMaskWords * 4;
+constexpr int kOffCMask = kOffCFlag + 4;
+constexpr int kOffPart = (kOffCMask + kMaskWords * 4 + 7) & ~7;     // [wave][16] doubles
+constexpr int kLdsBytes = kOffPart + kWavesPerQuad * 16 * 8;
 static_assert(kMaskFrames % kBatch == 0 && 32 % kBatch == 0, "a batch's bits never straddle a mask word");
 static_assert(kWGsPerCU * kLdsBytes <= 163840, "two workgroups per CU");
 static_assert(kExchangeBytes <= kRegionBytes && kRoundRows * 1024 <= kRegionBytes, "a wave's region holds a round's rows and its FFT exchange buffer");
@@ -210,8 +218,11 @@ __global__ __launch_bounds__(kThreads, 2) void amcx_features18_quad_kernel(
   float* mx_part = reinterpret_cast<float*>(smem + kOffMx);
   unsigned* const redo_flag = reinterpret_cast<unsigned*>(smem + kOffFlag);
   unsigned* const redo_mask = reinterpret_cast<unsigned*>(smem + kOffMask);
-  if (tid == 0) *redo_flag = 0;
-  for (int w = tid; w < kMaskWords; w += kThreads) redo_mask[w] = 0;
+  unsigned* const cancel_flag = reinterpret_cast<unsigned*>(smem + kOffCFlag);
+  unsigned* const cancel_mask = reinterpret_cast<unsigned*>(smem + kOffCMask);
+  double* const part = reinterpret_cast<double*>(smem + kOffPart);
+  if (tid == 0) { *redo_flag = 0; *cancel_flag = 0; }
+  for (int w = tid; w < kMaskWords; w += kThreads) { redo_mask[w] = 0; cancel_mask[w] = 0; }
 
   // ---- tables of the 2048-point register FFT ----
   constexpr int R = C2::kFftRows;                           // 16
@@ -308,6 +319,12 @@ __global__ __launch_bounds__(kThreads, 2) void amcx_features18_quad_kernel(
         redo_mask[rel >> 5] |= (unsigned)mk << (rel & 31);                     // this wave is the mask's only writer
         *redo_flag = 1;
       }
+      const unsigned long long cm = __builtin_amdgcn_ballot_w64(cancel);       // cancelling cumulants: the pass at the end of the launch
+      if (cm != 0 && lane == 0) {
+        const unsigned rel = (unsigned)((f_first / kBatch - wg) / n_wg) * kBatch;
+        cancel_mask[rel >> 5] |= (unsigned)cm << (rel & 31);
+        *cancel_flag = 1;
+      }
     }
     unsigned long long ties = __builtin_amdgcn_ballot_w64(tie);
     const float sct = RG ? __builtin_bit_cast(float, (127 - ex) << 23) : 1.0f;   // the 2^-ex the frame was multiplied by
@@ -324,11 +341,13 @@ __global__ __launch_bounds__(kThreads, 2) void amcx_features18_quad_kernel(
 #pragma unroll
       for (int j = 0; j < 18; ++j) dst[j] = feat[j];
     }
-    unsigned long long cz = __builtin_amdgcn_ballot_w64(cancel);
-    while (cz != 0) {                                       // a cumulant that cancels below what fp32 sums resolve: ids 10-18 from fp64 sums, over the stored row
-      const int idx = __builtin_ctzll(cz);
-      cz &= cz - 1;
-      wave_exact_cumulants<kN>(iq + (f_first + idx) * row_stride, sct, RG ? ex / 2 : 0, lane, lane == idx, out + (f_first + idx) * out_stride);
+    if constexpr (RG) {                                     // a re-run frame that cancels as well (rare squared): this wave alone, now
+      unsigned long long cz = __builtin_amdgcn_ballot_w64(cancel);
+      while (cz != 0) {
+        const int idx = __builtin_ctzll(cz);
+        cz &= cz - 1;
+        wave_exact_cumulants<kN>(iq + (f_first + idx) * row_stride, sct, ex / 2, lane, lane == idx, out + (f_first + idx) * out_stride);
+      }
     }
   };
 
@@ -557,6 +576,40 @@ __global__ __launch_bounds__(kThreads, 2) void amcx_features18_quad_kernel(
         if (q == 0) finalise(std::true_type{}, f, 1, stash, ex);
         // (the next marked frame's stash rows are written behind ITS barrier (1), which the wave with quarter 0 joins
         //  only after the finaliser above; mx_part is not read by it)
+      }
+    }
+  }
+
+  // ---- cancellation pass: |C20| ... |C63| of the frames on the cancellation list again, from fp64 moment sums ----
+  // All four waves walk the list (the same LDS words behind the barrier that ended the frame loop: the same frames in the
+  // same order in every wave, so the barriers below are common): wave q sweeps quarter q in fp64 (wave_exact_moments), lane 0
+  // of each wave leaves its 15 sums in LDS, the wave with quarter 0 adds the four in a fixed order and overwrites columns 9-17
+  // of the row its finaliser stored (same wave, behind two barriers).  Reference: features.py:46-58, 116-185 in complex128.
+  if (__builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile unsigned*>(cancel_flag)) != 0) {
+    const int n_words = (n_iters * kBatch + 31) >> 5;
+    for (int w = 0; w < n_words; ++w) {
+      unsigned todo = __builtin_amdgcn_readfirstlane(reinterpret_cast<volatile unsigned*>(cancel_mask)[w]);
+      while (todo != 0) {
+        const int idx = __builtin_ctz(todo);
+        todo &= todo - 1;
+        const int local = 32 * w + idx;
+        const long long f = first_frame_of(local / kBatch) + local % kBatch;
+        double t[15];
+        wave_exact_moments<kQuarter>(iq + f * row_stride + q * kQuarter, 1.0f, lane, t);
+        if (lane == 0) {
+#pragma unroll
+          for (int k = 0; k < 15; ++k) part[q * 16 + k] = t[k];
+        }
+        __syncthreads();
+        if (q == 0 && lane == 0) {
+          double u[15];
+#pragma unroll
+          for (int k = 0; k < 15; ++k) u[k] = (part[k] + part[16 + k]) + (part[32 + k] + part[48 + k]);
+          float* const dst = out + f * out_stride;
+          moment_features(u[0], u[1], u[2], u[3], u[4], u[5], u[6], u[7], u[8], u[9], u[10], u[11], u[12], u[13], u[14], (double)kN,
+                          [&](int j, int, double v) { dst[j] = (float)v; });
+        }
+        __syncthreads();                                    // `part` is free for the next frame
       }
     }
   }
