@@ -20,9 +20,13 @@ from amcpy_amd import synth  # noqa: E402
 from amcpy_amd.features import features18  # noqa: E402
 from oracle import iq_features_oracle as orc  # noqa: E402
 
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-per = int(sys.argv[2]) if len(sys.argv) > 2 else 128
-variant = sys.argv[3] if len(sys.argv) > 3 else "wave"
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+N = int(args[0]) if len(args) > 0 else 2048
+per = int(args[1]) if len(args) > 1 else 128
+variant = args[2] if len(args) > 2 else "wave"
+# --device-arena: the frames bench.py times (synth.device_frames, rank 0: the benchmark's own arena, cell by cell) instead of
+# the host generator's; `per` = 4096 is then the whole BASELINE shape
+DEVICE_ARENA = "--device-arena" in sys.argv
 IDS = (10, 12, 13, 14, 15, 16, 17, 18)
 
 
@@ -76,8 +80,15 @@ dev_flags = {k: [] for k in KAPPAS}
 rows = []
 for mi, mod in enumerate(synth.MODS6):
     for si, snr in enumerate(synth.snr_grid(26)):
-        x = synth.host_block(mod, float(snr), per, N, seed=70000 + 100 * mi + si)
-        got = features18(torch.from_numpy(x).cuda(), variant=variant).cpu().numpy().astype(np.float64)
+        if DEVICE_ARENA:
+            if si == 0:
+                cell_block = synth.device_frames(mod, 26, per, N, device=torch.device("cuda", 0), rank=0, mod_idx=mi)
+            xd = cell_block[si]
+            x = xd.cpu().numpy()
+            got = features18(xd, variant=variant).cpu().numpy().astype(np.float64)
+        else:
+            x = synth.host_block(mod, float(snr), per, N, seed=70000 + 100 * mi + si)
+            got = features18(torch.from_numpy(x).cuda(), variant=variant).cpu().numpy().astype(np.float64)
         m = orc.batch_moments(x)
         terms = orc.cumulant_terms(m)
         S = orc.conditioning_scales(x)
@@ -95,7 +106,7 @@ fid, mi, snr, err, gold, S, Sabs, E = R.T
 lim = 1e-5 * np.maximum(gold, S)
 ratio = err / lim
 n_frames = len(synth.MODS6) * 26 * per
-print(f"N={N} variant={variant}: {n_frames} frames")
+print(f"N={N} variant={variant}: {n_frames} frames" + (" of the benchmark's own arena (synth.device_frames, rank 0)" if DEVICE_ARENA else ""))
 for f in IDS:
     k = fid == f
     q = lambda v: " ".join(f"{x:.2e}" for x in np.quantile(v, [0.5, 0.9, 0.99, 0.999, 1.0]))  # noqa: E731
